@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the Pioneer-arm hot path on N MI355X.
+
+One "step" = one pass of the hot path (BulletEnv.step of the reference:
+integrate + FK + reward + TimeLimit + auto-reset + 137-float observation) over
+the whole env batch of a rank, with synthetic actions already resident in HBM.
+N=1 workload = the configuration BASELINE.json's metric is quoted on: 65 536
+Pioneer-arm envs on one GPU.  For N>1 every rank steps its own 65 536-env shard
+(global env ids rank*65536..; no data-path collective — envs are independent),
+so scaling is "weak".  Launch for N>1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_ENV_STEP = 750   # 24 action + 92 state in + 80 state out + 548 obs + 6 reward/flags
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--obs-layout", default="env_major", choices=["env_major", "feature_major"])
+    ap.add_argument("--action-layout", default="env_major", choices=["env_major", "feature_major"])
+    ap.add_argument("--fused", type=int, default=1,
+                    help="steps per kernel launch (1 = pnr_step per step; T>1 = pnr_rollout of T steps)")
+    ap.add_argument("--ring", type=int, default=32, help="obs ring depth (rollout-buffer slices)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--mode", default="kinematic", choices=["kinematic", "dynamic"])
+    return ap.parse_args()
+
+
+def cpu_baseline(n_envs, seconds):
+    """The CPU oracle (a port, float64) timed on this host's cores on a bounded sample."""
+    import numpy as np
+    from oracle import COracle
+    from oracle.binding import ORC_REF
+    cores = os.cpu_count() or 1
+    n = min(n_envs, 65536)
+    orc = COracle(n, seed=0, precision=ORC_REF, auto_reset=True, nthreads=cores)
+    orc.reset(want_obs=False)
+    rng = np.random.RandomState(1234)
+    acts = [(rng.uniform(-1, 1, size=(n, 6)) * orc.a_max).astype(np.float32) for _ in range(4)]
+    import ctypes as C_
+    from oracle.binding import OrcState, _ptr
+    obs = np.empty((n, 137)); rew = np.empty(n); done = np.empty(n, np.uint8); tr = np.empty(n, np.uint8)
+
+    def run(k):
+        t0 = time.perf_counter()
+        for i in range(k):
+            a = acts[i & 3]
+            orc.lib.orc_step_batch(C_.byref(orc.p), orc._sp(), C_.c_int64(n), C_.c_int64(0),
+                                   _ptr(a, C_.c_float), _ptr(obs, C_.c_double), _ptr(rew, C_.c_double),
+                                   _ptr(done, C_.c_uint8), _ptr(tr, C_.c_uint8), None, C_.c_int(cores))
+        return time.perf_counter() - t0
+
+    run(2)
+    probe = run(5) / 5
+    k = max(5, min(5000, int(seconds / max(probe, 1e-6))))
+    dt = run(k)
+    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {k} steps, float64 C oracle (oracle/pnr_oracle.c), OpenMP over envs, {dt:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    from pioneer_amd import PioneerVectorEnv, EngineConfig, _lib
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.envs
+    T = max(1, args.fused)
+    env = PioneerVectorEnv(n, device=dev, seed=0, env_id_offset=rank * n,
+                           engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
+                                                      obs_layout=args.obs_layout,
+                                                      action_layout=args.action_layout, mode=args.mode))
+    env.reset()
+
+    # synthetic inputs, resident in HBM before the timed region
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    amax = torch.from_numpy(env.a_max).to(dev)
+    n_act = max(16, T)
+    if args.action_layout == "env_major":
+        acts = (torch.rand(n_act, n, 6, generator=g, device=dev) * 2 - 1) * amax
+    else:
+        acts = (torch.rand(n_act, 6, n, generator=g, device=dev) * 2 - 1) * amax[:, None]
+    ring = max(args.ring, T)
+    ring -= ring % T
+    obs = torch.empty((ring,) + tuple(env.obs_shape), dtype=torch.float32, device=dev)
+    rew = torch.empty((ring, n), dtype=torch.float32, device=dev)
+    done = torch.empty((ring, n), dtype=torch.uint8, device=dev)
+    trunc = torch.empty((ring, n), dtype=torch.uint8, device=dev)
+
+    lib, h = env.lib, env._h
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    P = lambda t, i: C.c_void_p(t[i].data_ptr())  # noqa: E731
+
+    if T == 1:
+        calls = [(P(acts, i % n_act), P(obs, i % ring), P(rew, i % ring), P(done, i % ring), P(trunc, i % ring))
+                 for i in range(math.lcm(n_act, ring))]
+
+        def run(k):
+            m = len(calls)
+            for i in range(k):
+                a, o, r, d, tr = calls[i % m]
+                rc = lib.pnr_step(h, a, o, r, d, tr, None, sp)
+                if rc:
+                    _lib.check(rc, h)
+    else:
+        nslots = ring // T
+        calls = [(P(acts, 0), P(obs, s * T), P(rew, s * T), P(done, s * T), P(trunc, s * T)) for s in range(nslots)]
+
+        def run(k):
+            assert k % T == 0, "--steps/--warmup must be multiples of --fused"
+            for i in range(k // T):
+                a, o, r, d, tr = calls[i % nslots]
+                rc = lib.pnr_rollout(h, T, a, o, r, d, tr, sp)
+                if rc:
+                    _lib.check(rc, h)
+
+    K, W = args.steps, args.warmup
+    if T > 1:
+        K -= K % T
+        W -= W % T
+    run(W)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)       # torch's current stream == the stream pnr_step launches on
+    run(K)
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_env_steps = float(n) * world * K
+    value = total_env_steps / elapsed
+
+    if rank == 0:
+        launches = K // T
+        launch_ms = ev_ms / launches
+        algo_bytes = BYTES_PER_ENV_STEP * n * T          # per launch
+        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                rec = json.load(open(prof))
+                key = f"{args.mode}:{args.obs_layout}:{n}:{T}"
+                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        kname = "pnr::step_kernel" if args.mode == "kinematic" else "pnr::dyn_step_kernel"
+        out = {
+            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n} Pioneer-arm envs per GPU, physics-only step "
+                                   f"(integrate+FK+reward+TimeLimit(500)+auto-reset+obs[137]), random actions U(-a_max,a_max) resident in HBM",
+                       "envs_per_gpu": n, "total_envs": n * world, "mode": args.mode,
+                       "obs_layout": args.obs_layout, "action_layout": args.action_layout,
+                       "steps_per_launch": T, "obs_ring_slices": ring, "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": launch_ms, "timing": "HIP events on the launch stream around the timed region / launches"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,208 @@
+/*
+ * pioneer_amd.h — C ABI of the MI355X-native Pioneer-arm step/rollout engine.
+ *
+ * The reference (xdralex/pioneer) has no FFI layer: its boundary is the Python
+ * gym.Env protocol of pioneer/envs/pioneer/pioneer_knm_env.py as consumed by
+ * RLlib.  This header is the C-ABI a maintainer would bind in place of that
+ * Python hot path; every entry point names the reference interface it
+ * replaces (file:line, relative to the reference tree).
+ *
+ * Conventions
+ *   - every function returns an int status (PNR_OK == 0, < 0 on error); no
+ *     exceptions cross the boundary; pnr_last_error() gives the message;
+ *   - all I/O buffers are caller-owned DEVICE pointers (plain pointers and
+ *     sizes; no torch types); the library owns only the per-env state;
+ *   - calls are asynchronous on the given HIP stream (passed as void*, i.e.
+ *     a hipStream_t; NULL = the default stream) and never synchronise;
+ *   - a handle is not thread-safe; distinct handles are independent;
+ *   - there is NO CPU backend: pnr_create fails with PNR_ERR_NODEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef PIONEER_AMD_H
+#define PIONEER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNR_ABI_VERSION 1
+
+#define PNR_DOF 6          /* revolute joints of pioneer_knm_6dof.urdf:209-264 */
+#define PNR_OBS_DIM 137    /* pioneer_knm_env.py:194-211 (26 pieces)         */
+#define PNR_STATE_WORDS 24 /* a[6] v[6] r[6] target[3] potential step episode */
+#define PNR_INFO_DIM 4     /* r_pot, r_step, r_done, dist (numeric subset of   */
+                           /* the info dict, pioneer_knm_env.py:167-179)      */
+#define PNR_DYN_STATE_WORDS 36 /* dynamics mode: q[6] qd[6] + 24 params       */
+
+enum pnr_status {
+    PNR_OK = 0,
+    PNR_ERR_INVALID = -1,     /* bad argument (AssertionError in the reference) */
+    PNR_ERR_HIP = -2,         /* a HIP runtime call failed                      */
+    PNR_ERR_NOMEM = -3,
+    PNR_ERR_NODEVICE = -4,    /* no usable gfx950 device                        */
+    PNR_ERR_UNSUPPORTED = -5
+};
+
+/* Memory layout of a [num_envs x F] batch. */
+enum pnr_layout {
+    PNR_ENV_MAJOR = 0,     /* row-major [num_envs][F] — what gym/RLlib see      */
+    PNR_FEATURE_MAJOR = 1  /* [F][num_envs] — coalesced without an LDS transpose */
+};
+
+enum pnr_mode {
+    PNR_MODE_KINEMATIC = 0, /* the reference's live semantics ("parity mode")   */
+    PNR_MODE_DYNAMIC = 1    /* ABA forward dynamics + PD torque tracking         */
+};
+
+/*
+ * Tunables.  Field names and defaults follow PioneerKinematicConfig
+ * (pioneer_knm_env.py:19-34) and SimulationConfig (bullet_env.py:36-44);
+ * max_episode_steps is gym.wrappers.TimeLimit's argument
+ * (pioneer/launch/pioneer_knm_train.py:27).  Fill with pnr_config_default().
+ */
+typedef struct pnr_config {
+    uint32_t struct_size; /* sizeof(pnr_config), checked by pnr_create */
+    uint32_t abi_version; /* PNR_ABI_VERSION */
+
+    /* PioneerKinematicConfig */
+    double max_v_to_r;            /* 2       */
+    double max_a_to_v;            /* 10      */
+    double done_distance;         /* 0.1     */
+    double award_max;             /* 100.0   */
+    double award_done;            /* 5.0     */
+    double award_potential_slope; /* 10.0    */
+    double penalty_step;          /* 1/100   */
+    double target_lo[3];          /* (15,-10,2) */
+    double target_hi[3];          /* (25, 10,6) */
+    double target_radius;         /* 0.2 (visual only in the reference) */
+
+    /* SimulationConfig */
+    double timestep;              /* 1/240 */
+    int32_t frame_skip;           /* 10    */
+    double gravity;               /* 0     */
+
+    /* TimeLimit; 0 disables truncation */
+    int32_t max_episode_steps;    /* 500   */
+
+    /* engine options (no reference counterpart) */
+    int32_t auto_reset;           /* 1: done|truncated envs are re-drawn in-kernel */
+    int32_t obs_layout;           /* enum pnr_layout */
+    int32_t action_layout;        /* enum pnr_layout */
+    int32_t mode;                 /* enum pnr_mode */
+
+    /* dynamics mode only (PD surface of bullet_scene.py:123-155; unpinned) */
+    double pd_kp;                 /* position gain  [torque/rad]         */
+    double pd_kd;                 /* velocity gain  [torque/(rad/s)]     */
+    double torque_limit;          /* |tau| cap; <= 0 = unlimited         */
+    double joint_damping;         /* viscous, URDF default 0             */
+    double joint_friction;        /* Coulomb (smoothed), URDF default 0  */
+    int32_t teleport;             /* 1: reference semantics — q:=r, qd:=0 before the sub-steps */
+    int32_t randomize;            /* 1: per-env link-mass / friction / damping draws at reset  */
+    double rand_mass_lo, rand_mass_hi;         /* scale on every link mass, U(lo,hi) */
+    double rand_friction_lo, rand_friction_hi; /* per-joint Coulomb friction         */
+    double rand_damping_lo, rand_damping_hi;   /* per-joint viscous damping          */
+    double ground_z;              /* contact plane height for the pointer; NaN = no plane */
+    double contact_kp, contact_kd;/* penalty contact stiffness / damping  */
+} pnr_config;
+
+typedef struct pnr_env_s* pnr_handle;
+
+/* Derived per-joint constants of PioneerKinematicEnv.__init__
+ * (pioneer_knm_env.py:56-61, :72, :217-220). */
+typedef struct pnr_constants {
+    float r_lo[PNR_DOF], r_hi[PNR_DOF]; /* joint_limits(), float32 */
+    float v_max[PNR_DOF];               /* max_v_to_r * (r_hi - r_lo) */
+    float a_max[PNR_DOF];               /* max_a_to_v * v_max == action_space bound */
+    double dt;                          /* world.step_time = timestep * frame_skip */
+    double eps;                         /* 1e-5 */
+} pnr_constants;
+
+/* PioneerKinematicConfig() / SimulationConfig() defaults. */
+int pnr_config_default(pnr_config* cfg);
+
+/* Constants derived from a config without creating a device handle. */
+int pnr_get_constants(const pnr_config* cfg, pnr_constants* out);
+
+/*
+ * Replaces PioneerKinematicEnv.__init__ (pioneer_knm_env.py:39-74) +
+ * BulletEnv.__init__/reset_simulator/load_scene (bullet_env.py:66-148) for
+ * num_envs independent envs on HIP device `device_id`.  `env_id_offset` is the
+ * global index of local env 0: the reset RNG is keyed by (seed, global env
+ * id, episode#), so trajectories do not depend on how a batch is sharded
+ * across GPUs.  State is undefined until the first pnr_reset.
+ */
+int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset,
+               int device_id, uint64_t seed, pnr_handle* out);
+
+int pnr_destroy(pnr_handle h);
+
+/* seed(): pioneer_knm_env.py:107-109.  Takes effect at the next reset. */
+int pnr_seed(pnr_handle h, uint64_t seed);
+
+/*
+ * Replaces BulletEnv.reset (bullet_env.py:187-190) + reset_world
+ * (pioneer_knm_env.py:76-105).
+ *   mask        [num_envs] bytes, non-zero = reset this env; NULL = all
+ *   joint_pos   [num_envs][6] env-major float32 or NULL — the reference's
+ *               `joint_positions` override; NULL draws r ~ U(r_lo, r_hi)
+ *   target_pos  [num_envs][3] env-major float32 or NULL — `target_position`
+ *               override; NULL draws target ~ U(target_lo, target_hi)
+ *   obs_out     obs batch in cfg.obs_layout, or NULL; rows of envs that are
+ *               not reset are left untouched
+ */
+int pnr_reset(pnr_handle h, const uint8_t* mask, const float* joint_pos,
+              const float* target_pos, float* obs_out, void* stream);
+
+/*
+ * Replaces BulletEnv.step (bullet_env.py:192-197) = act
+ * (pioneer_knm_env.py:111-182) + observe (:184-211) + TimeLimit.step for every
+ * env of the batch, in one kernel launch.
+ *   actions    [num_envs x 6] float32 in cfg.action_layout
+ *   obs        [num_envs x 137] float32 in cfg.obs_layout
+ *   reward     [num_envs] float32
+ *   done       [num_envs] bytes — the env's own `done` (distance < done_distance)
+ *   truncated  [num_envs] bytes — TimeLimit.truncated (elapsed >= max && !done); may be NULL
+ *   info       [num_envs][4] float32 (r_pot, r_step, r_done, dist) or NULL
+ */
+int pnr_step(pnr_handle h, const float* actions, float* obs, float* reward,
+             uint8_t* done, uint8_t* truncated, float* info, void* stream);
+
+/*
+ * T consecutive steps in ONE launch with open-loop actions (state stays in
+ * registers between steps).  Buffers are the pnr_step ones with a leading
+ * [T] axis: actions [T][N x 6], obs [T][N x 137], reward/done/truncated [T][N].
+ * Same results as T calls of pnr_step.
+ */
+int pnr_rollout(pnr_handle h, int32_t T, const float* actions, float* obs,
+                float* reward, uint8_t* done, uint8_t* truncated, void* stream);
+
+/* observe() without stepping (pioneer_knm_env.py:184-211). */
+int pnr_observe(pnr_handle h, float* obs_out, void* stream);
+
+/*
+ * Raw state for checkpoint / tests, as planar 32-bit words [24][num_envs]:
+ * words 0-5 a, 6-11 v, 12-17 r, 18-20 target, 21 potential (float32),
+ * 22 step_index, 23 episode (uint32).  Device pointers.
+ */
+int pnr_get_state(pnr_handle h, uint32_t* words_out, void* stream);
+int pnr_set_state(pnr_handle h, const uint32_t* words_in, void* stream);
+
+/* Dynamics-mode extra state, planar float32 [36][num_envs]: q[6], qd[6],
+ * link-mass scale[11], friction[6], damping[6], 1 pad.  PNR_ERR_UNSUPPORTED in
+ * kinematic mode. */
+int pnr_get_dyn_state(pnr_handle h, float* words_out, void* stream);
+int pnr_set_dyn_state(pnr_handle h, const float* words_in, void* stream);
+
+int64_t pnr_num_envs(pnr_handle h);
+
+/* Last error message of `h`, or of the calling thread when h == NULL. */
+const char* pnr_last_error(pnr_handle h);
+
+int pnr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIONEER_AMD_H */

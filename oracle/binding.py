@@ -1,0 +1,175 @@
+"""ctypes binding of the C oracle (test infrastructure; see pnr_oracle.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DOF = 6
+OBS = 137
+
+
+def oracle_lib_path() -> str:
+    return os.path.join(_HERE, "libpnr_oracle.so")
+
+
+def build_oracle(force: bool = False) -> str:
+    """Compile libpnr_oracle.so with gcc (a few hundred ms)."""
+    path = oracle_lib_path()
+    srcs = [os.path.join(_HERE, f) for f in
+            ("pnr_oracle.c", "pnr_oracle.h", "pnr_dyn_oracle.c", "pnr_dyn_oracle.h", "Makefile")]
+    stale = (not os.path.exists(path)) or any(
+        os.path.getmtime(s) > os.path.getmtime(path) for s in srcs if os.path.exists(s))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return path
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("max_v_to_r", C.c_double), ("max_a_to_v", C.c_double), ("done_distance", C.c_double),
+        ("award_max", C.c_double), ("award_done", C.c_double),
+        ("award_potential_slope", C.c_double), ("penalty_step", C.c_double),
+        ("target_lo", C.c_double * 3), ("target_hi", C.c_double * 3),
+        ("timestep", C.c_double),
+        ("frame_skip", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("precision", C.c_int32), ("auto_reset", C.c_int32),
+        ("seed", C.c_uint64),
+        ("r_lo", C.c_float * DOF), ("r_hi", C.c_float * DOF),
+        ("v_max", C.c_float * DOF), ("a_max", C.c_float * DOF),
+        ("dt", C.c_double), ("eps", C.c_double),
+    ]
+
+
+class OrcState(C.Structure):
+    _fields_ = [
+        ("a", C.c_float * DOF), ("v", C.c_float * DOF), ("r", C.c_double * DOF),
+        ("r_is_f64", C.c_int32),
+        ("target", C.c_double * 3), ("potential", C.c_double),
+        ("step_index", C.c_uint32), ("episode", C.c_uint32),
+    ]
+
+
+STATE_DTYPE = np.dtype([
+    ("a", np.float32, DOF), ("v", np.float32, DOF), ("r", np.float64, DOF),
+    ("r_is_f64", np.int32), ("_pad", np.int32),
+    ("target", np.float64, 3), ("potential", np.float64),
+    ("step_index", np.uint32), ("episode", np.uint32),
+])
+
+ORC_REF, ORC_DEV = 0, 1
+
+
+def _ptr(arr, ctype):
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class COracle:
+    """Batched CPU oracle.  ``precision``: ORC_REF (reference-exact) or ORC_DEV."""
+
+    def __init__(self, num_envs=1, seed=0, precision=ORC_REF, auto_reset=False,
+                 max_episode_steps=500, env_id_offset=0, nthreads=1, **tunables):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        assert L.orc_sizeof_params() == C.sizeof(OrcParams), "orc_params layout drift"
+        assert L.orc_sizeof_state() == C.sizeof(OrcState) == STATE_DTYPE.itemsize, \
+            "orc_state layout drift"
+        L.orc_potential.restype = C.c_double
+        L.orc_potential.argtypes = [C.POINTER(OrcParams), C.c_double]
+        self.p = OrcParams()
+        L.orc_params_default(C.byref(self.p))
+        for k, v in tunables.items():
+            if k in ("target_lo", "target_hi"):
+                for i in range(3):
+                    getattr(self.p, k)[i] = float(v[i])
+            else:
+                assert hasattr(self.p, k), k
+                setattr(self.p, k, v)
+        self.p.seed = seed
+        self.p.precision = precision
+        self.p.auto_reset = int(auto_reset)
+        self.p.max_episode_steps = max_episode_steps
+        L.orc_params_derive(C.byref(self.p))
+        self.n = int(num_envs)
+        self.off = int(env_id_offset)
+        self.nthreads = int(nthreads)
+        self.state = np.zeros(self.n, dtype=STATE_DTYPE)
+
+    # -- constants ---------------------------------------------------------------
+    @property
+    def r_lo(self): return np.array(self.p.r_lo[:], dtype=np.float32)
+    @property
+    def r_hi(self): return np.array(self.p.r_hi[:], dtype=np.float32)
+    @property
+    def v_max(self): return np.array(self.p.v_max[:], dtype=np.float32)
+    @property
+    def a_max(self): return np.array(self.p.a_max[:], dtype=np.float32)
+    @property
+    def dt(self): return self.p.dt
+
+    def _sp(self):
+        return self.state.ctypes.data_as(C.POINTER(OrcState))
+
+    # -- calls ---------------------------------------------------------------------
+    def fk(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, DOF)
+        out = np.empty((q.shape[0], 3))
+        for i in range(q.shape[0]):
+            self.lib.orc_fk_pointer(_ptr(q[i], C.c_double), _ptr(out[i], C.c_double))
+        return out
+
+    def potential(self, d):
+        return self.lib.orc_potential(C.byref(self.p), float(d))
+
+    def philox(self, ctr, key):
+        c = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+        self.lib.orc_philox4x32_10(c, k, o)
+        return list(o)
+
+    def reset(self, mask=None, joint_pos=None, target_pos=None, want_obs=True):
+        n = self.n
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        jp = None if joint_pos is None else np.ascontiguousarray(joint_pos, dtype=np.float64).reshape(n, DOF)
+        tp = None if target_pos is None else np.ascontiguousarray(target_pos, dtype=np.float64).reshape(n, 3)
+        obs = np.zeros((n, OBS)) if want_obs else None
+        self.lib.orc_reset_batch(C.byref(self.p), self._sp(), C.c_int64(n), C.c_int64(self.off),
+                                 _ptr(m, C.c_uint8), _ptr(jp, C.c_double), _ptr(tp, C.c_double),
+                                 _ptr(obs, C.c_double), C.c_int(self.nthreads))
+        return obs
+
+    def step(self, actions, want_obs=True, want_info=False):
+        n = self.n
+        act = np.ascontiguousarray(actions, dtype=np.float32).reshape(n, DOF)
+        obs = np.empty((n, OBS)) if want_obs else None
+        rew = np.empty(n)
+        done = np.empty(n, dtype=np.uint8)
+        trunc = np.empty(n, dtype=np.uint8)
+        info = np.empty((n, 4)) if want_info else None
+        self.lib.orc_step_batch(C.byref(self.p), self._sp(), C.c_int64(n), C.c_int64(self.off),
+                                _ptr(act, C.c_float), _ptr(obs, C.c_double), _ptr(rew, C.c_double),
+                                _ptr(done, C.c_uint8), _ptr(trunc, C.c_uint8), _ptr(info, C.c_double),
+                                C.c_int(self.nthreads))
+        if want_info:
+            return obs, rew, done, trunc, info
+        return obs, rew, done, trunc
+
+    def observe(self):
+        obs = np.empty((self.n, OBS))
+        for e in range(self.n):
+            self.lib.orc_observe(C.byref(self.p), C.byref(OrcState.from_buffer(self.state, e * STATE_DTYPE.itemsize)),
+                                 _ptr(obs[e], C.c_double))
+        return obs
+
+    # -- engine interchange -----------------------------------------------------------
+    def state_words(self):
+        w = np.empty((24, self.n), dtype=np.uint32)
+        self.lib.orc_state_to_words(self._sp(), C.c_int64(self.n), _ptr(w, C.c_uint32))
+        return w
+
+    def load_state_words(self, w):
+        w = np.ascontiguousarray(w, dtype=np.uint32).reshape(24, self.n)
+        self.lib.orc_state_from_words(self._sp(), C.c_int64(self.n), _ptr(w, C.c_uint32))

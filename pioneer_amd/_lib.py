@@ -1,0 +1,135 @@
+"""ctypes binding of libpioneer_amd.so (the C ABI of include/pioneer_amd.h).
+
+There is no fallback: if the HIP library is missing or a call fails, this
+module raises.  ``build_library()`` compiles it in-tree with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libpioneer_amd.so")
+SOURCES = ["pnr_api.hip", "pnr_device.h", "pnr_dyn.h", "pnr_model.h"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "pioneer_amd.h")
+
+DOF = 6
+OBS_DIM = 137
+STATE_WORDS = 24
+INFO_DIM = 4
+DYN_STATE_WORDS = 36
+
+PNR_OK = 0
+ENV_MAJOR, FEATURE_MAJOR = 0, 1
+MODE_KINEMATIC, MODE_DYNAMIC = 0, 1
+
+
+class PnrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pioneer_amd error {code}: {msg}")
+        self.code = code
+
+
+class PnrConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+        ("max_v_to_r", C.c_double), ("max_a_to_v", C.c_double), ("done_distance", C.c_double),
+        ("award_max", C.c_double), ("award_done", C.c_double),
+        ("award_potential_slope", C.c_double), ("penalty_step", C.c_double),
+        ("target_lo", C.c_double * 3), ("target_hi", C.c_double * 3), ("target_radius", C.c_double),
+        ("timestep", C.c_double), ("frame_skip", C.c_int32), ("gravity", C.c_double),
+        ("max_episode_steps", C.c_int32),
+        ("auto_reset", C.c_int32), ("obs_layout", C.c_int32), ("action_layout", C.c_int32),
+        ("mode", C.c_int32),
+        ("pd_kp", C.c_double), ("pd_kd", C.c_double), ("torque_limit", C.c_double),
+        ("joint_damping", C.c_double), ("joint_friction", C.c_double),
+        ("teleport", C.c_int32), ("randomize", C.c_int32),
+        ("rand_mass_lo", C.c_double), ("rand_mass_hi", C.c_double),
+        ("rand_friction_lo", C.c_double), ("rand_friction_hi", C.c_double),
+        ("rand_damping_lo", C.c_double), ("rand_damping_hi", C.c_double),
+        ("ground_z", C.c_double), ("contact_kp", C.c_double), ("contact_kd", C.c_double),
+    ]
+
+
+class PnrConstants(C.Structure):
+    _fields_ = [
+        ("r_lo", C.c_float * DOF), ("r_hi", C.c_float * DOF),
+        ("v_max", C.c_float * DOF), ("a_max", C.c_float * DOF),
+        ("dt", C.c_double), ("eps", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); the list tests check against include/pioneer_amd.h
+_VP = C.c_void_p
+SIGNATURES = {
+    "pnr_abi_version": (C.c_int, []),
+    "pnr_config_default": (C.c_int, [C.POINTER(PnrConfig)]),
+    "pnr_get_constants": (C.c_int, [C.POINTER(PnrConfig), C.POINTER(PnrConstants)]),
+    "pnr_create": (C.c_int, [C.POINTER(PnrConfig), C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.POINTER(_VP)]),
+    "pnr_destroy": (C.c_int, [_VP]),
+    "pnr_seed": (C.c_int, [_VP, C.c_uint64]),
+    "pnr_reset": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "pnr_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pnr_rollout": (C.c_int, [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pnr_observe": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_get_state": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_set_state": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_get_dyn_state": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_set_dyn_state": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_num_envs": (C.c_int64, [_VP]),
+    "pnr_last_error": (C.c_char_p, [_VP]),
+}
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> pioneer_amd/csrc/libpioneer_amd.so (in-tree)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libpioneer_amd.so")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+           "-o", LIB_PATH, os.path.join(CSRC, "pnr_api.hip")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP library; raise loudly if it is not there (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  pioneer_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pnr_abi_version() != 1:
+        raise ImportError("libpioneer_amd.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(code, handle=None):
+    if code != PNR_OK:
+        msg = load_library().pnr_last_error(handle)
+        raise PnrError(code, msg.decode() if msg else "unknown")

@@ -1,0 +1,124 @@
+"""Configuration dataclasses.
+
+``PioneerKinematicConfig`` / ``SimulationConfig`` / ``RenderConfig`` keep the
+reference's field names and defaults (pioneer/envs/pioneer/pioneer_knm_env.py:19-34,
+pioneer/envs/bullet/bullet_env.py:18-62); ``EngineConfig`` holds the options that
+only exist in this engine.
+"""
+from dataclasses import dataclass
+from typing import Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class PioneerKinematicConfig:
+    max_v_to_r: float = 2       # seconds^-1
+    max_a_to_v: float = 10      # seconds^-1
+
+    done_distance: float = 0.1
+
+    award_max: float = 100.0
+    award_done: float = 5.0
+    award_potential_slope: float = 10.0
+    penalty_step: float = 1 / 100
+
+    target_lo: Tuple[float, float, float] = (15, -10, 2)
+    target_hi: Tuple[float, float, float] = (25, 10, 6)
+    target_radius: float = 0.2
+    target_rgba: Tuple[float, float, float, float] = (1.0, 0.0, 0.0, 0.5)
+
+
+@dataclass
+class SimulationConfig:
+    timestep: float = 1 / 240
+    frame_skip: int = 10
+
+    gravity: float = 0
+
+    self_collision: bool = False
+    collision_parent: bool = True
+
+    @property
+    def frames_per_second(self) -> int:
+        return int(np.round(1 / (self.timestep * self.frame_skip)))
+
+
+@dataclass
+class RenderConfig:
+    camera_target: Tuple[float, float, float] = (0, 0, 0)
+    camera_distance: float = 100.0
+    camera_yaw: float = 120.0
+    camera_pitch: float = -30.0
+    camera_roll: float = 0.0
+    render_width: int = 1280
+    render_height: int = 800
+    projection_fov: float = 30
+    projection_near: float = 0.1
+    projection_far: float = 200.0
+
+
+@dataclass
+class EngineConfig:
+    """Options without a reference counterpart."""
+    max_episode_steps: int = 500        # gym TimeLimit of pioneer_knm_train.py:27; 0 = off
+    auto_reset: bool = True             # re-draw done|truncated envs inside the step kernel
+    obs_layout: str = "env_major"       # "env_major" [N,137] | "feature_major" [137,N]
+    action_layout: str = "env_major"    # "env_major" [N,6]   | "feature_major" [6,N]
+    mode: str = "kinematic"             # "kinematic" (reference semantics) | "dynamic"
+    # dynamics mode
+    pd_kp: float = 4000.0
+    pd_kd: float = 400.0
+    torque_limit: float = 0.0
+    joint_damping: float = 0.0
+    joint_friction: float = 0.0
+    teleport: bool = False
+    randomize: bool = False
+    rand_mass: Tuple[float, float] = (0.5, 1.5)
+    rand_friction: Tuple[float, float] = (0.0, 0.1)
+    rand_damping: Tuple[float, float] = (0.0, 0.1)
+    ground_z: float = float("nan")
+    contact_kp: float = 2000.0
+    contact_kd: float = 50.0
+
+
+_LAYOUTS = {"env_major": _lib.ENV_MAJOR, "feature_major": _lib.FEATURE_MAJOR}
+_MODES = {"kinematic": _lib.MODE_KINEMATIC, "dynamic": _lib.MODE_DYNAMIC}
+
+
+def to_c_config(pioneer: PioneerKinematicConfig, sim: SimulationConfig, engine: EngineConfig) -> _lib.PnrConfig:
+    """Dataclasses -> the C struct, starting from pnr_config_default()."""
+    lib = _lib.load_library()
+    c = _lib.PnrConfig()
+    _lib.check(lib.pnr_config_default(c))
+    assert len(pioneer.target_lo) == 3      # pioneer_knm_env.py:84
+    assert len(pioneer.target_hi) == 3      # pioneer_knm_env.py:85
+    for name in ("max_v_to_r", "max_a_to_v", "done_distance", "award_max", "award_done",
+                 "award_potential_slope", "penalty_step", "target_radius"):
+        setattr(c, name, float(getattr(pioneer, name)))
+    for k in range(3):
+        c.target_lo[k] = float(pioneer.target_lo[k])
+        c.target_hi[k] = float(pioneer.target_hi[k])
+    c.timestep = float(sim.timestep)
+    c.frame_skip = int(sim.frame_skip)
+    c.gravity = float(sim.gravity)
+    if engine.obs_layout not in _LAYOUTS or engine.action_layout not in _LAYOUTS:
+        raise AssertionError(f"layouts must be one of {sorted(_LAYOUTS)}")
+    if engine.mode not in _MODES:
+        raise AssertionError(f"mode must be one of {sorted(_MODES)}")
+    c.max_episode_steps = int(engine.max_episode_steps)
+    c.auto_reset = int(bool(engine.auto_reset))
+    c.obs_layout = _LAYOUTS[engine.obs_layout]
+    c.action_layout = _LAYOUTS[engine.action_layout]
+    c.mode = _MODES[engine.mode]
+    c.pd_kp, c.pd_kd, c.torque_limit = float(engine.pd_kp), float(engine.pd_kd), float(engine.torque_limit)
+    c.joint_damping, c.joint_friction = float(engine.joint_damping), float(engine.joint_friction)
+    c.teleport, c.randomize = int(bool(engine.teleport)), int(bool(engine.randomize))
+    c.rand_mass_lo, c.rand_mass_hi = map(float, engine.rand_mass)
+    c.rand_friction_lo, c.rand_friction_hi = map(float, engine.rand_friction)
+    c.rand_damping_lo, c.rand_damping_hi = map(float, engine.rand_damping)
+    c.ground_z = float(engine.ground_z)
+    c.contact_kp, c.contact_kd = float(engine.contact_kp), float(engine.contact_kd)
+    return c

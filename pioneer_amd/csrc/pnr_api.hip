@@ -1,0 +1,529 @@
+// pnr_api.hip — kernels + C ABI (include/pioneer_amd.h) of the MI355X-native
+// Pioneer-arm engine.  gfx950 only; no CPU fallback.
+//
+// Execution shape: one env per lane, one 64-lane wave per workgroup.  State
+// lives in HBM as six float4 planes [6][n] (24 words per env), so a wave moves
+// each plane with one 1-KiB dwordx4 instruction.  Env-major observations are
+// staged through a [64][137] LDS tile and leave as 16-byte lane-linear stores
+// (a wave's 64 rows are one contiguous 35 KB span); feature-major observations
+// are stored directly.  Envs never interact, so there is no cross-workgroup
+// traffic and block -> XCD placement only matters for L2 residency of the
+// state planes (block b touches the same lines every launch).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/pioneer_amd.h"
+#include "pnr_device.h"
+#include "pnr_dyn.h"
+
+namespace pnr {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------
+// step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps
+// ---------------------------------------------------------------------------------
+template <bool OBS_EM, bool ACT_EM>
+__global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
+{
+    __shared__ __attribute__((aligned(16))) float tile[OBS_EM ? kWave * kObsDim : 4];
+
+    const int lane = threadIdx.x;
+    const long long tile0 = (long long)blockIdx.x * kWave;
+    const long long e = tile0 + lane;
+    const bool valid = e < P.n;
+    const long long n = P.n;
+    const int nvalid = (int)((n - tile0) < kWave ? (n - tile0) : kWave);
+
+    EnvState s;
+    if (valid) {
+        load_state(P.state, n, e, s);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) { s.a[i] = 0.f; s.v[i] = 0.f; s.r[i] = 0.f; }
+        s.tgt[0] = s.tgt[1] = s.tgt[2] = 0.f; s.pot = 0.f; s.step = 0; s.episode = 0;
+    }
+
+    for (int t = 0; t < P.T; ++t) {
+        // -- action of this step ----------------------------------------------------
+        float act[kDof];
+        if (valid) {
+            const float* A = P.actions + (long long)t * n * kDof;
+            if (ACT_EM) {
+                const float2* a2 = reinterpret_cast<const float2*>(A + e * kDof);
+                const float2 x0 = a2[0], x1 = a2[1], x2 = a2[2];
+                act[0] = x0.x; act[1] = x0.y; act[2] = x1.x; act[3] = x1.y; act[4] = x2.x; act[5] = x2.y;
+            } else {
+#pragma unroll
+                for (int i = 0; i < kDof; ++i) act[i] = A[(long long)i * n + e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kDof; ++i) act[i] = 0.f;
+        }
+
+        // -- act(): integrate the PREVIOUS action, then latch the new one -----------
+        s.step += 1;                                                  // bullet_env.py:193
+#pragma unroll
+        for (int i = 0; i < kDof; ++i)
+            integrate_joint(s.a[i], s.v[i], s.r[i], P.v_max[i], P.r_lo[i], P.r_hi[i],
+                            P.dt, P.eps, s.v[i], s.r[i]);
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) s.a[i] = act[i];               // :144 (quirk Q1)
+
+        Pose q;
+        compute_pose(s, q);
+
+        // -- reward block, pioneer_knm_env.py:157-165 -----------------------------------
+        const float old_pot = s.pot;
+        const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
+        const bool done = q.dist < P.done_dist;                       // :160
+        const float r_pot = pot - old_pot;
+        const float r_step = -P.penalty;
+        const float r_done = done ? P.award_done : 0.0f;
+        const float rw = (r_pot + r_step) + r_done;                   // :165
+        s.pot = pot;
+        // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
+        const bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
+
+        if (valid) {
+            const long long o = (long long)t * n + e;
+            P.reward[o] = rw;
+            P.done[o] = (uint8_t)done;
+            if (P.trunc) P.trunc[o] = (uint8_t)trunc;
+            if (P.info) reinterpret_cast<float4*>(P.info)[o] = make_float4(r_pot, r_step, r_done, q.dist);
+        }
+
+        // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
+        if (P.auto_reset && (done || trunc)) {
+            reset_env(P, s, P.env_off + (unsigned long long)e, nullptr, nullptr);
+            compute_pose(s, q);
+        }
+
+        // -- observe() ----------------------------------------------------------------
+        float* obs_t = P.obs + (long long)t * n * kObsDim;
+        if (OBS_EM) {
+            if (t > 0) __syncthreads();   // previous flush done before the tile is rewritten
+            SinkLdsTile sink{tile + lane * kObsDim};
+            emit_obs(P, s, q, sink);
+            __syncthreads();
+            flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
+        } else {
+            SinkFeatureMajor sink{obs_t + e, n, valid};
+            emit_obs(P, s, q, sink);
+        }
+    }
+
+    if (valid) store_state(P.state, n, e, s);
+}
+
+// ---------------------------------------------------------------------------------
+// reset / observe kernel.  MODE 0: reset (mask / overrides), 1: observe only.
+// OBS: 0 none, 1 feature-major, 2 env-major via LDS tile (all rows written),
+//      3 env-major direct rows (masked reset).
+// ---------------------------------------------------------------------------------
+template <int MODE, int OBS>
+__global__ __launch_bounds__(kWave) void reset_kernel(const KParams P)
+{
+    __shared__ __attribute__((aligned(16))) float tile[OBS == 2 ? kWave * kObsDim : 4];
+    const int lane = threadIdx.x;
+    const long long tile0 = (long long)blockIdx.x * kWave;
+    const long long e = tile0 + lane;
+    const long long n = P.n;
+    const bool valid = e < n;
+    const int nvalid = (int)((n - tile0) < kWave ? (n - tile0) : kWave);
+
+    EnvState s;
+    bool active = valid;
+    if (valid) {
+        load_state(P.state, n, e, s);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) { s.a[i] = 0.f; s.v[i] = 0.f; s.r[i] = 0.f; }
+        s.tgt[0] = s.tgt[1] = s.tgt[2] = 0.f; s.pot = 0.f; s.step = 0; s.episode = 0;
+    }
+    if (MODE == 0) {
+        if (valid && P.mask) active = P.mask[e] != 0;
+        if (active) {
+            reset_env(P, s, P.env_off + (unsigned long long)e,
+                      P.joint_pos ? P.joint_pos + e * kDof : nullptr,
+                      P.target_pos ? P.target_pos + e * 3 : nullptr);
+            store_state(P.state, n, e, s);
+        }
+    }
+    if (OBS != 0) {
+        Pose q;
+        compute_pose(s, q);
+        if (OBS == 1) {
+            SinkFeatureMajor sink{P.obs + e, n, active};
+            emit_obs(P, s, q, sink);
+        } else if (OBS == 2) {
+            SinkLdsTile sink{tile + lane * kObsDim};
+            emit_obs(P, s, q, sink);
+            __syncthreads();
+            flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
+        } else {
+            SinkRowDirect sink{P.obs + e * kObsDim, active};
+            emit_obs(P, s, q, sink);
+        }
+    }
+}
+
+// planar words [24][n] <-> float4 planes [6][n]
+__global__ void state_to_words_kernel(const float4* __restrict__ st, uint32_t* __restrict__ w, long long n)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+#pragma unroll
+    for (int p = 0; p < kStatePlanes; ++p) {
+        const float4 v = st[p * n + e];
+        w[(4 * p + 0) * n + e] = __float_as_uint(v.x);
+        w[(4 * p + 1) * n + e] = __float_as_uint(v.y);
+        w[(4 * p + 2) * n + e] = __float_as_uint(v.z);
+        w[(4 * p + 3) * n + e] = __float_as_uint(v.w);
+    }
+}
+
+__global__ void words_to_state_kernel(float4* __restrict__ st, const uint32_t* __restrict__ w, long long n)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+#pragma unroll
+    for (int p = 0; p < kStatePlanes; ++p) {
+        st[p * n + e] = make_float4(__uint_as_float(w[(4 * p + 0) * n + e]), __uint_as_float(w[(4 * p + 1) * n + e]),
+                                    __uint_as_float(w[(4 * p + 2) * n + e]), __uint_as_float(w[(4 * p + 3) * n + e]));
+    }
+}
+
+}  // namespace pnr
+
+// =====================================================================================
+// host side
+// =====================================================================================
+using namespace pnr;
+
+struct pnr_env_s {
+    pnr_config cfg;
+    pnr_constants k;
+    KParams base;        // constants pre-filled; pointers set per call
+    long long n;
+    unsigned long long env_off;
+    int device;
+    float4* state;
+    float4* dyn;         // dynamics-mode planes or null
+    char err[512];
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(pnr_handle h, int code, const char* fmt, ...)
+{
+    char* dst = h ? h->err : g_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    if (h) { strncpy(g_err, h->err, sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(h, PNR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
+    } while (0)
+
+// RAII current-device switch: launches and allocations go to the handle's device.
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) { switched = hipSetDevice(dev) == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+extern "C" {
+
+int pnr_abi_version(void) { return PNR_ABI_VERSION; }
+
+int pnr_config_default(pnr_config* c)
+{
+    if (!c) return fail(nullptr, PNR_ERR_INVALID, "pnr_config_default: null config");
+    memset(c, 0, sizeof(*c));
+    c->struct_size = (uint32_t)sizeof(pnr_config);
+    c->abi_version = PNR_ABI_VERSION;
+    // PioneerKinematicConfig, pioneer_knm_env.py:19-34
+    c->max_v_to_r = 2; c->max_a_to_v = 10; c->done_distance = 0.1;
+    c->award_max = 100.0; c->award_done = 5.0; c->award_potential_slope = 10.0;
+    c->penalty_step = 1.0 / 100;
+    c->target_lo[0] = 15; c->target_lo[1] = -10; c->target_lo[2] = 2;
+    c->target_hi[0] = 25; c->target_hi[1] = 10; c->target_hi[2] = 6;
+    c->target_radius = 0.2;
+    // SimulationConfig, bullet_env.py:36-41
+    c->timestep = 1.0 / 240; c->frame_skip = 10; c->gravity = 0;
+    c->max_episode_steps = 500;  // pioneer_knm_train.py:27
+    c->auto_reset = 1;
+    c->obs_layout = PNR_ENV_MAJOR; c->action_layout = PNR_ENV_MAJOR;
+    c->mode = PNR_MODE_KINEMATIC;
+    // dynamics mode (no reference values)
+    c->pd_kp = 4000.0; c->pd_kd = 400.0; c->torque_limit = 0.0;
+    c->joint_damping = 0.0; c->joint_friction = 0.0;
+    c->teleport = 0; c->randomize = 0;
+    c->rand_mass_lo = 0.5; c->rand_mass_hi = 1.5;
+    c->rand_friction_lo = 0.0; c->rand_friction_hi = 0.1;
+    c->rand_damping_lo = 0.0; c->rand_damping_hi = 0.1;
+    c->ground_z = NAN; c->contact_kp = 2000.0; c->contact_kd = 50.0;
+    return PNR_OK;
+}
+
+static int check_config(const pnr_config* c)
+{
+    if (!c) return fail(nullptr, PNR_ERR_INVALID, "null config");
+    if (c->struct_size != sizeof(pnr_config) || c->abi_version != PNR_ABI_VERSION)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_config size/version mismatch (got %u/%u, want %zu/%d)",
+                    c->struct_size, c->abi_version, sizeof(pnr_config), PNR_ABI_VERSION);
+    if (!(c->timestep > 0) || c->frame_skip < 1)
+        return fail(nullptr, PNR_ERR_INVALID, "timestep must be > 0 and frame_skip >= 1");
+    if (c->obs_layout != PNR_ENV_MAJOR && c->obs_layout != PNR_FEATURE_MAJOR)
+        return fail(nullptr, PNR_ERR_INVALID, "bad obs_layout %d", c->obs_layout);
+    if (c->action_layout != PNR_ENV_MAJOR && c->action_layout != PNR_FEATURE_MAJOR)
+        return fail(nullptr, PNR_ERR_INVALID, "bad action_layout %d", c->action_layout);
+    if (c->mode != PNR_MODE_KINEMATIC && c->mode != PNR_MODE_DYNAMIC)
+        return fail(nullptr, PNR_ERR_INVALID, "bad mode %d", c->mode);
+    if (c->max_episode_steps < 0) return fail(nullptr, PNR_ERR_INVALID, "max_episode_steps < 0");
+    for (int k = 0; k < 3; ++k)
+        if (!(c->target_hi[k] >= c->target_lo[k]))
+            return fail(nullptr, PNR_ERR_INVALID, "target_hi[%d] < target_lo[%d]", k, k);
+    return PNR_OK;
+}
+
+int pnr_get_constants(const pnr_config* c, pnr_constants* out)
+{
+    int rc = check_config(c);
+    if (rc) return rc;
+    if (!out) return fail(nullptr, PNR_ERR_INVALID, "pnr_get_constants: null out");
+    for (int i = 0; i < kDof; ++i) {
+        // joint_limits(): float32 of the URDF limits, pioneer_knm_env.py:217-220
+        out->r_lo[i] = (float)(-kJoints[i].limit);
+        out->r_hi[i] = (float)(kJoints[i].limit);
+        // :57-58  python scalar * float32 array stays float32
+        const float span = out->r_hi[i] - out->r_lo[i];
+        out->v_max[i] = (float)c->max_v_to_r * span;
+        out->a_max[i] = (float)c->max_a_to_v * out->v_max[i];
+    }
+    out->dt = c->timestep * (double)c->frame_skip;  // bullet_scene.py:277-279
+    out->eps = 1e-5;                                // pioneer_knm_env.py:61
+    return PNR_OK;
+}
+
+static void fill_base(pnr_handle h)
+{
+    KParams& P = h->base;
+    memset(&P, 0, sizeof(P));
+    const pnr_config& c = h->cfg;
+    P.state = h->state;
+    P.n = h->n;
+    P.env_off = h->env_off;
+    P.T = 1;
+    P.max_steps = c.max_episode_steps;
+    P.auto_reset = c.auto_reset;
+    P.dt = h->k.dt; P.eps = h->k.eps;
+    for (int k = 0; k < 3; ++k) { P.tlo[k] = c.target_lo[k]; P.tspan[k] = c.target_hi[k] - c.target_lo[k]; }
+    for (int i = 0; i < kDof; ++i) {
+        P.r_lo[i] = h->k.r_lo[i]; P.r_hi[i] = h->k.r_hi[i]; P.v_max[i] = h->k.v_max[i];
+        // np.cos/np.sin of the float32 limit arrays (obs constants, :196-197)
+        P.c_lo[i] = (float)std::cos((double)P.r_lo[i]); P.s_lo[i] = (float)std::sin((double)P.r_lo[i]);
+        P.c_hi[i] = (float)std::cos((double)P.r_hi[i]); P.s_hi[i] = (float)std::sin((double)P.r_hi[i]);
+    }
+    P.pot_m = (float)(c.award_max - c.award_done);
+    P.pot_s = (float)c.award_potential_slope;
+    P.penalty = (float)c.penalty_step;
+    P.award_done = (float)c.award_done;
+    P.done_dist = (float)c.done_distance;
+}
+
+int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, int device_id,
+               uint64_t seed, pnr_handle* out)
+{
+    if (!out) return fail(nullptr, PNR_ERR_INVALID, "pnr_create: null out");
+    *out = nullptr;
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    if (num_envs < 1) return fail(nullptr, PNR_ERR_INVALID, "num_envs must be >= 1 (got %lld)", (long long)num_envs);
+    if (env_id_offset < 0) return fail(nullptr, PNR_ERR_INVALID, "env_id_offset < 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, PNR_ERR_NODEVICE, "no HIP device visible (this engine has no CPU backend)");
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, PNR_ERR_NODEVICE, "device_id %d out of range [0,%d)", device_id, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PNR_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only",
+                    device_id, prop.gcnArchName);
+
+    pnr_handle h = new (std::nothrow) pnr_env_s();
+    if (!h) return fail(nullptr, PNR_ERR_NOMEM, "host allocation failed");
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->n = num_envs;
+    h->env_off = (unsigned long long)env_id_offset;
+    h->device = device_id;
+    pnr_get_constants(cfg, &h->k);
+
+    DeviceGuard g(device_id);
+    hipError_t e = hipMalloc((void**)&h->state, sizeof(float4) * kStatePlanes * (size_t)num_envs);
+    if (e != hipSuccess) { delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(state) failed: %s", hipGetErrorString(e)); }
+    (void)hipMemset(h->state, 0, sizeof(float4) * kStatePlanes * (size_t)num_envs);
+    if (cfg->mode == PNR_MODE_DYNAMIC) {
+        e = hipMalloc((void**)&h->dyn, sizeof(float4) * kDynPlanes * (size_t)num_envs);
+        if (e != hipSuccess) { (void)hipFree(h->state); delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(dyn) failed: %s", hipGetErrorString(e)); }
+        (void)hipMemset(h->dyn, 0, sizeof(float4) * kDynPlanes * (size_t)num_envs);
+    }
+    fill_base(h);
+    h->base.seed_lo = (unsigned)seed; h->base.seed_hi = (unsigned)(seed >> 32);
+    *out = h;
+    return PNR_OK;
+}
+
+int pnr_destroy(pnr_handle h)
+{
+    if (!h) return PNR_OK;
+    DeviceGuard g(h->device);
+    if (h->state) (void)hipFree(h->state);
+    if (h->dyn) (void)hipFree(h->dyn);
+    delete h;
+    return PNR_OK;
+}
+
+int pnr_seed(pnr_handle h, uint64_t seed)
+{
+    if (!h) return fail(nullptr, PNR_ERR_INVALID, "null handle");
+    h->base.seed_lo = (unsigned)seed; h->base.seed_hi = (unsigned)(seed >> 32);
+    return PNR_OK;
+}
+
+int64_t pnr_num_envs(pnr_handle h) { return h ? h->n : -1; }
+
+const char* pnr_last_error(pnr_handle h) { return h ? h->err : g_err; }
+
+static inline unsigned grid_for(long long n) { return (unsigned)((n + kWave - 1) / kWave); }
+
+int pnr_reset(pnr_handle h, const uint8_t* mask, const float* joint_pos, const float* target_pos,
+              float* obs_out, void* stream)
+{
+    if (!h) return fail(nullptr, PNR_ERR_INVALID, "null handle");
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    KParams P = h->base;
+    P.mask = mask; P.joint_pos = joint_pos; P.target_pos = target_pos; P.obs = obs_out;
+    const dim3 grid(grid_for(h->n)), block(kWave);
+    if (!obs_out) hipLaunchKernelGGL((reset_kernel<0, 0>), grid, block, 0, st, P);
+    else if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<0, 1>), grid, block, 0, st, P);
+    else if (!mask) hipLaunchKernelGGL((reset_kernel<0, 2>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((reset_kernel<0, 3>), grid, block, 0, st, P);
+    HIP_TRY(h, hipGetLastError());
+    if (h->cfg.mode == PNR_MODE_DYNAMIC) return dyn_reset_launch(h->dyn, P, h->cfg, st) ? fail(h, PNR_ERR_HIP, "dyn reset launch failed") : PNR_OK;
+    return PNR_OK;
+}
+
+int pnr_observe(pnr_handle h, float* obs_out, void* stream)
+{
+    if (!h) return fail(nullptr, PNR_ERR_INVALID, "null handle");
+    if (!obs_out) return fail(h, PNR_ERR_INVALID, "pnr_observe: null obs_out");
+    DeviceGuard g(h->device);
+    KParams P = h->base;
+    P.obs = obs_out;
+    const dim3 grid(grid_for(h->n)), block(kWave);
+    if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((reset_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, P);
+    HIP_TRY(h, hipGetLastError());
+    return PNR_OK;
+}
+
+static int launch_step(pnr_handle h, int T, const float* actions, float* obs, float* reward,
+                       uint8_t* done, uint8_t* truncated, float* info, void* stream)
+{
+    if (!h) return fail(nullptr, PNR_ERR_INVALID, "null handle");
+    if (!actions || !obs || !reward || !done)
+        return fail(h, PNR_ERR_INVALID, "actions, obs, reward and done must be non-null");
+    if (T < 1) return fail(h, PNR_ERR_INVALID, "T must be >= 1 (got %d)", T);
+    if (info && (reinterpret_cast<uintptr_t>(info) & 15u))
+        return fail(h, PNR_ERR_INVALID, "info must be 16-byte aligned");
+    if (h->cfg.action_layout == PNR_ENV_MAJOR && (reinterpret_cast<uintptr_t>(actions) & 7u))
+        return fail(h, PNR_ERR_INVALID, "env-major actions must be 8-byte aligned");
+    DeviceGuard g(h->device);
+    KParams P = h->base;
+    P.T = T; P.actions = actions; P.obs = obs; P.reward = reward; P.done = done; P.trunc = truncated; P.info = info;
+    const dim3 grid(grid_for(h->n)), block(kWave);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->cfg.mode == PNR_MODE_DYNAMIC) {
+        if (dyn_step_launch(h->dyn, P, h->cfg, st)) return fail(h, PNR_ERR_HIP, "dyn step launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return PNR_OK;
+    }
+    const bool oem = h->cfg.obs_layout == PNR_ENV_MAJOR, aem = h->cfg.action_layout == PNR_ENV_MAJOR;
+    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, st, P);
+    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P);
+    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P);
+    HIP_TRY(h, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_step(pnr_handle h, const float* actions, float* obs, float* reward, uint8_t* done,
+             uint8_t* truncated, float* info, void* stream)
+{
+    return launch_step(h, 1, actions, obs, reward, done, truncated, info, stream);
+}
+
+int pnr_rollout(pnr_handle h, int32_t T, const float* actions, float* obs, float* reward,
+                uint8_t* done, uint8_t* truncated, void* stream)
+{
+    return launch_step(h, T, actions, obs, reward, done, truncated, nullptr, stream);
+}
+
+int pnr_get_state(pnr_handle h, uint32_t* words_out, void* stream)
+{
+    if (!h || !words_out) return fail(h, PNR_ERR_INVALID, "pnr_get_state: null argument");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(state_to_words_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, h->state, words_out, h->n);
+    HIP_TRY(h, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_set_state(pnr_handle h, const uint32_t* words_in, void* stream)
+{
+    if (!h || !words_in) return fail(h, PNR_ERR_INVALID, "pnr_set_state: null argument");
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(words_to_state_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, h->state, words_in, h->n);
+    HIP_TRY(h, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_get_dyn_state(pnr_handle h, float* words_out, void* stream)
+{
+    if (!h || !words_out) return fail(h, PNR_ERR_INVALID, "pnr_get_dyn_state: null argument");
+    if (!h->dyn) return fail(h, PNR_ERR_UNSUPPORTED, "handle is not in dynamics mode");
+    DeviceGuard g(h->device);
+    if (dyn_words_launch(h->dyn, words_out, nullptr, h->n, (hipStream_t)stream)) return fail(h, PNR_ERR_HIP, "launch failed");
+    return PNR_OK;
+}
+
+int pnr_set_dyn_state(pnr_handle h, const float* words_in, void* stream)
+{
+    if (!h || !words_in) return fail(h, PNR_ERR_INVALID, "pnr_set_dyn_state: null argument");
+    if (!h->dyn) return fail(h, PNR_ERR_UNSUPPORTED, "handle is not in dynamics mode");
+    DeviceGuard g(h->device);
+    if (dyn_words_launch(h->dyn, nullptr, words_in, h->n, (hipStream_t)stream)) return fail(h, PNR_ERR_HIP, "launch failed");
+    return PNR_OK;
+}
+
+}  // extern "C"

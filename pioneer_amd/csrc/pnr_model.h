@@ -1,0 +1,56 @@
+// pnr_model.h — compile-time model table of the Pioneer 6-DoF arm.
+//
+// The engine's own compact description of the robot (not a copy of the URDF
+// file): the kinematic chain after merging fixed joints, per moving body the
+// joint axis, the joint origin in the parent body frame, limits, and the
+// lumped inertial data used by dynamics mode.  Source of the numbers:
+// reference assets/pioneer_knm_6dof.urdf:27-275.
+// Everything is constexpr so kernels unroll over it and fold the constants.
+#pragma once
+
+namespace pnr {
+
+constexpr int kDof = 6;
+constexpr int kObsDim = 137;
+constexpr int kStatePlanes = 6;   // float4 planes per env (24 words)
+constexpr int kDynPlanes = 9;     // float4 planes of dynamics-mode extra state (36 words)
+
+enum Axis : int { AX = 0, AY = 1, AZ = 2 };
+
+struct JointDef {
+    Axis axis;          // revolute axis in the child frame (== parent frame at q = 0)
+    double ox, oy, oz;  // joint origin in the parent body frame
+    double limit;       // symmetric position limit, rad (URDF text value)
+};
+
+// Moving bodies 1..6 (fixed joints merged into their parents):
+//   body1 = rotator1 + hinge1          urdf:209-219   q1 about z
+//   body2 = arm1                       urdf:221-227   q2 about y, origin (0,0,3)
+//   body3 = arm2                       urdf:229-235   q3 about y, origin (0,0,11)
+//   body4 = rotator2 + hinge2          urdf:237-248   q4 about x, origin (0,1,0)
+//   body5 = arm3                       urdf:250-256   q5 about y, origin (11,0,0)
+//   body6 = rotator3+effector+pointer  urdf:258-275   q6 about x, origin (0,0,0)
+constexpr JointDef kJoints[kDof] = {
+    {AZ, 0.0, 0.0, 0.0, 3.1416},
+    {AY, 0.0, 0.0, 3.0, 1.309},
+    {AY, 0.0, 0.0, 11.0, 1.309},
+    {AX, 0.0, 1.0, 0.0, 3.1416},
+    {AY, 11.0, 0.0, 0.0, 1.5708},
+    {AX, 0.0, 0.0, 0.0, 3.1416},
+};
+
+// robot:pointer frame origin in body 6 (urdf:271-275)
+constexpr double kTipX = 3.6, kTipY = 0.0, kTipZ = 1.9;
+
+// URDF links lumped into each moving body, in URDF order (for per-link mass
+// randomisation): index into the 11 non-world links
+//   0 base(static) 1 rotator1 2 hinge1 3 arm1 4 arm2 5 rotator2 6 hinge2
+//   7 arm3 8 rotator3 9 effector 10 pointer
+constexpr int kNumLinks = 11;
+constexpr int kLinkBody[kNumLinks] = {-1, 0, 0, 1, 2, 3, 3, 4, 5, 5, 5};
+// every link: mass 1, inertia diag(1,1,1) about its own frame origin, COM at the
+// origin (urdf inertial blocks, e.g. :29-34); the pointer link sits at kTip in body 6.
+constexpr double kLinkMass = 1.0;
+constexpr double kLinkInertia = 1.0;
+
+}  // namespace pnr

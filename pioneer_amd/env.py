@@ -1,0 +1,189 @@
+"""Single-env façade with the reference's ``gym.Env`` surface.
+
+``PioneerKinematicEnv`` here is what RLlib's ``register_env`` creator would return
+in place of pioneer.envs.pioneer.PioneerKinematicEnv (pioneer_knm_env.py:37-242):
+``reset() -> obs[137]``, ``step(action[6]) -> (obs, reward, done, info)``,
+``seed``, ``action_space``, ``observation_space``, ``reward_range``, ``metadata``,
+``reset_world(joint_positions, target_position)``, ``dof``, ``joint_limits()``,
+``joint_positions()``.  It is a one-env batch of the HIP engine (no CPU path);
+``TimeLimit`` reproduces gym.wrappers.TimeLimit as used at pioneer_knm_train.py:27.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .config import EngineConfig, PioneerKinematicConfig, RenderConfig, SimulationConfig
+from .spaces import Box
+from .vector_env import PioneerVectorEnv
+
+Action = np.ndarray
+Observation = np.ndarray
+
+
+def arr2str(arr, fmt: str = ".3f") -> str:
+    """pioneer/collections_util.py:13-14."""
+    return "[" + ", ".join([f"{x:{fmt}}" for x in arr]) + "]"
+
+
+class PioneerKinematicEnv:
+    def __init__(self,
+                 headless: bool = True,
+                 pioneer_config: Optional[PioneerKinematicConfig] = None,
+                 simulation_config: Optional[SimulationConfig] = None,
+                 render_config: Optional[RenderConfig] = None,
+                 device=None,
+                 mode: str = "kinematic"):
+        self.headless = headless
+        self.config = pioneer_config or PioneerKinematicConfig()
+        self.simulation_config = simulation_config or SimulationConfig()
+        self.render_config = render_config or RenderConfig()
+        self.metadata = {                                                  # bullet_env.py:76-79
+            "render.modes": ["human", "rgb_array"],
+            "video.frames_per_second": self.simulation_config.frames_per_second,
+        }
+        self.world_index = -1                                              # bullet_env.py:85
+        self.step_index = 0
+
+        # the env itself never truncates or auto-resets: TimeLimit / the sampler do
+        engine = EngineConfig(max_episode_steps=0, auto_reset=False, mode=mode)
+        self._seed_value = self._fresh_seed()
+        self._vec = PioneerVectorEnv(1, device=device, seed=self._seed_value,
+                                     pioneer_config=self.config,
+                                     simulation_config=self.simulation_config, engine_config=engine)
+        self.r_lo, self.r_hi = self.joint_limits()                         # :56
+        self.v_max = self._vec.v_max                                       # :57
+        self.a_max = self._vec.a_max                                       # :58
+        self.dt = self._vec.dt                                             # :60
+        self.eps = self._vec.eps                                           # :61
+
+        self._obs = self.reset_world()                                     # :69 (+ reset_simulator in BulletEnv.__init__)
+        self.action_space = Box(-self.a_max, self.a_max, dtype=np.float32)  # :72
+        self.observation_space = self.observation_to_space(self.observe())  # :73
+        self.reward_range = (-float("inf"), float("inf"))                  # :74
+
+    # -- randomness ------------------------------------------------------------------
+    @staticmethod
+    def _fresh_seed() -> int:
+        return int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0] >> np.uint64(1))
+
+    def seed(self, seed=None) -> List[int]:                                # :107-109
+        self._seed_value = self._fresh_seed() if seed is None else int(seed)
+        self._vec.seed(self._seed_value)
+        return [self._seed_value]
+
+    # -- state mirrors -------------------------------------------------------------------
+    def _state(self):
+        return self._vec.state_dict()
+
+    @property
+    def a(self) -> np.ndarray: return self._state()["a"][0]
+    @property
+    def v(self) -> np.ndarray: return self._state()["v"][0]
+    @property
+    def r(self) -> np.ndarray: return self._state()["r"][0]
+    @property
+    def potential(self) -> float: return float(self._state()["potential"][0])
+    @property
+    def dof(self) -> int: return self._vec.dof                            # :213-215
+
+    def joint_limits(self) -> Tuple[np.ndarray, np.ndarray]:               # :217-220
+        return self._vec.r_lo.copy(), self._vec.r_hi.copy()
+
+    def joint_positions(self) -> np.ndarray:                               # :222-223
+        return self.r.astype(np.float64)
+
+    # -- reset / step ----------------------------------------------------------------------
+    def reset_world(self, joint_positions: Optional[np.ndarray] = None,
+                    target_position: Optional[Tuple[float, float, float]] = None) -> Observation:
+        """pioneer_knm_env.py:76-105; returns the observation of the new state."""
+        jp = tp = None
+        if joint_positions is not None:
+            positions_list = list(joint_positions)
+            assert len(positions_list) == self.dof                         # :227
+            jp = np.asarray(positions_list, dtype=np.float32)[None]
+        if target_position is not None:
+            assert len(target_position) == 3
+            tp = np.asarray(target_position, dtype=np.float32)[None]
+        obs = self._vec.reset(joint_positions=jp, target_positions=tp)
+        self._obs = obs[0].double().cpu().numpy()
+        return self._obs
+
+    def reset(self) -> Observation:                                        # bullet_env.py:187-190
+        self.world_index += 1
+        self.step_index = 0
+        return self.reset_world()
+
+    def step(self, action: Action) -> Tuple[Observation, float, bool, Dict]:  # bullet_env.py:192-197
+        self.step_index += 1
+        act = np.asarray(action, dtype=np.float32).reshape(1, self.dof)
+        obs, rew, done, _trunc, info = self._vec.vector_step(torch.from_numpy(act), want_info=True)
+        obs = obs[0].double().cpu().numpy()                                # float64[137], quirk Q6
+        reward = float(rew[0].item())
+        is_done = bool(done[0].item())
+        r_pot, r_step, r_done, dist = (float(x) for x in info[0].cpu().numpy())
+        st = self._state()
+        info_dict = {                                                      # :167-179
+            "r_pot": f"{r_pot:.3f}", "r_step": f"{r_step:.3f}", "r_done": f"{r_done:.3f}",
+            "rw": f"{reward:.3f}",
+            "dist": f"{dist:.3f}", "pot": f"{float(st['potential'][0]):.3f}",
+            "a": arr2str(st["a"][0]), "v": arr2str(st["v"][0]), "r": arr2str(st["r"][0]),
+        }
+        self._obs = obs
+        return obs, reward, is_done, info_dict
+
+    def observe(self) -> Observation:                                      # :184-211
+        return self._vec.observe()[0].double().cpu().numpy()
+
+    def render(self, mode="human"):                                        # bullet_env.py:156-185
+        if mode == "human":
+            return None
+        raise AssertionError(f'Render mode "{mode}" is not supported')     # no rasteriser in this engine
+
+    @staticmethod
+    def observation_to_space(observation: Observation) -> Box:             # :238-242
+        low = np.full(observation.shape, -float("inf"), dtype=np.float32)
+        high = np.full(observation.shape, float("inf"), dtype=np.float32)
+        return Box(low, high, dtype=observation.dtype)
+
+    def close(self):
+        self._vec.close()
+
+
+class TimeLimit:
+    """gym.wrappers.TimeLimit semantics (pioneer_knm_train.py:27)."""
+
+    def __init__(self, env, max_episode_steps: int):
+        self.env = env
+        self._max_episode_steps = max_episode_steps
+        self._elapsed_steps = None
+        self.action_space = env.action_space
+        self.observation_space = env.observation_space
+        self.reward_range = env.reward_range
+        self.metadata = env.metadata
+
+    def step(self, action):
+        assert self._elapsed_steps is not None, "Cannot call env.step() before calling reset()"
+        observation, reward, done, info = self.env.step(action)
+        self._elapsed_steps += 1
+        if self._elapsed_steps >= self._max_episode_steps:
+            info["TimeLimit.truncated"] = not done
+            done = True
+        return observation, reward, done, info
+
+    def reset(self, **kwargs):
+        self._elapsed_steps = 0
+        return self.env.reset(**kwargs)
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+
+def make_env(env_config: Dict) -> TimeLimit:
+    """The ``prepare_env`` creator of pioneer_knm_train.py:20-27."""
+    pioneer_config = PioneerKinematicConfig(
+        award_potential_slope=float(env_config["award_potential_slope"]),
+        award_done=float(env_config["award_done"]),
+        penalty_step=float(env_config["penalty_step"]),
+    )
+    return TimeLimit(PioneerKinematicEnv(pioneer_config=pioneer_config), max_episode_steps=500)

@@ -1,0 +1,265 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerances (float32 engine vs float64 oracle, ORC_DEV storage model):
+  * joint state a, v, r and target: BIT-EXACT (the integrator reproduces the
+    reference's mixed-precision arithmetic; reset draws share Philox4x32-10);
+  * cos/sin observation entries: 4e-7 absolute (<= ~2 float32 ulp at 1.0 on top
+    of the oracle's own float32 rounding);
+  * pointer xyz / diff / distance: 3e-5 absolute in a ~30-unit workspace
+    (relative 1e-6);
+  * potential 2e-5, reward 4e-5 absolute (difference of two float32 potentials <= 95).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import COracle
+from oracle.binding import ORC_DEV
+
+pytestmark = pytest.mark.gpu
+
+TRIG_TOL = 4e-7
+POS_TOL = 3e-5
+POT_TOL = 2e-5
+REW_TOL = 4e-5
+
+TRIG_IDX = np.r_[6:18, 24:36, 42:54, 60:72, 78:90, 96:108, 114:126]
+LIN_IDX = np.r_[0:6, 18:24, 36:42, 90:96, 108:114, 129:132]      # exact float32 copies
+SUB_IDX = np.r_[54:60, 72:78]                                      # float32 subtractions (exact vs oracle)
+POS_IDX = np.r_[126:129, 132:136]
+
+
+def make_pair(n, seed=0, layout="env_major", act_layout="env_major", auto_reset=True, max_steps=500, **cfg):
+    from pioneer_amd import PioneerVectorEnv, EngineConfig, PioneerKinematicConfig
+    env = PioneerVectorEnv(n, device="cuda:0", seed=seed,
+                           pioneer_config=PioneerKinematicConfig(**cfg),
+                           engine_config=EngineConfig(auto_reset=auto_reset, obs_layout=layout,
+                                                      action_layout=act_layout, max_episode_steps=max_steps))
+    orc = COracle(n, seed=seed, precision=ORC_DEV, auto_reset=auto_reset, max_episode_steps=max_steps,
+                  nthreads=8, **cfg)
+    return env, orc
+
+
+def to_env_major(env, obs):
+    o = obs.double().cpu().numpy()
+    return o.T if env.feature_major_obs else o
+
+
+def check_obs(got, want, borderline=None):
+    """got/want [n,137] float64."""
+    keep = np.ones(got.shape[0], bool) if borderline is None else ~borderline
+    g, w = got[keep], want[keep]
+    assert np.array_equal(g[:, LIN_IDX], w[:, LIN_IDX]), "linear obs entries must be exact"
+    assert np.array_equal(g[:, SUB_IDX], w[:, SUB_IDX]), "r - r_lo / r_hi - r must be exact float32"
+    assert np.abs(g[:, TRIG_IDX] - w[:, TRIG_IDX]).max() <= TRIG_TOL
+    assert np.abs(g[:, POS_IDX] - w[:, POS_IDX]).max() <= POS_TOL
+    assert np.abs(g[:, 136] - w[:, 136]).max() <= POT_TOL
+
+
+def check_state_exact(env, orc):
+    w = env.get_state().cpu().numpy().view(np.uint32)
+    ow = orc.state_words()
+    assert np.array_equal(w[:21], ow[:21]), "a, v, r, target must be bit-exact"
+    assert np.array_equal(w[22:], ow[22:]), "step_index / episode must match"
+    pot = w[21].view(np.float32).astype(np.float64)
+    opot = ow[21].view(np.float32).astype(np.float64)
+    assert np.abs(pot - opot).max() <= POT_TOL
+
+
+def run_parity(n, steps, layout="env_major", act_layout="env_major", seed=3, action_scale=1.0, **kw):
+    env, orc = make_pair(n, seed=seed, layout=layout, act_layout=act_layout, **kw)
+    obs = env.reset()
+    check_obs(to_env_major(env, obs), orc.reset())
+    rng = np.random.RandomState(seed)
+    for t in range(steps):
+        act = (rng.uniform(-1, 1, size=(n, 6)) * env.a_max * action_scale).astype(np.float32)
+        a_dev = torch.from_numpy(act.T.copy() if env.feature_major_act else act).cuda()
+        obs, rew, done, trunc, info = env.vector_step(a_dev, want_info=True)
+        oobs, orew, odone, otrunc, oinfo = orc.step(act, want_info=True)
+        dist = oinfo[:, 3]
+        # an env whose distance sits within float32 noise of done_distance may flip `done`
+        borderline = np.abs(dist - orc.p.done_distance) < POS_TOL
+        assert borderline.sum() <= max(1, n // 1000)
+        d = done.cpu().numpy()
+        assert np.array_equal(d[~borderline], odone[~borderline])
+        assert np.array_equal(trunc.cpu().numpy()[~borderline], otrunc[~borderline])
+        if borderline.any() and not np.array_equal(d, odone):
+            pytest.skip("done flipped on a borderline env; trajectories legitimately fork")
+        assert np.abs(rew.double().cpu().numpy() - orew).max() <= REW_TOL
+        assert np.abs(info.double().cpu().numpy()[:, :3] - oinfo[:, :3]).max() <= REW_TOL
+        assert np.abs(info.double().cpu().numpy()[:, 3] - oinfo[:, 3]).max() <= POS_TOL
+        check_obs(to_env_major(env, obs), oobs)
+    check_state_exact(env, orc)
+    env.close()
+
+
+@pytest.mark.parametrize("layout,act_layout", [("env_major", "env_major"), ("feature_major", "feature_major"),
+                                               ("env_major", "feature_major"), ("feature_major", "env_major")])
+def test_step_parity_4096(layout, act_layout):
+    """BASELINE config[1] size: 4096 envs, random policy, 40 steps incl. auto-resets by truncation."""
+    run_parity(4096, 40, layout, act_layout, max_steps=25)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 1000])
+def test_ragged_batch_sizes(n):
+    """Partial waves / partial LDS tiles / unaligned tile tails."""
+    run_parity(n, 12, "env_major", max_steps=5)
+    run_parity(n, 12, "feature_major", "feature_major", max_steps=5)
+
+
+def test_saturating_actions_and_limits():
+    """Large constant-sign actions drive every joint through velocity saturation into its limit."""
+    n = 512
+    env, orc = make_pair(n, seed=1, auto_reset=False, max_steps=0)
+    env.reset(); orc.reset()
+    sign = np.where(np.arange(n)[:, None] % 2 == 0, 1.0, -1.0) * np.ones((1, 6))
+    act = (sign * env.a_max).astype(np.float32)
+    for t in range(60):
+        obs, rew, done, trunc = env.vector_step(torch.from_numpy(act).cuda())
+        oobs, orew, odone, otrunc = orc.step(act)
+        check_obs(obs.double().cpu().numpy(), oobs)
+    st = env.state_dict()
+    assert np.all(st["r"] <= env.r_hi) and np.all(st["r"] >= env.r_lo)
+    assert np.all(np.abs(st["v"]) <= env.v_max)
+    assert np.all((st["r"] == env.r_hi) | (st["r"] == env.r_lo)), "every joint must be parked at a limit"
+    check_state_exact(env, orc)
+    env.close()
+
+
+def test_unclipped_actions():
+    """The env does not clip actions (RLlib does): 5x a_max must still match."""
+    run_parity(1024, 20, action_scale=5.0, max_steps=0, auto_reset=False)
+
+
+def test_reset_overrides_and_mask():
+    """reset_world(joint_positions, target_position) overrides + masked reset leave other envs alone."""
+    n = 300
+    env, orc = make_pair(n, seed=11, auto_reset=False)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(5)
+    act = (rng.uniform(-1, 1, size=(n, 6)) * env.a_max).astype(np.float32)
+    for _ in range(3):
+        env.vector_step(torch.from_numpy(act).cuda()); orc.step(act)
+    mask = (rng.rand(n) < 0.3).astype(np.uint8)
+    jp = rng.uniform(env.r_lo, env.r_hi, size=(n, 6)).astype(np.float32)
+    tp = rng.uniform([15, -10, 2], [25, 10, 6], size=(n, 3)).astype(np.float32)
+    before = env.observe().double().cpu().numpy()
+    obs = env.reset(mask=torch.from_numpy(mask).cuda(), joint_positions=jp, target_positions=tp)
+    oobs = orc.reset(mask=mask, joint_pos=jp.astype(np.float64), target_pos=tp.astype(np.float64))
+    got = obs.double().cpu().numpy()
+    check_obs(got[mask == 1], oobs[mask == 1])
+    assert np.array_equal(got[mask == 0], before[mask == 0]), "unselected rows must be untouched"
+    check_state_exact(env, orc)
+    # masked reset with random draws
+    obs = env.reset(mask=torch.from_numpy(mask).cuda())
+    oobs = orc.reset(mask=mask)
+    check_obs(obs.double().cpu().numpy()[mask == 1], oobs[mask == 1])
+    check_state_exact(env, orc)
+    env.close()
+
+
+def test_rollout_equals_steps():
+    """pnr_rollout (T steps, one launch) == T x pnr_step, bit for bit."""
+    n, T = 1000, 17
+    for layout in ("env_major", "feature_major"):
+        env1, _ = make_pair(n, seed=9, layout=layout, max_steps=6)
+        env2, _ = make_pair(n, seed=9, layout=layout, max_steps=6)
+        env1.reset(); env2.reset()
+        g = torch.Generator(device="cpu").manual_seed(2)
+        acts = ((torch.rand(T, n, 6, generator=g) * 2 - 1) * torch.from_numpy(env1.a_max)).cuda()
+        obs_r, rew_r, done_r, trunc_r = env1.rollout(acts)
+        for t in range(T):
+            obs, rew, done, trunc = env2.vector_step(acts[t])
+            assert torch.equal(obs, obs_r[t]) and torch.equal(rew, rew_r[t])
+            assert torch.equal(done, done_r[t]) and torch.equal(trunc, trunc_r[t])
+        assert torch.equal(env1.get_state(), env2.get_state())
+        env1.close(); env2.close()
+
+
+def test_sharding_invariance():
+    """Trajectories are keyed by GLOBAL env id: two half-batches == one full batch."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    n = 512
+    full = PioneerVectorEnv(n, device="cuda:0", seed=5, engine_config=EngineConfig(max_episode_steps=7))
+    lo = PioneerVectorEnv(n // 2, device="cuda:0", seed=5, env_id_offset=0, engine_config=EngineConfig(max_episode_steps=7))
+    hi = PioneerVectorEnv(n // 2, device="cuda:0", seed=5, env_id_offset=n // 2, engine_config=EngineConfig(max_episode_steps=7))
+    o = full.reset(); a = lo.reset(); b = hi.reset()
+    assert torch.equal(o, torch.cat([a, b]))
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for _ in range(20):
+        act = ((torch.rand(n, 6, generator=g) * 2 - 1) * torch.from_numpy(full.a_max)).cuda()
+        o, r, d, t = full.vector_step(act)
+        oa, ra, da, ta = lo.vector_step(act[: n // 2]); ob, rb, db, tb = hi.vector_step(act[n // 2:])
+        assert torch.equal(o, torch.cat([oa, ob])) and torch.equal(r, torch.cat([ra, rb]))
+    for e in (full, lo, hi):
+        e.close()
+
+
+def test_full_size_properties_65536():
+    """BASELINE full size: size-independent properties over a 65 536-env rollout + oracle spot-check."""
+    n = 65536
+    env, orc = make_pair(n, seed=21, max_steps=500)
+    obs = env.reset(); orc.reset()
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    amax = torch.from_numpy(env.a_max).cuda()
+    r_lo = torch.from_numpy(env.r_lo).cuda(); r_hi = torch.from_numpy(env.r_hi).cuda()
+    vmax = torch.from_numpy(env.v_max).cuda()
+    for t in range(30):
+        act = (torch.rand(n, 6, generator=g, device="cuda") * 2 - 1) * amax
+        obs, rew, done, trunc = env.vector_step(act)
+        orc.step(act.cpu().numpy(), want_obs=False)
+        r = obs[:, 0:6]; v = obs[:, 90:96]
+        assert bool(((r >= r_lo) & (r <= r_hi)).all()), "joint limits violated"
+        assert bool((v.abs() <= vmax).all()), "velocity limit violated"
+        for base in (6, 60, 78, 96, 114):           # cos^2 + sin^2 == 1
+            c = obs[:, base:base + 6]; s = obs[:, base + 6:base + 12]
+            assert float((c * c + s * s - 1).abs().max()) < 1e-6
+        diff = obs[:, 129:132] - obs[:, 126:129]
+        assert float((diff - obs[:, 132:135]).abs().max()) < 1e-5         # diff = target - pointer
+        assert float((diff.norm(dim=1) - obs[:, 135]).abs().max()) < 2e-5  # distance = |diff|
+        assert torch.equal(obs[:, 108:114], act)                           # obs shows the action just given (Q1)
+        pot = 95.0 / (obs[:, 135] / 10.0 + 1.0)
+        assert float((pot - obs[:, 136]).abs().max()) < 2e-5
+    check_state_exact(env, orc)   # 65 536 envs x 30 steps, bit-exact joint state vs the oracle
+    env.close()
+
+
+def test_single_env_facade_matches_oracle():
+    """BASELINE config[0] shape: one env behind the gym.Env surface, TimeLimit(500) semantics."""
+    from pioneer_amd import PioneerKinematicEnv, TimeLimit
+    env = TimeLimit(PioneerKinematicEnv(device="cuda:0"), max_episode_steps=8)
+    orc = COracle(1, precision=ORC_DEV, auto_reset=False, max_episode_steps=8)
+    assert env.observation_space.shape == (137,) and env.observation_space.dtype == np.float64
+    assert env.action_space.shape == (6,) and env.action_space.dtype == np.float32
+    assert np.array_equal(env.action_space.high, orc.a_max)
+    env.reset()
+    jp = np.array([0.5, -0.4, 0.9, 1.2, -0.7, 2.0]); tp = (20.0, 3.0, 4.0)
+    obs = env.env.reset_world(jp, tp)
+    oobs = orc.reset(joint_pos=jp[None], target_pos=np.array(tp)[None])
+    check_obs(obs[None], oobs)
+    assert obs.dtype == np.float64 and obs.shape == (137,)
+    rng = np.random.RandomState(0)
+    for t in range(8):
+        a = env.action_space.sample()
+        obs, rew, done, info = env.step(a)
+        oobs, orew, odone, otrunc = orc.step(a[None])
+        check_obs(obs[None], oobs)
+        assert abs(rew - orew[0]) <= REW_TOL
+        assert isinstance(rew, float) and isinstance(done, bool)
+        assert set(info) >= {"r_pot", "r_step", "r_done", "rw", "dist", "pot", "a", "v", "r"}
+        if t == 7:
+            assert done and info["TimeLimit.truncated"] is True
+    env.close()
+
+
+def test_errors_are_loud():
+    from pioneer_amd import PioneerVectorEnv, PnrError
+    env = PioneerVectorEnv(8, device="cuda:0")
+    env.reset()
+    with pytest.raises(AssertionError):
+        env.vector_step(torch.zeros(7, 6).cuda())
+    with pytest.raises(PnrError):
+        PioneerVectorEnv(0, device="cuda:0")
+    env.close()
+    with pytest.raises(RuntimeError):
+        env.vector_step(torch.zeros(8, 6).cuda())
