@@ -195,6 +195,13 @@ int pnr_set_state(pnr_handle h, const uint32_t* words_in, void* stream);
 int pnr_get_dyn_state(pnr_handle h, float* words_out, void* stream);
 int pnr_set_dyn_state(pnr_handle h, const float* words_in, void* stream);
 
+/* Diagnostic: the engine's float32 sin/cos (the np.sin/np.cos replacement used
+ * for obs entries, pioneer_knm_env.py:195-203) over a device array x[n].
+ * bounded != 0 selects the Cody-Waite path used for r, v and limit distances;
+ * 0 the path used for raw actions (falls back to full reduction above 2^17). */
+int pnr_diag_sincos(const float* x, float* sin_out, float* cos_out, int64_t n,
+                    int bounded, void* stream);
+
 int64_t pnr_num_envs(pnr_handle h);
 
 /* Last error message of `h`, or of the calling thread when h == NULL. */

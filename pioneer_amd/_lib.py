@@ -77,6 +77,7 @@ SIGNATURES = {
     "pnr_set_state": (C.c_int, [_VP, _VP, _VP]),
     "pnr_get_dyn_state": (C.c_int, [_VP, _VP, _VP]),
     "pnr_set_dyn_state": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_diag_sincos": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int, _VP]),
     "pnr_num_envs": (C.c_int64, [_VP]),
     "pnr_last_error": (C.c_char_p, [_VP]),
 }

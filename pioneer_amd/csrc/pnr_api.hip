@@ -31,7 +31,7 @@ constexpr int kWave = 64;
 template <bool OBS_EM, bool ACT_EM>
 __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 {
-    __shared__ __attribute__((aligned(16))) float tile[OBS_EM ? kWave * kObsDim : 4];
+    __shared__ __attribute__((aligned(16))) float tile[kWave * kObsDim];
 
     const int lane = threadIdx.x;
     const long long tile0 = (long long)blockIdx.x * kWave;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
         s.step += 1;                                                  // bullet_env.py:193
 #pragma unroll
         for (int i = 0; i < kDof; ++i)
-            integrate_joint(s.a[i], s.v[i], s.r[i], P.v_max[i], P.r_lo[i], P.r_hi[i],
+            integrate_joint(s.a[i], s.v[i], s.r[i], P.v_max[i], limit_lo(i), limit_hi(i),
                             P.dt, P.eps, s.v[i], s.r[i]);
 #pragma unroll
         for (int i = 0; i < kDof; ++i) s.a[i] = act[i];               // :144 (quirk Q1)
@@ -107,15 +107,17 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 
         // -- observe() ----------------------------------------------------------------
         float* obs_t = P.obs + (long long)t * n * kObsDim;
+        if (t > 0) __syncthreads();       // previous flush done before the tile is rewritten
         if (OBS_EM) {
-            if (t > 0) __syncthreads();   // previous flush done before the tile is rewritten
             SinkLdsTile sink{tile + lane * kObsDim};
             emit_obs(P, s, q, sink);
             __syncthreads();
             flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
         } else {
-            SinkFeatureMajor sink{obs_t + e, n, valid};
+            SinkLdsFeatureTile sink{tile + lane};
             emit_obs(P, s, q, sink);
+            __syncthreads();
+            flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
         }
     }
 
@@ -124,13 +126,14 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 
 // ---------------------------------------------------------------------------------
 // reset / observe kernel.  MODE 0: reset (mask / overrides), 1: observe only.
-// OBS: 0 none, 1 feature-major, 2 env-major via LDS tile (all rows written),
-//      3 env-major direct rows (masked reset).
+// OBS: 0 none, 1 feature-major direct (masked reset), 2 env-major via LDS tile
+//      (all rows written), 3 env-major direct rows (masked reset), 4 feature-major
+//      via LDS tile (all columns written).
 // ---------------------------------------------------------------------------------
 template <int MODE, int OBS>
 __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P)
 {
-    __shared__ __attribute__((aligned(16))) float tile[OBS == 2 ? kWave * kObsDim : 4];
+    __shared__ __attribute__((aligned(16))) float tile[(OBS == 2 || OBS == 4) ? kWave * kObsDim : 4];
     const int lane = threadIdx.x;
     const long long tile0 = (long long)blockIdx.x * kWave;
     const long long e = tile0 + lane;
@@ -167,6 +170,11 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P)
             emit_obs(P, s, q, sink);
             __syncthreads();
             flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
+        } else if (OBS == 4) {
+            SinkLdsFeatureTile sink{tile + lane};
+            emit_obs(P, s, q, sink);
+            __syncthreads();
+            flush_feature_tile(tile, P.obs + tile0, n, nvalid, lane);
         } else {
             SinkRowDirect sink{P.obs + e * kObsDim, active};
             emit_obs(P, s, q, sink);
@@ -198,6 +206,16 @@ __global__ void words_to_state_kernel(float4* __restrict__ st, const uint32_t* _
         st[p * n + e] = make_float4(__uint_as_float(w[(4 * p + 0) * n + e]), __uint_as_float(w[(4 * p + 1) * n + e]),
                                     __uint_as_float(w[(4 * p + 2) * n + e]), __uint_as_float(w[(4 * p + 3) * n + e]));
     }
+}
+
+__global__ void diag_sincos_kernel(const float* __restrict__ x, float* __restrict__ sn, float* __restrict__ cs,
+                                   long long n, int bounded)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    if (bounded) sincos_bounded(x[i], s, c); else sincos_any(x[i], s, c);
+    sn[i] = s; cs[i] = c;
 }
 
 }  // namespace pnr
@@ -335,12 +353,7 @@ static void fill_base(pnr_handle h)
     P.auto_reset = c.auto_reset;
     P.dt = h->k.dt; P.eps = h->k.eps;
     for (int k = 0; k < 3; ++k) { P.tlo[k] = c.target_lo[k]; P.tspan[k] = c.target_hi[k] - c.target_lo[k]; }
-    for (int i = 0; i < kDof; ++i) {
-        P.r_lo[i] = h->k.r_lo[i]; P.r_hi[i] = h->k.r_hi[i]; P.v_max[i] = h->k.v_max[i];
-        // np.cos/np.sin of the float32 limit arrays (obs constants, :196-197)
-        P.c_lo[i] = (float)std::cos((double)P.r_lo[i]); P.s_lo[i] = (float)std::sin((double)P.r_lo[i]);
-        P.c_hi[i] = (float)std::cos((double)P.r_hi[i]); P.s_hi[i] = (float)std::sin((double)P.r_hi[i]);
-    }
+    for (int i = 0; i < kDof; ++i) P.v_max[i] = h->k.v_max[i];
     P.pot_m = (float)(c.award_max - c.award_done);
     P.pot_s = (float)c.award_potential_slope;
     P.penalty = (float)c.penalty_step;
@@ -367,6 +380,13 @@ int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, i
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, PNR_ERR_NODEVICE, "device %d is %s; this library is built for gfx950 only",
                     device_id, prop.gcnArchName);
+
+    for (int i = 0; i < kDof; ++i) {
+        // the obs constants of pnr_model.h must be np.cos/np.sin of the float32 limits
+        const float c = (float)std::cos((double)limit_hi(i)), s = (float)std::sin((double)limit_hi(i));
+        if (c != kLimitCos[i] || s != kLimitSin[i])
+            return fail(nullptr, PNR_ERR_INVALID, "model table: cos/sin constants of joint %d are stale", i);
+    }
 
     pnr_handle h = new (std::nothrow) pnr_env_s();
     if (!h) return fail(nullptr, PNR_ERR_NOMEM, "host allocation failed");
@@ -425,7 +445,8 @@ int pnr_reset(pnr_handle h, const uint8_t* mask, const float* joint_pos, const f
     P.mask = mask; P.joint_pos = joint_pos; P.target_pos = target_pos; P.obs = obs_out;
     const dim3 grid(grid_for(h->n)), block(kWave);
     if (!obs_out) hipLaunchKernelGGL((reset_kernel<0, 0>), grid, block, 0, st, P);
-    else if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<0, 1>), grid, block, 0, st, P);
+    else if (h->cfg.obs_layout == PNR_FEATURE_MAJOR && mask) hipLaunchKernelGGL((reset_kernel<0, 1>), grid, block, 0, st, P);
+    else if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<0, 4>), grid, block, 0, st, P);
     else if (!mask) hipLaunchKernelGGL((reset_kernel<0, 2>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((reset_kernel<0, 3>), grid, block, 0, st, P);
     HIP_TRY(h, hipGetLastError());
@@ -441,7 +462,7 @@ int pnr_observe(pnr_handle h, float* obs_out, void* stream)
     KParams P = h->base;
     P.obs = obs_out;
     const dim3 grid(grid_for(h->n)), block(kWave);
-    if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, P);
+    if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<1, 4>), grid, block, 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL((reset_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, P);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
@@ -486,6 +507,16 @@ int pnr_rollout(pnr_handle h, int32_t T, const float* actions, float* obs, float
                 uint8_t* done, uint8_t* truncated, void* stream)
 {
     return launch_step(h, T, actions, obs, reward, done, truncated, nullptr, stream);
+}
+
+int pnr_diag_sincos(const float* x, float* sin_out, float* cos_out, int64_t n, int bounded, void* stream)
+{
+    if (!x || !sin_out || !cos_out || n < 0) return fail(nullptr, PNR_ERR_INVALID, "pnr_diag_sincos: bad argument");
+    if (n == 0) return PNR_OK;
+    hipLaunchKernelGGL(diag_sincos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, sin_out, cos_out, (long long)n, bounded);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
 }
 
 int pnr_get_state(pnr_handle h, uint32_t* words_out, void* stream)

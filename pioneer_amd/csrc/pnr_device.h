@@ -37,8 +37,7 @@ struct KParams {
     int pad0;
     double dt, eps;            // pioneer_knm_env.py:60-61
     double tlo[3], tspan[3];   // target_lo, target_hi - target_lo
-    float r_lo[kDof], r_hi[kDof], v_max[kDof];
-    float c_lo[kDof], s_lo[kDof], c_hi[kDof], s_hi[kDof];  // cos/sin of the limits (obs constants)
+    float v_max[kDof];         // max_v_to_r * (r_hi - r_lo); the limits themselves are constexpr (pnr_model.h)
     float pot_m, pot_s;        // award_max - award_done, award_potential_slope
     float penalty, award_done, done_dist;
     float pad1;
@@ -73,6 +72,42 @@ __device__ __forceinline__ void store_state(float4* __restrict__ st, long long n
     st[3 * n + e] = make_float4(s.r[0], s.r[1], s.r[2], s.r[3]);
     st[4 * n + e] = make_float4(s.r[4], s.r[5], s.tgt[0], s.tgt[1]);
     st[5 * n + e] = make_float4(s.tgt[2], s.pot, __uint_as_float(s.step), __uint_as_float(s.episode));
+}
+
+// ---- sin/cos -------------------------------------------------------------------------
+// np.sin / np.cos of the float32 observation pieces (pioneer_knm_env.py:195-203).
+// Cody-Waite reduction by pi/2 with three float32 constants and FMA, then
+// degree-7/8 minimax polynomials on [-pi/4, pi/4]; max abs error 9.3e-8 for
+// |x| <= 2^16 (tests/test_sincos.py sweeps it against float64).  Every trig
+// argument of the obs except the raw action is bounded by construction
+// (|r| <= pi, |r - r_lo| <= 2 pi, |v| <= v_max); ~22 VALU ops per pair instead
+// of ocml's sincosf with its inlined Payne-Hanek path.
+__device__ __forceinline__ void sincos_bounded(float x, float& sn, float& cs)
+{
+    const float k = __builtin_rintf(x * 0x1.45f306p-1f);                 // x * 2/pi
+    float r = __builtin_fmaf(-k, 0x1.921fb6p+0f, x);                     // pi/2 hi
+    r = __builtin_fmaf(-k, -0x1.777a5cp-25f, r);                         // pi/2 mid
+    r = __builtin_fmaf(-k, -0x1.ee59dap-50f, r);                         // pi/2 lo
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    const float s0 = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    const float c0 = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? c0 : s0;
+    const float cc = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
+}
+
+// The raw action is not bounded by the env (RLlib clips it, the env does not):
+// beyond 2^17 fall back to ocml's fully-reduced sincosf.
+__device__ __forceinline__ void sincos_any(float x, float& sn, float& cs)
+{
+    if (__builtin_fabsf(x) <= 131072.0f) sincos_bounded(x, sn, cs);
+    else sincosf(x, &sn, &cs);
 }
 
 // ---- integrator: pioneer_knm_env.py:113-146 -------------------------------------
@@ -168,7 +203,7 @@ __device__ __forceinline__ void reset_env(const KParams& P, EnvState& s, unsigne
     }
 #pragma unroll
     for (int i = 0; i < kDof; ++i) {
-        const double lo = (double)P.r_lo[i], hi = (double)P.r_hi[i];
+        const double lo = (double)limit_lo(i), hi = (double)limit_hi(i);
         const float drawn = (float)(lo + (hi - lo) * u01(w[i]));          // :80-81
         s.r[i] = jp ? jp[i] : drawn;                                       // :94 (stored as float32)
         s.a[i] = 0.0f;                                                     // :92
@@ -195,7 +230,7 @@ struct Pose {
 __device__ __forceinline__ void compute_pose(const EnvState& s, Pose& q)
 {
 #pragma unroll
-    for (int i = 0; i < kDof; ++i) sincosf(s.r[i], &q.s[i], &q.c[i]);
+    for (int i = 0; i < kDof; ++i) sincos_bounded(s.r[i], q.s[i], q.c[i]);
     fk_pointer(q.c, q.s, q.ptr);
 #pragma unroll
     for (int k = 0; k < 3; ++k) q.diff[k] = s.tgt[k] - q.ptr[k];          // :154
@@ -213,22 +248,22 @@ __device__ __forceinline__ void emit_obs(const KParams& P, const EnvState& s, co
         float sn, cs;
         // [0:18]  r, cos r, sin r
         out.put(0 + i, s.r[i]); out.put(6 + i, q.c[i]); out.put(12 + i, q.s[i]);
-        // [18:54] limits and their cos/sin (per-run constants)
-        out.put(18 + i, P.r_lo[i]); out.put(24 + i, P.c_lo[i]); out.put(30 + i, P.s_lo[i]);
-        out.put(36 + i, P.r_hi[i]); out.put(42 + i, P.c_hi[i]); out.put(48 + i, P.s_hi[i]);
+        // [18:54] limits and their cos/sin (compile-time constants)
+        out.put(18 + i, limit_lo(i)); out.put(24 + i, kLimitCos[i]); out.put(30 + i, -kLimitSin[i]);
+        out.put(36 + i, limit_hi(i)); out.put(42 + i, kLimitCos[i]); out.put(48 + i, kLimitSin[i]);
         // [54:72] r - r_lo (float32 subtraction, :191)
-        const float dlo = s.r[i] - P.r_lo[i];
-        sincosf(dlo, &sn, &cs);
+        const float dlo = s.r[i] - limit_lo(i);
+        sincos_bounded(dlo, sn, cs);
         out.put(54 + i, dlo); out.put(60 + i, cs); out.put(66 + i, sn);
         // [72:90] r_hi - r (:192)
-        const float dhi = P.r_hi[i] - s.r[i];
-        sincosf(dhi, &sn, &cs);
+        const float dhi = limit_hi(i) - s.r[i];
+        sincos_bounded(dhi, sn, cs);
         out.put(72 + i, dhi); out.put(78 + i, cs); out.put(84 + i, sn);
         // [90:108] v
-        sincosf(s.v[i], &sn, &cs);
+        sincos_bounded(s.v[i], sn, cs);
         out.put(90 + i, s.v[i]); out.put(96 + i, cs); out.put(102 + i, sn);
         // [108:126] a (the action just given, quirk Q1)
-        sincosf(s.a[i], &sn, &cs);
+        sincos_any(s.a[i], sn, cs);
         out.put(108 + i, s.a[i]); out.put(114 + i, cs); out.put(120 + i, sn);
     }
 #pragma unroll
@@ -258,6 +293,34 @@ struct SinkRowDirect {
     float* row; bool valid;
     __device__ __forceinline__ void put(int f, float v) { if (valid) row[f] = v; }
 };
+
+// feature-major through an LDS tile [137][64]: lane-contiguous ds_write_b32, then
+// 16-byte stores where 16 lanes cover one feature's 64 envs (256 B) and a wave
+// instruction covers four features
+struct SinkLdsFeatureTile {
+    float* col;   // tile + lane
+    __device__ __forceinline__ void put(int f, float v) { col[f * 64] = v; }
+};
+
+// Flush a [137][64] feature tile to obs[f*n + tile0 + 0..63].
+__device__ __forceinline__ void flush_feature_tile(const float* __restrict__ lds, float* __restrict__ dst,
+                                                   long long n, int nvalid, int lane)
+{
+    // dst = obs_t + tile0; row f lives at dst + f*n
+    if (nvalid == 64 && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(n * 4)) & 15u) == 0) {
+        const int sub = lane >> 4, col4 = (lane & 15) * 4;
+        for (int f0 = 0; f0 < kObsDim; f0 += 4) {
+            const int f = f0 + sub;
+            if (f < kObsDim) {
+                const float4 v = *reinterpret_cast<const float4*>(lds + f * 64 + col4);
+                *reinterpret_cast<float4*>(dst + (long long)f * n + col4) = v;
+            }
+        }
+    } else {
+        for (int f = 0; f < kObsDim; ++f)
+            if (lane < nvalid) dst[(long long)f * n + lane] = lds[f * 64 + lane];
+    }
+}
 
 // Copy a wave's LDS tile (rows [0, nvalid) of 137 floats) to its contiguous
 // place in an env-major obs batch with 16-byte lane-linear stores.

@@ -39,6 +39,19 @@ constexpr JointDef kJoints[kDof] = {
     {AX, 0.0, 0.0, 0.0, 3.1416},
 };
 
+// float32 joint limits as the env stores them (joint_limits(), pioneer_knm_env.py:217-220)
+// and float32(cos/sin) of them — the 36 per-run constant observation entries
+// (pioneer_knm_env.py:196-197).  r_lo = -r_hi exactly, so cos(r_lo) = cos(r_hi),
+// sin(r_lo) = -sin(r_hi).  pnr_create re-derives these with libm and refuses
+// to run on a mismatch.
+__host__ __device__ constexpr float limit_hi(int j) { return (float)kJoints[j].limit; }
+__host__ __device__ constexpr float limit_lo(int j) { return -(float)kJoints[j].limit; }
+constexpr float kCos3_1416 = -0x1.000000p+0f, kSin3_1416 = -0x1.e5ddeap-18f;
+constexpr float kCos1_309 = 0x1.090714p-2f, kSin1_309 = 0x1.ee8df0p-1f;
+constexpr float kCos1_5708 = -0x1.e5ddeap-19f, kSin1_5708 = 0x1.000000p+0f;
+constexpr float kLimitCos[kDof] = {kCos3_1416, kCos1_309, kCos1_309, kCos3_1416, kCos1_5708, kCos3_1416};
+constexpr float kLimitSin[kDof] = {kSin3_1416, kSin1_309, kSin1_309, kSin3_1416, kSin1_5708, kSin3_1416};
+
 // robot:pointer frame origin in body 6 (urdf:271-275)
 constexpr double kTipX = 3.6, kTipY = 0.0, kTipZ = 1.9;
 

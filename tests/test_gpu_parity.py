@@ -7,7 +7,10 @@ Tolerances (float32 engine vs float64 oracle, ORC_DEV storage model):
     of the oracle's own float32 rounding);
   * pointer xyz / diff / distance: 3e-5 absolute in a ~30-unit workspace
     (relative 1e-6);
-  * potential 2e-5, reward 4e-5 absolute (difference of two float32 potentials <= 95).
+  * potential 1e-4, reward 2e-4 absolute: potential = 95/(d/10+1) <= 95 is a float32
+    (ulp 7.6e-6 near 95) with |d pot / d dist| <= 9.5, so a 3e-5 distance error alone can
+    move it by ~3e-4 at dist -> 0 and by < 1e-4 in the target box; the reward is a
+    difference of two such potentials.
 """
 import numpy as np
 import pytest
@@ -20,8 +23,8 @@ pytestmark = pytest.mark.gpu
 
 TRIG_TOL = 4e-7
 POS_TOL = 3e-5
-POT_TOL = 2e-5
-REW_TOL = 4e-5
+POT_TOL = 1e-4
+REW_TOL = 2e-4
 
 TRIG_IDX = np.r_[6:18, 24:36, 42:54, 60:72, 78:90, 96:108, 114:126]
 LIN_IDX = np.r_[0:6, 18:24, 36:42, 90:96, 108:114, 129:132]      # exact float32 copies
