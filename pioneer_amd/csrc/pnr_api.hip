@@ -1,19 +1,21 @@
 // pnr_api.hip — kernels + C ABI (include/pioneer_amd.h) of the MI355X-native
 // Pioneer-arm engine.  gfx950 only; no CPU fallback.
 //
-// Execution shape: one env per lane, one 64-lane wave per workgroup.  State
-// lives in HBM as six float4 planes [6][n] (24 words per env), so a wave moves
-// each plane with one 1-KiB dwordx4 instruction.  Env-major observations are
-// staged through a [64][137] LDS tile and leave as 16-byte lane-linear stores
-// (a wave's 64 rows are one contiguous 35 KB span); feature-major observations
-// are stored directly.  Envs never interact, so there is no cross-workgroup
-// traffic and block -> XCD placement only matters for L2 residency of the
-// state planes (block b touches the same lines every launch).
+// Execution shape: a lane PAIR per env (three joints per lane), one 64-lane wave
+// = 32 envs per workgroup.  State lives in HBM as three float4 planes [3][2n]
+// (24 words per env), so a wave moves each plane with one 1-KiB dwordx4
+// instruction.  Observations are staged through a 17.5 KB LDS tile and leave as
+// 16-byte stores: env-major rows of a wave are one contiguous 17.5 KB span;
+// feature-major columns leave as 128-B segments, eight features per
+// instruction.  Envs never interact, so there is no cross-workgroup traffic and
+// block -> XCD placement only matters for L2 residency of the state planes
+// (block b touches the same lines every launch).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -23,63 +25,68 @@
 
 namespace pnr {
 
-constexpr int kWave = 64;
-
 // ---------------------------------------------------------------------------------
-// step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps
+// step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps.
+// One wave = 32 envs (lane pair per env), one wave per workgroup.
 // ---------------------------------------------------------------------------------
 template <bool OBS_EM, bool ACT_EM>
 __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kWave * kObsDim];
+    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
 
     const int lane = threadIdx.x;
-    const long long tile0 = (long long)blockIdx.x * kWave;
-    const long long e = tile0 + lane;
-    const bool valid = e < P.n;
+    const int p = lane & 1;                 // which half of the env's joints
+    const int el = lane >> 1;               // env within the wave's tile
     const long long n = P.n;
-    const int nvalid = (int)((n - tile0) < kWave ? (n - tile0) : kWave);
+    const long long tile0 = (long long)blockIdx.x * kEnvsPerWave;
+    const long long e = tile0 + el;
+    const long long rec = 2 * tile0 + lane; // state record index (2e + p)
+    const bool valid = e < n;
+    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
 
-    EnvState s;
-    if (valid) {
-        load_state(P.state, n, e, s);
-    } else {
-#pragma unroll
-        for (int i = 0; i < kDof; ++i) { s.a[i] = 0.f; s.v[i] = 0.f; s.r[i] = 0.f; }
-        s.tgt[0] = s.tgt[1] = s.tgt[2] = 0.f; s.pot = 0.f; s.step = 0; s.episode = 0;
-    }
+    // PNR_DIAG timing-only ablations (outputs are wrong when set; see DESIGN.md "Where the time goes")
+    const bool diag_noflush = P.diag & 2, diag_noemit = P.diag & 4, diag_nostate = P.diag & 8;
+
+    LaneState s;
+    if (valid) load_state(P.state, n, rec, p, s);   // the pair shares `valid`, so DPP partners are live
+    else zero_state(s);
+
+    const float vmax0 = p ? P.v_max[kJpl + 0] : P.v_max[0];
+    const float vmax1 = p ? P.v_max[kJpl + 1] : P.v_max[1];
+    const float vmax2 = p ? P.v_max[kJpl + 2] : P.v_max[2];
+    const float vmax[kJpl] = {vmax0, vmax1, vmax2};
 
     for (int t = 0; t < P.T; ++t) {
-        // -- action of this step ----------------------------------------------------
-        float act[kDof];
+        // -- action of this step (this lane's three joints) --------------------------
+        float act[kJpl];
         if (valid) {
             const float* A = P.actions + (long long)t * n * kDof;
             if (ACT_EM) {
-                const float2* a2 = reinterpret_cast<const float2*>(A + e * kDof);
-                const float2 x0 = a2[0], x1 = a2[1], x2 = a2[2];
-                act[0] = x0.x; act[1] = x0.y; act[2] = x1.x; act[3] = x1.y; act[4] = x2.x; act[5] = x2.y;
+                const float* a3 = A + e * kDof + kJpl * p;      // 12 B per lane, lanes contiguous
+                act[0] = a3[0]; act[1] = a3[1]; act[2] = a3[2];
             } else {
 #pragma unroll
-                for (int i = 0; i < kDof; ++i) act[i] = A[(long long)i * n + e];
+                for (int i = 0; i < kJpl; ++i) act[i] = A[(long long)(kJpl * p + i) * n + e];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < kDof; ++i) act[i] = 0.f;
+            for (int i = 0; i < kJpl; ++i) act[i] = 0.f;
         }
 
         // -- act(): integrate the PREVIOUS action, then latch the new one -----------
         s.step += 1;                                                  // bullet_env.py:193
 #pragma unroll
-        for (int i = 0; i < kDof; ++i)
-            integrate_joint(s.a[i], s.v[i], s.r[i], P.v_max[i], limit_lo(i), limit_hi(i),
-                            P.dt, P.eps, s.v[i], s.r[i]);
+        for (int i = 0; i < kJpl; ++i) {
+            const float lim = lane_limit(p, i);
+            integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, P.dt, P.eps, s.v[i], s.r[i]);
+        }
 #pragma unroll
-        for (int i = 0; i < kDof; ++i) s.a[i] = act[i];               // :144 (quirk Q1)
+        for (int i = 0; i < kJpl; ++i) s.a[i] = act[i];               // :144 (quirk Q1)
 
         Pose q;
-        compute_pose(s, q);
+        compute_pose(s, p, q);
 
-        // -- reward block, pioneer_knm_env.py:157-165 -----------------------------------
+        // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
         const float old_pot = s.pot;
         const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
         const bool done = q.dist < P.done_dist;                       // :160
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
         // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
         const bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
 
-        if (valid) {
+        if (valid && p == 0) {
             const long long o = (long long)t * n + e;
             P.reward[o] = rw;
             P.done[o] = (uint8_t)done;
@@ -100,28 +107,29 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
         }
 
         // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
+        // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
         if (P.auto_reset && (done || trunc)) {
-            reset_env(P, s, P.env_off + (unsigned long long)e, nullptr, nullptr);
-            compute_pose(s, q);
+            reset_env(P, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
+            compute_pose(s, p, q);
         }
 
         // -- observe() ----------------------------------------------------------------
         float* obs_t = P.obs + (long long)t * n * kObsDim;
         if (t > 0) __syncthreads();       // previous flush done before the tile is rewritten
         if (OBS_EM) {
-            SinkLdsTile sink{tile + lane * kObsDim};
-            emit_obs(P, s, q, sink);
+            SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
+            if (!diag_noemit) emit_obs(s, q, p, sink);
             __syncthreads();
-            flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
+            if (!diag_noflush) flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
         } else {
-            SinkLdsFeatureTile sink{tile + lane};
-            emit_obs(P, s, q, sink);
+            SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
+            emit_obs(s, q, p, sink);
             __syncthreads();
             flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
         }
     }
 
-    if (valid) store_state(P.state, n, e, s);
+    if (valid && !diag_nostate) store_state(P.state, n, rec, p, s);
 }
 
 // ---------------------------------------------------------------------------------
@@ -133,78 +141,90 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 template <int MODE, int OBS>
 __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P)
 {
-    __shared__ __attribute__((aligned(16))) float tile[(OBS == 2 || OBS == 4) ? kWave * kObsDim : 4];
+    __shared__ __attribute__((aligned(16))) float tile[(OBS == 2 || OBS == 4) ? kTileFloats : 4];
     const int lane = threadIdx.x;
-    const long long tile0 = (long long)blockIdx.x * kWave;
-    const long long e = tile0 + lane;
+    const int p = lane & 1, el = lane >> 1;
     const long long n = P.n;
+    const long long tile0 = (long long)blockIdx.x * kEnvsPerWave;
+    const long long e = tile0 + el;
+    const long long rec = 2 * tile0 + lane;
     const bool valid = e < n;
-    const int nvalid = (int)((n - tile0) < kWave ? (n - tile0) : kWave);
+    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
 
-    EnvState s;
+    LaneState s;
+    if (valid) load_state(P.state, n, rec, p, s);
+    else zero_state(s);
     bool active = valid;
-    if (valid) {
-        load_state(P.state, n, e, s);
-    } else {
-#pragma unroll
-        for (int i = 0; i < kDof; ++i) { s.a[i] = 0.f; s.v[i] = 0.f; s.r[i] = 0.f; }
-        s.tgt[0] = s.tgt[1] = s.tgt[2] = 0.f; s.pot = 0.f; s.step = 0; s.episode = 0;
-    }
     if (MODE == 0) {
         if (valid && P.mask) active = P.mask[e] != 0;
-        if (active) {
-            reset_env(P, s, P.env_off + (unsigned long long)e,
+        if (active) {   // both lanes of a pair take the same branch
+            reset_env(P, s, p, P.env_off + (unsigned long long)e,
                       P.joint_pos ? P.joint_pos + e * kDof : nullptr,
                       P.target_pos ? P.target_pos + e * 3 : nullptr);
-            store_state(P.state, n, e, s);
+            store_state(P.state, n, rec, p, s);
         }
     }
     if (OBS != 0) {
         Pose q;
-        compute_pose(s, q);
+        compute_pose(s, p, q);   // every lane takes part: the DPP exchange needs live partners
         if (OBS == 1) {
-            SinkFeatureMajor sink{P.obs + e, n, active};
-            emit_obs(P, s, q, sink);
+            SinkDirect sink{P.obs + e, n, kJpl * p, p, active};
+            emit_obs(s, q, p, sink);
         } else if (OBS == 2) {
-            SinkLdsTile sink{tile + lane * kObsDim};
-            emit_obs(P, s, q, sink);
+            SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
+            emit_obs(s, q, p, sink);
             __syncthreads();
             flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
         } else if (OBS == 4) {
-            SinkLdsFeatureTile sink{tile + lane};
-            emit_obs(P, s, q, sink);
+            SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
+            emit_obs(s, q, p, sink);
             __syncthreads();
             flush_feature_tile(tile, P.obs + tile0, n, nvalid, lane);
         } else {
-            SinkRowDirect sink{P.obs + e * kObsDim, active};
-            emit_obs(P, s, q, sink);
+            SinkDirect sink{P.obs + e * kObsDim, 1, kJpl * p, p, active};
+            emit_obs(s, q, p, sink);
         }
     }
 }
 
-// planar words [24][n] <-> float4 planes [6][n]
+// canonical planar words [24][n] (include/pioneer_amd.h) <-> the engine's pair records
+__device__ __forceinline__ int word_of(int p, int plane, int comp)
+{
+    // which canonical word sits in (half p, plane, component)
+    const int k = plane * 4 + comp;            // 0..11 within the half record
+    if (k < 3) return 0 + 3 * p + k;           // a
+    if (k < 6) return 6 + 3 * p + (k - 3);     // v
+    if (k < 9) return 12 + 3 * p + (k - 6);    // r
+    return (p ? 21 : 18) + (k - 9);            // target xyz | potential, step, episode
+}
+
 __global__ void state_to_words_kernel(const float4* __restrict__ st, uint32_t* __restrict__ w, long long n)
 {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    const long long rec = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rec >= 2 * n) return;
+    const long long e = rec >> 1; const int p = (int)(rec & 1);
 #pragma unroll
-    for (int p = 0; p < kStatePlanes; ++p) {
-        const float4 v = st[p * n + e];
-        w[(4 * p + 0) * n + e] = __float_as_uint(v.x);
-        w[(4 * p + 1) * n + e] = __float_as_uint(v.y);
-        w[(4 * p + 2) * n + e] = __float_as_uint(v.z);
-        w[(4 * p + 3) * n + e] = __float_as_uint(v.w);
+    for (int pl = 0; pl < kStatePlanes; ++pl) {
+        const float4 v = st[(long long)pl * 2 * n + rec];
+        w[(long long)word_of(p, pl, 0) * n + e] = __float_as_uint(v.x);
+        w[(long long)word_of(p, pl, 1) * n + e] = __float_as_uint(v.y);
+        w[(long long)word_of(p, pl, 2) * n + e] = __float_as_uint(v.z);
+        w[(long long)word_of(p, pl, 3) * n + e] = __float_as_uint(v.w);
     }
 }
 
 __global__ void words_to_state_kernel(float4* __restrict__ st, const uint32_t* __restrict__ w, long long n)
 {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    const long long rec = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rec >= 2 * n) return;
+    const long long e = rec >> 1; const int p = (int)(rec & 1);
 #pragma unroll
-    for (int p = 0; p < kStatePlanes; ++p) {
-        st[p * n + e] = make_float4(__uint_as_float(w[(4 * p + 0) * n + e]), __uint_as_float(w[(4 * p + 1) * n + e]),
-                                    __uint_as_float(w[(4 * p + 2) * n + e]), __uint_as_float(w[(4 * p + 3) * n + e]));
+    for (int pl = 0; pl < kStatePlanes; ++pl) {
+        st[(long long)pl * 2 * n + rec] =
+            make_float4(__uint_as_float(w[(long long)word_of(p, pl, 0) * n + e]),
+                        __uint_as_float(w[(long long)word_of(p, pl, 1) * n + e]),
+                        __uint_as_float(w[(long long)word_of(p, pl, 2) * n + e]),
+                        __uint_as_float(w[(long long)word_of(p, pl, 3) * n + e]));
     }
 }
 
@@ -234,6 +254,7 @@ struct pnr_env_s {
     int device;
     float4* state;
     float4* dyn;         // dynamics-mode planes or null
+    int diag;            // PNR_DIAG env var at create time (timing-only ablations; 0 in production)
     char err[512];
 };
 
@@ -398,14 +419,15 @@ int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, i
     pnr_get_constants(cfg, &h->k);
 
     DeviceGuard g(device_id);
-    hipError_t e = hipMalloc((void**)&h->state, sizeof(float4) * kStatePlanes * (size_t)num_envs);
+    hipError_t e = hipMalloc((void**)&h->state, sizeof(float4) * kStatePlanes * 2 * (size_t)num_envs);
     if (e != hipSuccess) { delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(state) failed: %s", hipGetErrorString(e)); }
-    (void)hipMemset(h->state, 0, sizeof(float4) * kStatePlanes * (size_t)num_envs);
+    (void)hipMemset(h->state, 0, sizeof(float4) * kStatePlanes * 2 * (size_t)num_envs);
     if (cfg->mode == PNR_MODE_DYNAMIC) {
         e = hipMalloc((void**)&h->dyn, sizeof(float4) * kDynPlanes * (size_t)num_envs);
         if (e != hipSuccess) { (void)hipFree(h->state); delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(dyn) failed: %s", hipGetErrorString(e)); }
         (void)hipMemset(h->dyn, 0, sizeof(float4) * kDynPlanes * (size_t)num_envs);
     }
+    { const char* e_ = getenv("PNR_DIAG"); h->diag = e_ ? atoi(e_) : 0; }
     fill_base(h);
     h->base.seed_lo = (unsigned)seed; h->base.seed_hi = (unsigned)(seed >> 32);
     *out = h;
@@ -433,7 +455,7 @@ int64_t pnr_num_envs(pnr_handle h) { return h ? h->n : -1; }
 
 const char* pnr_last_error(pnr_handle h) { return h ? h->err : g_err; }
 
-static inline unsigned grid_for(long long n) { return (unsigned)((n + kWave - 1) / kWave); }
+static inline unsigned grid_for(long long n) { return (unsigned)((n + kEnvsPerWave - 1) / kEnvsPerWave); }
 
 int pnr_reset(pnr_handle h, const uint8_t* mask, const float* joint_pos, const float* target_pos,
               float* obs_out, void* stream)
@@ -481,6 +503,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
         return fail(h, PNR_ERR_INVALID, "env-major actions must be 8-byte aligned");
     DeviceGuard g(h->device);
     KParams P = h->base;
+    P.diag = h->diag;
     P.T = T; P.actions = actions; P.obs = obs; P.reward = reward; P.done = done; P.trunc = truncated; P.info = info;
     const dim3 grid(grid_for(h->n)), block(kWave);
     hipStream_t st = (hipStream_t)stream;
@@ -523,7 +546,7 @@ int pnr_get_state(pnr_handle h, uint32_t* words_out, void* stream)
 {
     if (!h || !words_out) return fail(h, PNR_ERR_INVALID, "pnr_get_state: null argument");
     DeviceGuard g(h->device);
-    hipLaunchKernelGGL(state_to_words_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(state_to_words_kernel, dim3((unsigned)((2 * h->n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, h->state, words_out, h->n);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
@@ -533,7 +556,7 @@ int pnr_set_state(pnr_handle h, const uint32_t* words_in, void* stream)
 {
     if (!h || !words_in) return fail(h, PNR_ERR_INVALID, "pnr_set_state: null argument");
     DeviceGuard g(h->device);
-    hipLaunchKernelGGL(words_to_state_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(words_to_state_kernel, dim3((unsigned)((2 * h->n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, h->state, words_in, h->n);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;

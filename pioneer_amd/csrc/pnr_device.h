@@ -1,10 +1,18 @@
 // pnr_device.h — device-side building blocks of the kinematic ("parity mode")
 // step: integrator, forward kinematics, reward, reset draws, obs packing.
 //
+// Work decomposition: TWO lanes per env (a lane pair 2e, 2e+1), three joints per
+// lane.  Lane p of the pair owns joints 3p..3p+2: it integrates them, evaluates
+// their 15 sin/cos pairs and writes their 63 observation entries; the 12 values
+// the other half needs (cos/sin of the partner's joints for the forward
+// kinematics) cross by DPP quad_perm, which never touches LDS.  A 64-lane wave
+// therefore steps 32 envs and stages a 17.5 KB obs tile, so two waves fit per
+// SIMD at 65 536 envs: one wave's stores overlap the other's arithmetic.
+//
 // Compiled with -ffp-contract=off: the integrator reproduces the reference's
 // mixed float32/float64 arithmetic (NumPy 1.x promotion) operation by
 // operation, so nothing may be fused behind its back.  Where a fused
-// multiply-add is wanted (FK) it is written as __builtin_fmaf.
+// multiply-add is wanted (FK, polynomials) it is written as __builtin_fmaf.
 //
 // Reference lines are relative to xdralex/pioneer.
 #pragma once
@@ -16,9 +24,15 @@
 
 namespace pnr {
 
+constexpr int kWave = 64;
+constexpr int kLanesPerEnv = 2;
+constexpr int kJpl = kDof / kLanesPerEnv;      // joints per lane
+constexpr int kEnvsPerWave = kWave / kLanesPerEnv;
+constexpr int kTileFloats = kEnvsPerWave * kObsDim;
+
 // Kernel parameters (by value -> kernarg segment -> scalar loads).
 struct KParams {
-    float4* state;             // [6][n] float4 planes (library-owned)
+    float4* state;             // [3][2n] float4 planes (library-owned), see load_state
     const float* actions;      // step / rollout
     float* obs;
     float* reward;
@@ -34,7 +48,7 @@ struct KParams {
     int T;                     // steps per launch (rollout); 1 for step
     int max_steps;             // TimeLimit; 0 = off
     int auto_reset;
-    int pad0;
+    int diag;                  // timing-only ablation bits (PNR_DIAG), 0 in production
     double dt, eps;            // pioneer_knm_env.py:60-61
     double tlo[3], tspan[3];   // target_lo, target_hi - target_lo
     float v_max[kDof];         // max_v_to_r * (r_hi - r_lo); the limits themselves are constexpr (pnr_model.h)
@@ -43,42 +57,66 @@ struct KParams {
     float pad1;
 };
 
-// Per-env state held in registers.
-struct EnvState {
-    float a[kDof], v[kDof], r[kDof];
+// Per-lane state: this lane's three joints plus the env's common words (held by
+// both lanes of the pair after load).
+struct LaneState {
+    float a[kJpl], v[kJpl], r[kJpl];
     float tgt[3];
     float pot;
     uint32_t step, episode;
 };
 
-__device__ __forceinline__ void load_state(const float4* __restrict__ st, long long n, long long e, EnvState& s)
+// partner lane's value (lane ^ 1) by DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float xchg(float x)
 {
-    const float4 p0 = st[0 * n + e], p1 = st[1 * n + e], p2 = st[2 * n + e];
-    const float4 p3 = st[3 * n + e], p4 = st[4 * n + e], p5 = st[5 * n + e];
-    s.a[0] = p0.x; s.a[1] = p0.y; s.a[2] = p0.z; s.a[3] = p0.w;
-    s.a[4] = p1.x; s.a[5] = p1.y; s.v[0] = p1.z; s.v[1] = p1.w;
-    s.v[2] = p2.x; s.v[3] = p2.y; s.v[4] = p2.z; s.v[5] = p2.w;
-    s.r[0] = p3.x; s.r[1] = p3.y; s.r[2] = p3.z; s.r[3] = p3.w;
-    s.r[4] = p4.x; s.r[5] = p4.y; s.tgt[0] = p4.z; s.tgt[1] = p4.w;
-    s.tgt[2] = p5.x; s.pot = p5.y;
-    s.step = __float_as_uint(p5.z); s.episode = __float_as_uint(p5.w);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
 }
 
-__device__ __forceinline__ void store_state(float4* __restrict__ st, long long n, long long e, const EnvState& s)
+// State in HBM: three float4 planes [3][2n]; record (e, p) at index 2e + p:
+//   plane 0: a[3p] a[3p+1] a[3p+2] v[3p]
+//   plane 1: v[3p+1] v[3p+2] r[3p] r[3p+1]
+//   plane 2: r[3p+2] C0 C1 C2     p = 0: C = target xyz; p = 1: C = potential, step_index, episode
+// so a wave reads/writes each plane with one lane-contiguous 1-KiB dwordx4.
+__device__ __forceinline__ void load_state(const float4* __restrict__ st, long long n, long long rec, int p, LaneState& s)
 {
-    st[0 * n + e] = make_float4(s.a[0], s.a[1], s.a[2], s.a[3]);
-    st[1 * n + e] = make_float4(s.a[4], s.a[5], s.v[0], s.v[1]);
-    st[2 * n + e] = make_float4(s.v[2], s.v[3], s.v[4], s.v[5]);
-    st[3 * n + e] = make_float4(s.r[0], s.r[1], s.r[2], s.r[3]);
-    st[4 * n + e] = make_float4(s.r[4], s.r[5], s.tgt[0], s.tgt[1]);
-    st[5 * n + e] = make_float4(s.tgt[2], s.pot, __uint_as_float(s.step), __uint_as_float(s.episode));
+    const long long n2 = 2 * n;
+    const float4 p0 = st[rec], p1 = st[n2 + rec], p2 = st[2 * n2 + rec];
+    s.a[0] = p0.x; s.a[1] = p0.y; s.a[2] = p0.z; s.v[0] = p0.w;
+    s.v[1] = p1.x; s.v[2] = p1.y; s.r[0] = p1.z; s.r[1] = p1.w;
+    s.r[2] = p2.x;
+    const float o1 = xchg(p2.y), o2 = xchg(p2.z), o3 = xchg(p2.w);
+    s.tgt[0] = p ? o1 : p2.y; s.tgt[1] = p ? o2 : p2.z; s.tgt[2] = p ? o3 : p2.w;
+    s.pot = p ? p2.y : o1;
+    s.step = __float_as_uint(p ? p2.z : o2);
+    s.episode = __float_as_uint(p ? p2.w : o3);
 }
+
+__device__ __forceinline__ void store_state(float4* __restrict__ st, long long n, long long rec, int p, const LaneState& s)
+{
+    const long long n2 = 2 * n;
+    st[rec] = make_float4(s.a[0], s.a[1], s.a[2], s.v[0]);
+    st[n2 + rec] = make_float4(s.v[1], s.v[2], s.r[0], s.r[1]);
+    st[2 * n2 + rec] = make_float4(s.r[2], p ? s.pot : s.tgt[0], p ? __uint_as_float(s.step) : s.tgt[1],
+                                   p ? __uint_as_float(s.episode) : s.tgt[2]);
+}
+
+__device__ __forceinline__ void zero_state(LaneState& s)
+{
+#pragma unroll
+    for (int i = 0; i < kJpl; ++i) { s.a[i] = 0.f; s.v[i] = 0.f; s.r[i] = 0.f; }
+    s.tgt[0] = s.tgt[1] = s.tgt[2] = 0.f; s.pot = 0.f; s.step = 0; s.episode = 0;
+}
+
+// per-joint constants of this lane's joint i (joint 3p + i)
+__device__ __forceinline__ float lane_limit(int p, int i) { return p ? limit_hi(kJpl + i) : limit_hi(i); }
+__device__ __forceinline__ float lane_limit_cos(int p, int i) { return p ? kLimitCos[kJpl + i] : kLimitCos[i]; }
+__device__ __forceinline__ float lane_limit_sin(int p, int i) { return p ? kLimitSin[kJpl + i] : kLimitSin[i]; }
 
 // ---- sin/cos -------------------------------------------------------------------------
 // np.sin / np.cos of the float32 observation pieces (pioneer_knm_env.py:195-203).
 // Cody-Waite reduction by pi/2 with three float32 constants and FMA, then
 // degree-7/8 minimax polynomials on [-pi/4, pi/4]; max abs error 9.3e-8 for
-// |x| <= 2^16 (tests/test_sincos.py sweeps it against float64).  Every trig
+// |x| <= 2^16 (tests/test_gpu_sincos.py sweeps it against float64).  Every trig
 // argument of the obs except the raw action is bounded by construction
 // (|r| <= pi, |r - r_lo| <= 2 pi, |v| <= v_max); ~22 VALU ops per pair instead
 // of ocml's sincosf with its inlined Payne-Hanek path.
@@ -188,10 +226,12 @@ __device__ __forceinline__ double u01(uint32_t x) { return (double)(x >> 8) * (1
 
 // ---- reset: reset_world, pioneer_knm_env.py:76-105 --------------------------------
 // Draws r ~ U(r_lo, r_hi), target ~ U(target_lo, target_hi) from
-// Philox(key = seed, counter = (episode, global env id, block)); a = v = 0;
-// potential = 0 (quirk Q3); step_index = 0.  jp / tp override the draws
-// (reset_world's joint_positions / target_position arguments).
-__device__ __forceinline__ void reset_env(const KParams& P, EnvState& s, unsigned long long genv,
+// Philox(key = seed, counter = (episode, global env id, block)): words 0..5 are
+// the joints, 6..8 the target; a = v = 0; potential = 0 (quirk Q3);
+// step_index = 0.  jp / tp (this ENV's rows) override the draws, as
+// reset_world's joint_positions / target_position arguments do.  Both lanes of
+// a pair run this and keep their own three joints.
+__device__ __forceinline__ void reset_env(const KParams& P, LaneState& s, int p, unsigned long long genv,
                                           const float* jp, const float* tp)
 {
     uint32_t w[12];
@@ -202,36 +242,43 @@ __device__ __forceinline__ void reset_env(const KParams& P, EnvState& s, unsigne
         w[4 * b + 0] = o[0]; w[4 * b + 1] = o[1]; w[4 * b + 2] = o[2]; w[4 * b + 3] = o[3];
     }
 #pragma unroll
-    for (int i = 0; i < kDof; ++i) {
-        const double lo = (double)limit_lo(i), hi = (double)limit_hi(i);
-        const float drawn = (float)(lo + (hi - lo) * u01(w[i]));          // :80-81
-        s.r[i] = jp ? jp[i] : drawn;                                       // :94 (stored as float32)
-        s.a[i] = 0.0f;                                                     // :92
-        s.v[i] = 0.0f;                                                     // :93
+    for (int i = 0; i < kJpl; ++i) {
+        const double hi = (double)lane_limit(p, i), lo = -hi;
+        const uint32_t word = p ? w[kJpl + i] : w[i];
+        const float drawn = (float)(lo + (hi - lo) * u01(word));             // :80-81
+        s.r[i] = jp ? jp[kJpl * p + i] : drawn;                              // :94 (stored as float32)
+        s.a[i] = 0.0f;                                                       // :92
+        s.v[i] = 0.0f;                                                       // :93
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float drawn = (float)(P.tlo[k] + P.tspan[k] * u01(w[6 + k])); // :83-90
         s.tgt[k] = tp ? tp[k] : drawn;
     }
-    s.pot = 0.0f;                                                          // :105
-    s.step = 0;                                                            // bullet_env.py:99
+    s.pot = 0.0f;                                                            // :105
+    s.step = 0;                                                              // bullet_env.py:99
     s.episode += 1;
 }
 
 // ---- pose-dependent quantities -----------------------------------------------------
 struct Pose {
-    float c[kDof], s[kDof];  // cos r, sin r
+    float c[kJpl], s[kJpl];  // cos r, sin r of this lane's joints
     float ptr[3];            // pointer xyz
     float diff[3];
     float dist;
 };
 
-__device__ __forceinline__ void compute_pose(const EnvState& s, Pose& q)
+__device__ __forceinline__ void compute_pose(const LaneState& s, int p, Pose& q)
 {
+    float c6[kDof], s6[kDof];
 #pragma unroll
-    for (int i = 0; i < kDof; ++i) sincos_bounded(s.r[i], q.s[i], q.c[i]);
-    fk_pointer(q.c, q.s, q.ptr);
+    for (int i = 0; i < kJpl; ++i) {
+        sincos_bounded(s.r[i], q.s[i], q.c[i]);
+        const float oc = xchg(q.c[i]), os = xchg(q.s[i]);
+        c6[i] = p ? oc : q.c[i];        s6[i] = p ? os : q.s[i];
+        c6[kJpl + i] = p ? q.c[i] : oc; s6[kJpl + i] = p ? q.s[i] : os;
+    }
+    fk_pointer(c6, s6, q.ptr);
 #pragma unroll
     for (int k = 0; k < 3; ++k) q.diff[k] = s.tgt[k] - q.ptr[k];          // :154
     q.dist = sqrtf(__builtin_fmaf(q.diff[2], q.diff[2],
@@ -239,88 +286,74 @@ __device__ __forceinline__ void compute_pose(const EnvState& s, Pose& q)
 }
 
 // ---- observation: observe(), pioneer_knm_env.py:184-211 -----------------------------
-// Sink::put(f, value) receives feature f of this lane's env.
+// Sink::putj(f, v) writes per-joint feature f of this lane's joint column (the
+// sink adds 3p); Sink::putt(f0, f1, v) writes tail feature f0 (lane 0) or f1
+// (lane 1).  Tail pieces (126..136): lane 0 writes pointer + target, lane 1
+// diff + distance + potential.
 template <class Sink>
-__device__ __forceinline__ void emit_obs(const KParams& P, const EnvState& s, const Pose& q, Sink& out)
+__device__ __forceinline__ void emit_obs(const LaneState& s, const Pose& q, int p, Sink& out)
 {
 #pragma unroll
-    for (int i = 0; i < kDof; ++i) {
+    for (int i = 0; i < kJpl; ++i) {
         float sn, cs;
+        const float lim = lane_limit(p, i), lc = lane_limit_cos(p, i), ls = lane_limit_sin(p, i);
         // [0:18]  r, cos r, sin r
-        out.put(0 + i, s.r[i]); out.put(6 + i, q.c[i]); out.put(12 + i, q.s[i]);
+        out.putj(0 + i, s.r[i]); out.putj(6 + i, q.c[i]); out.putj(12 + i, q.s[i]);
         // [18:54] limits and their cos/sin (compile-time constants)
-        out.put(18 + i, limit_lo(i)); out.put(24 + i, kLimitCos[i]); out.put(30 + i, -kLimitSin[i]);
-        out.put(36 + i, limit_hi(i)); out.put(42 + i, kLimitCos[i]); out.put(48 + i, kLimitSin[i]);
+        out.putj(18 + i, -lim); out.putj(24 + i, lc); out.putj(30 + i, -ls);
+        out.putj(36 + i, lim);  out.putj(42 + i, lc); out.putj(48 + i, ls);
         // [54:72] r - r_lo (float32 subtraction, :191)
-        const float dlo = s.r[i] - limit_lo(i);
+        const float dlo = s.r[i] - (-lim);
         sincos_bounded(dlo, sn, cs);
-        out.put(54 + i, dlo); out.put(60 + i, cs); out.put(66 + i, sn);
+        out.putj(54 + i, dlo); out.putj(60 + i, cs); out.putj(66 + i, sn);
         // [72:90] r_hi - r (:192)
-        const float dhi = limit_hi(i) - s.r[i];
+        const float dhi = lim - s.r[i];
         sincos_bounded(dhi, sn, cs);
-        out.put(72 + i, dhi); out.put(78 + i, cs); out.put(84 + i, sn);
+        out.putj(72 + i, dhi); out.putj(78 + i, cs); out.putj(84 + i, sn);
         // [90:108] v
         sincos_bounded(s.v[i], sn, cs);
-        out.put(90 + i, s.v[i]); out.put(96 + i, cs); out.put(102 + i, sn);
+        out.putj(90 + i, s.v[i]); out.putj(96 + i, cs); out.putj(102 + i, sn);
         // [108:126] a (the action just given, quirk Q1)
         sincos_any(s.a[i], sn, cs);
-        out.put(108 + i, s.a[i]); out.put(114 + i, cs); out.put(120 + i, sn);
+        out.putj(108 + i, s.a[i]); out.putj(114 + i, cs); out.putj(120 + i, sn);
     }
+    // [126:137] p = 0: pointer xyz (126..128), target xyz (129..131)
+    //           p = 1: diff (132..134), distance (135), potential (136)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        out.put(126 + k, q.ptr[k]);   // pointer xyz
-        out.put(129 + k, s.tgt[k]);   // target xyz
-        out.put(132 + k, q.diff[k]);  // target - pointer
-    }
-    out.put(135, q.dist);
-    out.put(136, s.pot);
+    for (int k = 0; k < 3; ++k) out.putt(126 + k, 132 + k, p ? q.diff[k] : q.ptr[k]);
+    out.putt(129, 135, p ? q.dist : s.tgt[0]);
+    out.putt(130, 136, p ? s.pot : s.tgt[1]);
+    out.putt0(131, s.tgt[2]);
 }
 
 // Sinks -------------------------------------------------------------------------
-// feature-major [137][n]: lane-contiguous dword stores, coalesced as is
-struct SinkFeatureMajor {
-    float* base; long long n; bool valid;
-    __device__ __forceinline__ void put(int f, float v) { if (valid) base[(long long)f * n] = v; }
-};
-// env-major through an LDS tile [64][137]: row stride 137 dwords (odd) -> the 64
-// lanes of a ds_write_b32 hit distinct banks
+// env-major through an LDS tile [32][137]: the row stride of 137 dwords is odd, so
+// a pair-interleaved ds_write_b32 is at worst 2-way conflicted (free for writes)
 struct SinkLdsTile {
-    float* row;
-    __device__ __forceinline__ void put(int f, float v) { row[f] = v; }
+    float* row;    // tile + env_local * 137
+    int jo;        // 3p
+    int p;
+    __device__ __forceinline__ void putj(int f, float v) { row[f + jo] = v; }
+    __device__ __forceinline__ void putt(int f0, int f1, float v) { row[p ? f1 : f0] = v; }
+    __device__ __forceinline__ void putt0(int f0, float v) { if (!p) row[f0] = v; }
 };
-// env-major direct (masked reset only: rows of other envs must stay untouched)
-struct SinkRowDirect {
-    float* row; bool valid;
-    __device__ __forceinline__ void put(int f, float v) { if (valid) row[f] = v; }
-};
-
-// feature-major through an LDS tile [137][64]: lane-contiguous ds_write_b32, then
-// 16-byte stores where 16 lanes cover one feature's 64 envs (256 B) and a wave
-// instruction covers four features
+// feature-major through an LDS tile [137][32]
 struct SinkLdsFeatureTile {
-    float* col;   // tile + lane
-    __device__ __forceinline__ void put(int f, float v) { col[f * 64] = v; }
+    float* col;    // tile + env_local
+    int jo;
+    int p;
+    __device__ __forceinline__ void putj(int f, float v) { col[(f + jo) * kEnvsPerWave] = v; }
+    __device__ __forceinline__ void putt(int f0, int f1, float v) { col[(p ? f1 : f0) * kEnvsPerWave] = v; }
+    __device__ __forceinline__ void putt0(int f0, float v) { if (!p) col[f0 * kEnvsPerWave] = v; }
 };
-
-// Flush a [137][64] feature tile to obs[f*n + tile0 + 0..63].
-__device__ __forceinline__ void flush_feature_tile(const float* __restrict__ lds, float* __restrict__ dst,
-                                                   long long n, int nvalid, int lane)
-{
-    // dst = obs_t + tile0; row f lives at dst + f*n
-    if (nvalid == 64 && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(n * 4)) & 15u) == 0) {
-        const int sub = lane >> 4, col4 = (lane & 15) * 4;
-        for (int f0 = 0; f0 < kObsDim; f0 += 4) {
-            const int f = f0 + sub;
-            if (f < kObsDim) {
-                const float4 v = *reinterpret_cast<const float4*>(lds + f * 64 + col4);
-                *reinterpret_cast<float4*>(dst + (long long)f * n + col4) = v;
-            }
-        }
-    } else {
-        for (int f = 0; f < kObsDim; ++f)
-            if (lane < nvalid) dst[(long long)f * n + lane] = lds[f * 64 + lane];
-    }
-}
+// direct global stores with an element stride (masked reset only: rows / columns
+// of other envs must stay untouched); stride 1 = env-major row, n = feature-major
+struct SinkDirect {
+    float* base; long long stride; int jo; int p; bool on;
+    __device__ __forceinline__ void putj(int f, float v) { if (on) base[(long long)(f + jo) * stride] = v; }
+    __device__ __forceinline__ void putt(int f0, int f1, float v) { if (on) base[(long long)(p ? f1 : f0) * stride] = v; }
+    __device__ __forceinline__ void putt0(int f0, float v) { if (on && !p) base[(long long)f0 * stride] = v; }
+};
 
 // Copy a wave's LDS tile (rows [0, nvalid) of 137 floats) to its contiguous
 // place in an env-major obs batch with 16-byte lane-linear stores.
@@ -332,10 +365,31 @@ __device__ __forceinline__ void flush_tile(const float* __restrict__ lds, float*
         const int nvec = total >> 2;
         const float4* src4 = reinterpret_cast<const float4*>(lds);
         float4* dst4 = reinterpret_cast<float4*>(dst);
-        for (int j = lane; j < nvec; j += 64) dst4[j] = src4[j];
-        for (int j = (nvec << 2) + lane; j < total; j += 64) dst[j] = lds[j];
+        for (int j = lane; j < nvec; j += kWave) dst4[j] = src4[j];
+        for (int j = (nvec << 2) + lane; j < total; j += kWave) dst[j] = lds[j];
     } else {
-        for (int j = lane; j < total; j += 64) dst[j] = lds[j];
+        for (int j = lane; j < total; j += kWave) dst[j] = lds[j];
+    }
+}
+
+// Flush a [137][32] feature tile to obs[f*n + tile0 + 0..31]: 8 lanes x 16 B cover
+// one feature's 32 envs (128 B), a wave instruction covers eight features.
+__device__ __forceinline__ void flush_feature_tile(const float* __restrict__ lds, float* __restrict__ dst,
+                                                   long long n, int nvalid, int lane)
+{
+    if (nvalid == kEnvsPerWave && ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)(n * 4)) & 15u) == 0) {
+        const int sub = lane >> 3, col4 = (lane & 7) * 4;
+        for (int f0 = 0; f0 < kObsDim; f0 += 8) {
+            const int f = f0 + sub;
+            if (f < kObsDim) {
+                const float4 v = *reinterpret_cast<const float4*>(lds + f * kEnvsPerWave + col4);
+                *reinterpret_cast<float4*>(dst + (long long)f * n + col4) = v;
+            }
+        }
+    } else {
+        const int col = lane & (kEnvsPerWave - 1), half = lane >> 5;
+        for (int f = half; f < kObsDim; f += 2)
+            if (col < nvalid) dst[(long long)f * n + col] = lds[f * kEnvsPerWave + col];
     }
 }
 

@@ -12,7 +12,7 @@ namespace pnr {
 
 constexpr int kDof = 6;
 constexpr int kObsDim = 137;
-constexpr int kStatePlanes = 6;   // float4 planes per env (24 words)
+constexpr int kStatePlanes = 3;   // float4 planes per half-env record (2 x 12 = 24 words per env)
 constexpr int kDynPlanes = 9;     // float4 planes of dynamics-mode extra state (36 words)
 
 enum Axis : int { AX = 0, AY = 1, AZ = 2 };
