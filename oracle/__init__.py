@@ -11,5 +11,5 @@ Two restatements live here:
 * ``numpy_twin`` — an independent pure-NumPy transliteration of the same
   reference lines, used to cross-check the C code at small sizes.
 """
-from .binding import COracle, OrcParams, OrcState, build_oracle, oracle_lib_path  # noqa: F401
+from .binding import COracle, DynOracle, OrcParams, OrcState, build_oracle, oracle_lib_path  # noqa: F401
 from . import numpy_twin  # noqa: F401

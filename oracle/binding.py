@@ -173,3 +173,112 @@ class COracle:
     def load_state_words(self, w):
         w = np.ascontiguousarray(w, dtype=np.uint32).reshape(24, self.n)
         self.lib.orc_state_from_words(self._sp(), C.c_int64(self.n), _ptr(w, C.c_uint32))
+
+
+# ---- dynamics-mode oracle (pnr_dyn_oracle.c) --------------------------------------------------
+LINKS = 11
+
+
+class OrcDynParams(C.Structure):
+    _fields_ = [
+        ("kp", C.c_double), ("kd", C.c_double), ("torque_limit", C.c_double), ("gravity", C.c_double),
+        ("timestep", C.c_double), ("frame_skip", C.c_int32), ("teleport", C.c_int32),
+        ("randomize", C.c_int32), ("pad", C.c_int32),
+        ("joint_damping", C.c_double), ("joint_friction", C.c_double),
+        ("rand_mass_lo", C.c_double), ("rand_mass_hi", C.c_double),
+        ("rand_friction_lo", C.c_double), ("rand_friction_hi", C.c_double),
+        ("rand_damping_lo", C.c_double), ("rand_damping_hi", C.c_double),
+        ("ground_z", C.c_double), ("contact_kp", C.c_double), ("contact_kd", C.c_double),
+    ]
+
+
+DYN_STATE_DTYPE = np.dtype([
+    ("q", np.float64, DOF), ("qd", np.float64, DOF), ("mass_scale", np.float64, LINKS),
+    ("friction", np.float64, DOF), ("damping", np.float64, DOF),
+])
+
+
+class DynOracle(COracle):
+    """Batched dynamics-mode oracle: kinematic command state + simulated (q, qd)."""
+
+    def __init__(self, num_envs=1, dyn=None, **kw):
+        kw.setdefault("precision", ORC_DEV)
+        super().__init__(num_envs, **kw)
+        L = self.lib
+        assert L.orc_dyn_sizeof_params() == C.sizeof(OrcDynParams), "orc_dyn_params layout drift"
+        assert L.orc_dyn_sizeof_state() == DYN_STATE_DTYPE.itemsize, "orc_dyn_state layout drift"
+        self.d = OrcDynParams()
+        L.orc_dyn_params_default(C.byref(self.d))
+        self.d.timestep = self.p.timestep
+        self.d.frame_skip = self.p.frame_skip
+        for k, v in (dyn or {}).items():
+            assert hasattr(self.d, k), k
+            setattr(self.d, k, v)
+        self.dstate = np.zeros(self.n, dtype=DYN_STATE_DTYPE)
+        self.dstate["mass_scale"] = 1.0
+
+    def _dp(self):
+        return self.dstate.ctypes.data_as(C.c_void_p)
+
+    def reset(self, mask=None, joint_pos=None, target_pos=None, want_obs=True):
+        n = self.n
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        jp = None if joint_pos is None else np.ascontiguousarray(joint_pos, dtype=np.float64).reshape(n, DOF)
+        tp = None if target_pos is None else np.ascontiguousarray(target_pos, dtype=np.float64).reshape(n, 3)
+        obs = np.zeros((n, OBS)) if want_obs else None
+        self.lib.orc_dyn_reset_batch(C.byref(self.d), C.byref(self.p), self._sp(), self._dp(), C.c_int64(n),
+                                     C.c_int64(self.off), _ptr(m, C.c_uint8), _ptr(jp, C.c_double),
+                                     _ptr(tp, C.c_double), _ptr(obs, C.c_double), C.c_int(self.nthreads))
+        return obs
+
+    def step(self, actions, want_obs=True, want_info=False):
+        n = self.n
+        act = np.ascontiguousarray(actions, dtype=np.float32).reshape(n, DOF)
+        obs = np.empty((n, OBS)) if want_obs else None
+        rew = np.empty(n); done = np.empty(n, dtype=np.uint8); trunc = np.empty(n, dtype=np.uint8)
+        info = np.empty((n, 4)) if want_info else None
+        self.lib.orc_dyn_step_batch(C.byref(self.d), C.byref(self.p), self._sp(), self._dp(), C.c_int64(n),
+                                    C.c_int64(self.off), _ptr(act, C.c_float), _ptr(obs, C.c_double),
+                                    _ptr(rew, C.c_double), _ptr(done, C.c_uint8), _ptr(trunc, C.c_uint8),
+                                    _ptr(info, C.c_double), C.c_int(self.nthreads))
+        return (obs, rew, done, trunc, info) if want_info else (obs, rew, done, trunc)
+
+    # single-env helpers on dstate[e]
+    def _one(self, e=0):
+        return C.c_void_p(self.dstate.ctypes.data + e * DYN_STATE_DTYPE.itemsize)
+
+    def aba(self, tau, gravity=0.0, f_tip=None, e=0):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        qdd = np.empty(DOF)
+        f = None if f_tip is None else np.ascontiguousarray(f_tip, dtype=np.float64)
+        self.lib.orc_dyn_aba(self._one(e), _ptr(tau, C.c_double), C.c_double(gravity), _ptr(f, C.c_double),
+                             _ptr(qdd, C.c_double))
+        return qdd
+
+    def energy(self, gravity=0.0, e=0):
+        ke, pe = C.c_double(), C.c_double()
+        self.lib.orc_dyn_energy(self._one(e), C.c_double(gravity), C.byref(ke), C.byref(pe))
+        return ke.value, pe.value
+
+    def tip(self, e=0):
+        pos, vel = np.empty(3), np.empty(3)
+        self.lib.orc_dyn_tip(self._one(e), _ptr(pos, C.c_double), _ptr(vel, C.c_double))
+        return pos, vel
+
+    def substep(self, r_ref, v_ref, e=0):
+        r = np.ascontiguousarray(r_ref, dtype=np.float64); v = np.ascontiguousarray(v_ref, dtype=np.float64)
+        self.lib.orc_dyn_substep(C.byref(self.d), C.byref(self.p), self._one(e), _ptr(r, C.c_double), _ptr(v, C.c_double))
+
+    def dyn_words(self):
+        """Engine interchange: planar float32 [36][n] (include/pioneer_amd.h pnr_get_dyn_state)."""
+        w = np.zeros((36, self.n), dtype=np.float32)
+        w[0:6] = self.dstate["q"].T; w[6:12] = self.dstate["qd"].T
+        w[12:23] = self.dstate["mass_scale"].T; w[23:29] = self.dstate["friction"].T
+        w[29:35] = self.dstate["damping"].T
+        return w
+
+    def load_dyn_words(self, w):
+        w = np.asarray(w, dtype=np.float32).reshape(36, self.n)
+        self.dstate["q"] = w[0:6].T; self.dstate["qd"] = w[6:12].T
+        self.dstate["mass_scale"] = w[12:23].T; self.dstate["friction"] = w[23:29].T
+        self.dstate["damping"] = w[29:35].T

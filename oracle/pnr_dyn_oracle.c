@@ -1,2 +1,363 @@
+/*
+ * pnr_dyn_oracle.c — float64 dynamics-mode oracle (see pnr_dyn_oracle.h: TEST
+ * INFRASTRUCTURE, PARITY UNPINNED).  Deliberately generic and slow: 6x6 spatial
+ * matrices, explicit Pluecker transforms (Featherstone, "Rigid Body Dynamics
+ * Algorithms", ch. 2 and Table 7.1), so that it shares no shortcuts with the
+ * specialised HIP kernel it checks.
+ *
+ * Conventions: motion vectors [w; v], force vectors [n; f], all in body
+ * coordinates at the body-frame origin; joint i connects body i-1 (body 0 = the
+ * fixed base) to body i: translate by o_i in the parent frame, rotate by q_i
+ * about a coordinate axis.
+ */
 #include "pnr_dyn_oracle.h"
-int orc_dyn_available(void) { return 0; }
+
+#include <math.h>
+#include <string.h>
+
+/* ---- model table (assets/pioneer_knm_6dof.urdf, fixed joints merged) -------------------- */
+static const int AXIS[ORC_DOF] = {2, 1, 1, 0, 1, 0};                 /* z y y x y x  (urdf:213,226,234,242,255,263) */
+static const double ORIGIN[ORC_DOF][3] = {                            /* joint origins in the parent body frame */
+    {0, 0, 0}, {0, 0, 3}, {0, 0, 11}, {0, 1, 0}, {11, 0, 0}, {0, 0, 0}};
+static const double TIP[3] = {3.6, 0.0, 1.9};                         /* urdf:271-275 */
+/* URDF link -> moving body (0-based), -1 = static base; link order:
+ * base rotator1 hinge1 arm1 arm2 rotator2 hinge2 arm3 rotator3 effector pointer */
+static const int LINK_BODY[ORC_LINKS] = {-1, 0, 0, 1, 2, 3, 3, 4, 5, 5, 5};
+static const double FRICTION_EPS = 0.05;                              /* smooth sign(qd) = qd / sqrt(qd^2 + eps^2) */
+
+typedef double vec6[6];
+typedef double mat6[6][6];
+
+static void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* rotation matrix R(axis, q): child coordinates -> parent coordinates */
+static void rot_axis(int axis, double q, double R[3][3])
+{
+    double c = cos(q), s = sin(q);
+    memset(R, 0, 9 * sizeof(double));
+    int a = axis, b = (axis + 1) % 3, d = (axis + 2) % 3;
+    R[a][a] = 1; R[b][b] = c; R[b][d] = -s; R[d][b] = s; R[d][d] = c;
+}
+
+/* 6x6 motion transform parent -> child: X = [E 0; -E rx  E], E = R^T */
+static void xform_motion(int axis, double q, const double r[3], mat6 X)
+{
+    double R[3][3], E[3][3];
+    rot_axis(axis, q, R);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) E[i][j] = R[j][i];
+    double rx[3][3] = {{0, -r[2], r[1]}, {r[2], 0, -r[0]}, {-r[1], r[0], 0}};
+    memset(X, 0, sizeof(mat6));
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        X[i][j] = E[i][j]; X[3 + i][3 + j] = E[i][j];
+        double t = 0; for (int k = 0; k < 3; k++) t += E[i][k] * rx[k][j];
+        X[3 + i][j] = -t;
+    }
+}
+
+static void matvec6(const mat6 A, const vec6 x, vec6 y)
+{
+    for (int i = 0; i < 6; i++) { double t = 0; for (int j = 0; j < 6; j++) t += A[i][j] * x[j]; y[i] = t; }
+}
+static void matTvec6(const mat6 A, const vec6 x, vec6 y)
+{
+    for (int i = 0; i < 6; i++) { double t = 0; for (int j = 0; j < 6; j++) t += A[j][i] * x[j]; y[i] = t; }
+}
+/* v x m (motion) */
+static void crm(const vec6 v, const vec6 m, vec6 o)
+{
+    double a[3], b[3], c[3];
+    cross3(v, m, a); cross3(v, m + 3, b); cross3(v + 3, m, c);
+    for (int i = 0; i < 3; i++) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+/* v x* f (force) */
+static void crf(const vec6 v, const vec6 f, vec6 o)
+{
+    double a[3], b[3], c[3];
+    cross3(v, f, a); cross3(v + 3, f + 3, b); cross3(v, f + 3, c);
+    for (int i = 0; i < 3; i++) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+
+/* spatial inertia of each moving body about its frame origin from the per-link scales */
+static void body_inertias(const double scale[ORC_LINKS], mat6 I[ORC_DOF], double mass[ORC_DOF], double h[ORC_DOF][3])
+{
+    double Ibar[ORC_DOF][3][3];
+    memset(Ibar, 0, sizeof(Ibar)); memset(mass, 0, ORC_DOF * sizeof(double)); memset(h, 0, ORC_DOF * 3 * sizeof(double));
+    for (int l = 0; l < ORC_LINKS; l++) {
+        int b = LINK_BODY[l];
+        if (b < 0) continue;
+        double m = 1.0 * scale[l], in = 1.0 * scale[l];   /* mass 1, inertia diag(1,1,1) (e.g. urdf:44-47) */
+        const double zero[3] = {0, 0, 0};
+        const double* c = (l == ORC_LINKS - 1) ? TIP : zero; /* only the pointer link is offset in its body */
+        mass[b] += m;
+        for (int k = 0; k < 3; k++) h[b][k] += m * c[k];
+        double c2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+            Ibar[b][i][j] += (i == j ? in + m * c2 : 0.0) - m * c[i] * c[j];   /* parallel axis */
+    }
+    for (int b = 0; b < ORC_DOF; b++) {
+        memset(I[b], 0, sizeof(mat6));
+        double hx[3][3] = {{0, -h[b][2], h[b][1]}, {h[b][2], 0, -h[b][0]}, {-h[b][1], h[b][0], 0}};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+            I[b][i][j] = Ibar[b][i][j];
+            I[b][i][3 + j] = hx[i][j];
+            I[b][3 + i][j] = hx[j][i];
+            I[b][3 + i][3 + j] = (i == j) ? mass[b] : 0.0;
+        }
+    }
+}
+
+/* world pose of every body: R0[i] (body -> world), p0[i] (origin) */
+static void world_poses(const double q[ORC_DOF], double R0[ORC_DOF][3][3], double p0[ORC_DOF][3])
+{
+    double Rp[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, pp[3] = {0, 0, 0};
+    for (int i = 0; i < ORC_DOF; i++) {
+        double R[3][3];
+        rot_axis(AXIS[i], q[i], R);
+        for (int a = 0; a < 3; a++) {
+            p0[i][a] = pp[a];
+            for (int k = 0; k < 3; k++) p0[i][a] += Rp[a][k] * ORIGIN[i][k];
+        }
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            double t = 0; for (int k = 0; k < 3; k++) t += Rp[a][k] * R[k][b];
+            R0[i][a][b] = t;
+        }
+        memcpy(Rp, R0[i], sizeof(Rp)); memcpy(pp, p0[i], sizeof(pp));
+    }
+}
+
+static void body_velocities(const orc_dyn_state* s, mat6 X[ORC_DOF], vec6 v[ORC_DOF])
+{
+    vec6 vp = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ORC_DOF; i++) {
+        xform_motion(AXIS[i], s->q[i], ORIGIN[i], X[i]);
+        matvec6(X[i], vp, v[i]);
+        v[i][AXIS[i]] += s->qd[i];
+        memcpy(vp, v[i], sizeof(vec6));
+    }
+}
+
+void orc_dyn_aba(const orc_dyn_state* s, const double tau[ORC_DOF], double gravity,
+                 const double f_tip_world[3], double qdd[ORC_DOF])
+{
+    mat6 I[ORC_DOF], X[ORC_DOF], IA[ORC_DOF];
+    vec6 v[ORC_DOF], c[ORC_DOF], pA[ORC_DOF], U[ORC_DOF];
+    double mass[ORC_DOF], h[ORC_DOF][3], D[ORC_DOF], u[ORC_DOF];
+    body_inertias(s->mass_scale, I, mass, h);
+    body_velocities(s, X, v);
+
+    /* pass 1: velocity-product accelerations and bias forces */
+    for (int i = 0; i < ORC_DOF; i++) {
+        vec6 vj = {0, 0, 0, 0, 0, 0}, Iv;
+        vj[AXIS[i]] = s->qd[i];
+        crm(v[i], vj, c[i]);
+        memcpy(IA[i], I[i], sizeof(mat6));
+        matvec6(I[i], v[i], Iv);
+        crf(v[i], Iv, pA[i]);
+    }
+    if (f_tip_world) {
+        /* external force on the pointer, expressed in body-6 coordinates at its origin */
+        double R0[ORC_DOF][3][3], p0[ORC_DOF][3], fb[3], nb[3];
+        world_poses(s->q, R0, p0);
+        for (int a = 0; a < 3; a++) { fb[a] = 0; for (int k = 0; k < 3; k++) fb[a] += R0[5][k][a] * f_tip_world[k]; }
+        cross3(TIP, fb, nb);
+        for (int a = 0; a < 3; a++) { pA[5][a] -= nb[a]; pA[5][3 + a] -= fb[a]; }
+    }
+    /* pass 2: articulated inertias, tip to base */
+    for (int i = ORC_DOF - 1; i >= 0; i--) {
+        int k = AXIS[i];
+        for (int r = 0; r < 6; r++) U[i][r] = IA[i][r][k];
+        D[i] = U[i][k];
+        u[i] = tau[i] - pA[i][k];
+        if (i > 0) {
+            mat6 Ia, T; vec6 pa, Iac, t6;
+            for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) Ia[r][cc] = IA[i][r][cc] - U[i][r] * U[i][cc] / D[i];
+            matvec6(Ia, c[i], Iac);
+            for (int r = 0; r < 6; r++) pa[r] = pA[i][r] + Iac[r] + U[i][r] * u[i] / D[i];
+            /* IA[parent] += X^T Ia X ; pA[parent] += X^T pa */
+            for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) {
+                double t = 0; for (int m = 0; m < 6; m++) t += Ia[r][m] * X[i][m][cc];
+                T[r][cc] = t;
+            }
+            for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) {
+                double t = 0; for (int m = 0; m < 6; m++) t += X[i][m][r] * T[m][cc];
+                IA[i - 1][r][cc] += t;
+            }
+            matTvec6(X[i], pa, t6);
+            for (int r = 0; r < 6; r++) pA[i - 1][r] += t6[r];
+        }
+    }
+    /* pass 3: accelerations, base to tip; gravity as a base acceleration of +g along z */
+    vec6 ap = {0, 0, 0, 0, 0, gravity};
+    for (int i = 0; i < ORC_DOF; i++) {
+        vec6 a;
+        matvec6(X[i], ap, a);
+        for (int r = 0; r < 6; r++) a[r] += c[i][r];
+        double t = 0; for (int r = 0; r < 6; r++) t += U[i][r] * a[r];
+        qdd[i] = (u[i] - t) / D[i];
+        a[AXIS[i]] += qdd[i];
+        memcpy(ap, a, sizeof(vec6));
+    }
+}
+
+void orc_dyn_energy(const orc_dyn_state* s, double gravity, double* kinetic, double* potential)
+{
+    mat6 I[ORC_DOF], X[ORC_DOF]; vec6 v[ORC_DOF];
+    double mass[ORC_DOF], h[ORC_DOF][3], R0[ORC_DOF][3][3], p0[ORC_DOF][3];
+    body_inertias(s->mass_scale, I, mass, h);
+    body_velocities(s, X, v);
+    world_poses(s->q, R0, p0);
+    double ke = 0, pe = 0;
+    for (int i = 0; i < ORC_DOF; i++) {
+        vec6 Iv; matvec6(I[i], v[i], Iv);
+        for (int r = 0; r < 6; r++) ke += 0.5 * v[i][r] * Iv[r];
+        double hz = 0; for (int k = 0; k < 3; k++) hz += R0[i][2][k] * h[i][k];
+        pe += gravity * (mass[i] * p0[i][2] + hz);
+    }
+    *kinetic = ke; *potential = pe;
+}
+
+void orc_dyn_tip(const orc_dyn_state* s, double pos[3], double vel[3])
+{
+    mat6 X[ORC_DOF]; vec6 v[ORC_DOF];
+    double R0[ORC_DOF][3][3], p0[ORC_DOF][3], wxt[3], vb[3];
+    body_velocities(s, X, v);
+    world_poses(s->q, R0, p0);
+    cross3(v[5], TIP, wxt);
+    for (int a = 0; a < 3; a++) vb[a] = v[5][3 + a] + wxt[a];
+    for (int a = 0; a < 3; a++) {
+        pos[a] = p0[5][a]; vel[a] = 0;
+        for (int k = 0; k < 3; k++) { pos[a] += R0[5][a][k] * TIP[k]; vel[a] += R0[5][a][k] * vb[k]; }
+    }
+}
+
+void orc_dyn_params_default(orc_dyn_params* d)
+{
+    memset(d, 0, sizeof(*d));
+    d->kp = 4000.0; d->kd = 400.0; d->torque_limit = 0.0;
+    d->gravity = 0.0; d->timestep = 1.0 / 240; d->frame_skip = 10;
+    d->teleport = 0; d->randomize = 0;
+    d->joint_damping = 0.0; d->joint_friction = 0.0;
+    d->rand_mass_lo = 0.5; d->rand_mass_hi = 1.5;
+    d->rand_friction_lo = 0.0; d->rand_friction_hi = 0.1;
+    d->rand_damping_lo = 0.0; d->rand_damping_hi = 0.1;
+    d->ground_z = NAN; d->contact_kp = 2000.0; d->contact_kd = 50.0;
+}
+
+void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state* s,
+                     const double r_ref[ORC_DOF], const double v_ref[ORC_DOF])
+{
+    double tau[ORC_DOF], qdd[ORC_DOF], ftip[3] = {0, 0, 0};
+    const double* fext = NULL;
+    for (int i = 0; i < ORC_DOF; i++) {
+        double t = 0.0;
+        if (!d->teleport) {
+            t = d->kp * (r_ref[i] - s->q[i]) + d->kd * (v_ref[i] - s->qd[i]);
+            if (d->torque_limit > 0) t = t > d->torque_limit ? d->torque_limit : (t < -d->torque_limit ? -d->torque_limit : t);
+        }
+        t -= s->damping[i] * s->qd[i];
+        t -= s->friction[i] * s->qd[i] / sqrt(s->qd[i] * s->qd[i] + FRICTION_EPS * FRICTION_EPS);
+        tau[i] = t;
+    }
+    if (d->ground_z == d->ground_z) {
+        double pos[3], vel[3];
+        orc_dyn_tip(s, pos, vel);
+        double depth = d->ground_z - pos[2];
+        if (depth > 0) {
+            double fz = d->contact_kp * depth - d->contact_kd * vel[2];
+            ftip[2] = fz > 0 ? fz : 0.0;
+            fext = ftip;
+        }
+    }
+    orc_dyn_aba(s, tau, d->gravity, fext, qdd);
+    for (int i = 0; i < ORC_DOF; i++) {          /* semi-implicit Euler + inelastic joint limits */
+        s->qd[i] += qdd[i] * d->timestep;
+        s->q[i] += s->qd[i] * d->timestep;
+        double hi = (double)p->r_hi[i], lo = (double)p->r_lo[i];
+        if (s->q[i] > hi) { s->q[i] = hi; if (s->qd[i] > 0) s->qd[i] = 0; }
+        if (s->q[i] < lo) { s->q[i] = lo; if (s->qd[i] < 0) s->qd[i] = 0; }
+    }
+}
+
+void orc_dyn_reset(const orc_dyn_params* d, const orc_params* p, const orc_state* ks, orc_dyn_state* s,
+                   uint64_t genv, uint32_t episode_drawn)
+{
+    for (int i = 0; i < ORC_DOF; i++) { s->q[i] = (double)(float)ks->r[i]; s->qd[i] = 0.0; }
+    double u[24];
+    if (d->randomize)
+        for (uint32_t b = 0; b < 6; b++) orc_draw_block(p, genv, episode_drawn, 3 + b, u + 4 * b);
+    for (int l = 0; l < ORC_LINKS; l++)
+        s->mass_scale[l] = d->randomize ? (double)(float)(d->rand_mass_lo + (d->rand_mass_hi - d->rand_mass_lo) * u[l]) : 1.0;
+    for (int i = 0; i < ORC_DOF; i++) {
+        s->friction[i] = d->randomize ? (double)(float)(d->rand_friction_lo + (d->rand_friction_hi - d->rand_friction_lo) * u[11 + i])
+                                      : (double)(float)d->joint_friction;
+        s->damping[i] = d->randomize ? (double)(float)(d->rand_damping_lo + (d->rand_damping_hi - d->rand_damping_lo) * u[17 + i])
+                                     : (double)(float)d->joint_damping;
+    }
+}
+
+void orc_dyn_step(const orc_dyn_params* d, const orc_params* p, orc_state* ks, orc_dyn_state* s,
+                  uint64_t genv, const float action[ORC_DOF], double obs[ORC_OBS],
+                  double* reward, uint8_t* done_out, uint8_t* trunc_out, double info[4])
+{
+    orc_integrate(p, ks, action);                 /* the kinematic command generator (parity-mode state) */
+    double r_ref[ORC_DOF], v_ref[ORC_DOF];
+    for (int i = 0; i < ORC_DOF; i++) { r_ref[i] = ks->r[i]; v_ref[i] = (double)ks->v[i]; }
+    if (d->teleport)                              /* resetJointState: pioneer_knm_env.py:148, bullet_scene.py:157-165 */
+        for (int i = 0; i < ORC_DOF; i++) { s->q[i] = r_ref[i]; s->qd[i] = 0.0; }
+    for (int k = 0; k < d->frame_skip; k++) orc_dyn_substep(d, p, s, r_ref, v_ref);   /* World.step, bullet_scene.py:273-275 */
+    /* device storage model: q, qd are float32 between steps */
+    double qf[ORC_DOF], qdf[ORC_DOF];
+    for (int i = 0; i < ORC_DOF; i++) {
+        s->q[i] = qf[i] = (double)(float)s->q[i];
+        s->qd[i] = qdf[i] = (double)(float)s->qd[i];
+        /* teleport = the reference's semantics: its obs shows the env's own v (pioneer_knm_env.py:202),
+         * not Bullet's joint velocity (which resetJointState zeroes) */
+        if (d->teleport) qdf[i] = (double)ks->v[i];
+    }
+    int flags = orc_reward(p, ks, qf, reward, info);
+    int done = flags & 1, trunc = (flags >> 1) & 1;
+    if (done_out) *done_out = (uint8_t)done;
+    if (trunc_out) *trunc_out = (uint8_t)trunc;
+    if (p->auto_reset && (done || trunc)) {
+        orc_reset(p, ks, genv, NULL, NULL);
+        orc_dyn_reset(d, p, ks, s, genv, ks->episode - 1);
+        for (int i = 0; i < ORC_DOF; i++) { qf[i] = s->q[i]; qdf[i] = 0.0; }
+    }
+    if (obs) orc_observe_qv(p, ks, qf, qdf, 0, obs);
+}
+
+void orc_dyn_reset_batch(const orc_dyn_params* d, const orc_params* p, orc_state* ks, orc_dyn_state* s,
+                         int64_t n, int64_t off, const uint8_t* mask, const double* joint_pos,
+                         const double* target_pos, double* obs, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < n; e++) {
+        if (mask && !mask[e]) continue;
+        orc_reset(p, &ks[e], (uint64_t)(off + e), joint_pos ? joint_pos + 6 * e : NULL,
+                  target_pos ? target_pos + 3 * e : NULL);
+        orc_dyn_reset(d, p, &ks[e], &s[e], (uint64_t)(off + e), ks[e].episode - 1);
+        if (obs) {
+            double qd0[ORC_DOF] = {0, 0, 0, 0, 0, 0};
+            orc_observe_qv(p, &ks[e], s[e].q, qd0, 0, obs + (int64_t)ORC_OBS * e);
+        }
+    }
+}
+
+void orc_dyn_step_batch(const orc_dyn_params* d, const orc_params* p, orc_state* ks, orc_dyn_state* s,
+                        int64_t n, int64_t off, const float* actions, double* obs,
+                        double* reward, uint8_t* done, uint8_t* truncated, double* info, int nthreads)
+{
+    (void)nthreads;
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int64_t e = 0; e < n; e++)
+        orc_dyn_step(d, p, &ks[e], &s[e], (uint64_t)(off + e), actions + 6 * e,
+                     obs ? obs + (int64_t)ORC_OBS * e : NULL, reward ? reward + e : NULL,
+                     done ? done + e : NULL, truncated ? truncated + e : NULL, info ? info + 4 * e : NULL);
+}
+
+int orc_dyn_sizeof_params(void) { return (int)sizeof(orc_dyn_params); }
+int orc_dyn_sizeof_state(void) { return (int)sizeof(orc_dyn_state); }

@@ -1,11 +1,91 @@
-/* pnr_dyn_oracle.h — float64 restatement of the dynamics-mode step (ABA + PD).
- * TEST INFRASTRUCTURE ONLY (see pnr_oracle.h).  Filled in with the dynamics kernel. */
+/*
+ * pnr_dyn_oracle.h — float64 CPU statement of the DYNAMICS-MODE step
+ * (Featherstone articulated-body algorithm + PD joint torques + joint limits +
+ * pointer/ground penalty contact, 10 sub-steps at 1/240 s).
+ *
+ * TEST INFRASTRUCTURE ONLY (see pnr_oracle.h).  PARITY UNPINNED: the reference
+ * never exercises dynamics (its World.step is a physical no-op)
+ * and pins nothing here; this oracle is validated by physics (tests/test_dyn_oracle.py:
+ * ABA == M^-1(tau - C) from an independent NumPy CRBA/RNEA, energy conservation,
+ * teleport mode == kinematic mode) and then used as the checker of the HIP kernel.
+ *
+ * Model: the six moving bodies obtained by merging the URDF's fixed joints
+ * (assets/pioneer_knm_6dof.urdf:27-275): every link has mass 1 and inertia
+ * diag(1,1,1) about its own frame origin; per-link mass scales s[11] (domain
+ * randomisation) multiply mass and inertia of link l.
+ */
 #ifndef PNR_DYN_ORACLE_H
 #define PNR_DYN_ORACLE_H
+
+#include <stdint.h>
+#include "pnr_oracle.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
-int orc_dyn_available(void);
+
+#define ORC_LINKS 11
+
+typedef struct orc_dyn_params {
+    double kp, kd;            /* PD gains on (r - q), (v - qd): Joint.control_position's positionGain/velocityGain role, bullet_scene.py:123-142 */
+    double torque_limit;      /* `force` cap; <= 0 = unlimited */
+    double gravity;           /* SimulationConfig.gravity, bullet_env.py:41 (setGravity(0,0,-g), bullet_scene.py:270) */
+    double timestep;          /* 1/240 */
+    int32_t frame_skip;       /* 10 sub-steps (World.step, bullet_scene.py:273-275) */
+    int32_t teleport;         /* 1: q := r, qd := 0 before the sub-steps and no motor torque (the reference's resetJointState semantics) */
+    int32_t randomize;        /* per-env draws at reset */
+    int32_t pad;
+    double joint_damping, joint_friction;     /* defaults when not randomised (URDF: 0) */
+    double rand_mass_lo, rand_mass_hi;
+    double rand_friction_lo, rand_friction_hi;
+    double rand_damping_lo, rand_damping_hi;
+    double ground_z;          /* NaN = no contact plane */
+    double contact_kp, contact_kd;
+} orc_dyn_params;
+
+typedef struct orc_dyn_state {
+    double q[ORC_DOF], qd[ORC_DOF];
+    double mass_scale[ORC_LINKS];
+    double friction[ORC_DOF], damping[ORC_DOF];
+} orc_dyn_state;
+
+void orc_dyn_params_default(orc_dyn_params* d);
+
+/* forward dynamics: qdd = ABA(q, qd, tau) with gravity g along -z and an optional
+ * external force on the pointer (world frame, applied at the pointer origin) */
+void orc_dyn_aba(const orc_dyn_state* s, const double tau[ORC_DOF], double gravity,
+                 const double f_tip_world[3], double qdd[ORC_DOF]);
+
+/* kinetic energy and gravitational potential energy (for conservation tests) */
+void orc_dyn_energy(const orc_dyn_state* s, double gravity, double* kinetic, double* potential);
+
+/* pointer position and linear velocity in the world frame */
+void orc_dyn_tip(const orc_dyn_state* s, double pos[3], double vel[3]);
+
+/* one sub-step (semi-implicit Euler at d->timestep) tracking (r_ref, v_ref) */
+void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state* s,
+                     const double r_ref[ORC_DOF], const double v_ref[ORC_DOF]);
+
+/* reset of the dynamics state after orc_reset: q = r, qd = 0, parameter draws */
+void orc_dyn_reset(const orc_dyn_params* d, const orc_params* p, const orc_state* ks, orc_dyn_state* s,
+                   uint64_t global_env_id, uint32_t episode_drawn);
+
+/* BulletEnv.step in dynamics mode: kinematic command integration, frame_skip sub-steps of
+ * ABA + PD, reward/obs from the simulated q, qd; auto-reset as in orc_step */
+void orc_dyn_step(const orc_dyn_params* d, const orc_params* p, orc_state* ks, orc_dyn_state* s,
+                  uint64_t global_env_id, const float action[ORC_DOF], double obs[ORC_OBS],
+                  double* reward, uint8_t* done, uint8_t* truncated, double info[4]);
+
+void orc_dyn_reset_batch(const orc_dyn_params* d, const orc_params* p, orc_state* ks, orc_dyn_state* s,
+                         int64_t n, int64_t env_id_offset, const uint8_t* mask, const double* joint_pos,
+                         const double* target_pos, double* obs, int nthreads);
+void orc_dyn_step_batch(const orc_dyn_params* d, const orc_params* p, orc_state* ks, orc_dyn_state* s,
+                        int64_t n, int64_t env_id_offset, const float* actions, double* obs,
+                        double* reward, uint8_t* done, uint8_t* truncated, double* info, int nthreads);
+
+int orc_dyn_sizeof_params(void);
+int orc_dyn_sizeof_state(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,6 +126,16 @@ void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint3
 /* 24-bit uniform in [0,1): exact in float32 and float64 */
 static double u01(uint32_t x) { return (double)(x >> 8) * (1.0 / 16777216.0); }
 
+/* uniform draw w of Philox block b (4 words per block) for (seed, env, episode) */
+void orc_draw_block(const orc_params* p, uint64_t genv, uint32_t episode, uint32_t block, double u[4])
+{
+    uint32_t key[2] = { (uint32_t)p->seed, (uint32_t)(p->seed >> 32) };
+    uint32_t ctr[4] = { episode, (uint32_t)genv, (uint32_t)(genv >> 32), block };
+    uint32_t w[4];
+    orc_philox4x32_10(ctr, key, w);
+    for (int i = 0; i < 4; i++) u[i] = u01(w[i]);
+}
+
 static void draw9(const orc_params* p, uint64_t genv, uint32_t episode, double u[9])
 {
     uint32_t key[2] = { (uint32_t)p->seed, (uint32_t)(p->seed >> 32) };
@@ -177,18 +187,20 @@ static void put_triple(double* dst, const double x[ORC_DOF], int as_f32)
     }
 }
 
-/* observe, pioneer_knm_env.py:184-211 */
-void orc_observe(const orc_params* p, const orc_state* s, double obs[ORC_OBS])
+/* observe, pioneer_knm_env.py:184-211, on explicit joint positions / velocities
+ * (kinematic mode: q = s->r, qd = s->v; dynamics mode: the simulated q, qd) */
+void orc_observe_qv(const orc_params* p, const orc_state* s, const double q[ORC_DOF],
+                    const double qd[ORC_DOF], int q_is_f64, double obs[ORC_OBS])
 {
     double pointer[3], diff[3];
-    orc_fk_pointer(s->r, pointer);                     /* :185, bullet_scene.py:58 */
+    orc_fk_pointer(q, pointer);                        /* :185, bullet_scene.py:58 */
     for (int k = 0; k < 3; k++) diff[k] = s->target[k] - pointer[k]; /* :188 */
     double distance = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]); /* :189 */
 
-    int f32 = !s->r_is_f64;
+    int f32 = !q_is_f64;
     double x[ORC_DOF];
     /* :195 r, cos r, sin r */
-    put_triple(obs + 0, s->r, f32);
+    put_triple(obs + 0, q, f32);
     /* :196-197 limits (always float32 arrays) */
     for (int i = 0; i < ORC_DOF; i++) x[i] = (double)p->r_lo[i];
     put_triple(obs + 18, x, 1);
@@ -196,15 +208,14 @@ void orc_observe(const orc_params* p, const orc_state* s, double obs[ORC_OBS])
     put_triple(obs + 36, x, 1);
     /* :191, :199  r - r_lo : float32 - float32 -> float32; float64 - float32 -> float64 */
     for (int i = 0; i < ORC_DOF; i++)
-        x[i] = f32 ? (double)((float)s->r[i] - p->r_lo[i]) : s->r[i] - (double)p->r_lo[i];
+        x[i] = f32 ? (double)((float)q[i] - p->r_lo[i]) : q[i] - (double)p->r_lo[i];
     put_triple(obs + 54, x, f32);
     /* :192, :200  r_hi - r */
     for (int i = 0; i < ORC_DOF; i++)
-        x[i] = f32 ? (double)(p->r_hi[i] - (float)s->r[i]) : (double)p->r_hi[i] - s->r[i];
+        x[i] = f32 ? (double)(p->r_hi[i] - (float)q[i]) : (double)p->r_hi[i] - q[i];
     put_triple(obs + 72, x, f32);
     /* :202-203 v, a */
-    for (int i = 0; i < ORC_DOF; i++) x[i] = (double)s->v[i];
-    put_triple(obs + 90, x, 1);
+    put_triple(obs + 90, qd, 1);
     for (int i = 0; i < ORC_DOF; i++) x[i] = (double)s->a[i];
     put_triple(obs + 108, x, 1);
     /* :205-210 */
@@ -217,6 +228,13 @@ void orc_observe(const orc_params* p, const orc_state* s, double obs[ORC_OBS])
     obs[136] = s->potential;
 }
 
+void orc_observe(const orc_params* p, const orc_state* s, double obs[ORC_OBS])
+{
+    double qd[ORC_DOF];
+    for (int i = 0; i < ORC_DOF; i++) qd[i] = (double)s->v[i];
+    orc_observe_qv(p, s, s->r, qd, s->r_is_f64, obs);
+}
+
 /* ---- step --------------------------------------------------------------------- */
 static double np_clip(double x, double lo, double hi)
 {
@@ -224,10 +242,8 @@ static double np_clip(double x, double lo, double hi)
     return x < lo ? lo : (x > hi ? hi : x);
 }
 
-/* act, pioneer_knm_env.py:111-182 */
-void orc_step(const orc_params* p, orc_state* s, uint64_t genv,
-              const float action[ORC_DOF], double obs[ORC_OBS], double* reward,
-              uint8_t* done_out, uint8_t* trunc_out, double info[4])
+/* the integrator loop of act(), pioneer_knm_env.py:113-146 (+ step_index, bullet_env.py:193) */
+void orc_integrate(const orc_params* p, orc_state* s, const float action[ORC_DOF])
 {
     s->step_index += 1; /* bullet_env.py:193 */
 
@@ -263,10 +279,15 @@ void orc_step(const orc_params* p, orc_state* s, uint64_t genv,
     }
     for (int i = 0; i < ORC_DOF; i++) s->a[i] = action[i]; /* :144 (quirk Q1) */
     s->r_is_f64 = 0;
+}
 
+/* the reward block of act(), pioneer_knm_env.py:148-165, + TimeLimit, for joint positions q.
+ * Returns done | truncated<<1. */
+int orc_reward(const orc_params* p, orc_state* s, const double q[ORC_DOF], double* reward, double info[4])
+{
     /* :148-155 teleport joints, FK, distance */
     double pointer[3], diff[3];
-    orc_fk_pointer(s->r, pointer);
+    orc_fk_pointer(q, pointer);
     for (int k = 0; k < 3; k++) diff[k] = s->target[k] - pointer[k];
     double distance = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
 
@@ -280,17 +301,28 @@ void orc_step(const orc_params* p, orc_state* s, uint64_t genv,
     double rw = reward_potential + reward_step + reward_done;
     s->potential = (p->precision == ORC_DEV) ? (double)(float)pot : pot;
 
-    /* :181 world.step(): 10 x stepSimulation with gravity 0, zero joint velocity,
-     * no colliders -> identity on the observable state (SURVEY.md a6) */
-
     /* gym.wrappers.TimeLimit.step: truncated = elapsed >= max and not done */
     int trunc = (p->max_episode_steps > 0) &&
                 (s->step_index >= (uint32_t)p->max_episode_steps) && !done;
-
     if (reward) *reward = rw;
+    if (info) { info[0] = reward_potential; info[1] = reward_step; info[2] = reward_done; info[3] = distance; }
+    return done | (trunc << 1);
+}
+
+/* act + observe: BulletEnv.step, bullet_env.py:192-197 */
+void orc_step(const orc_params* p, orc_state* s, uint64_t genv,
+              const float action[ORC_DOF], double obs[ORC_OBS], double* reward,
+              uint8_t* done_out, uint8_t* trunc_out, double info[4])
+{
+    orc_integrate(p, s, action);
+    int flags = orc_reward(p, s, s->r, reward, info);
+    int done = flags & 1, trunc = (flags >> 1) & 1;
+
+    /* :181 world.step(): 10 x stepSimulation with gravity 0, zero joint velocity,
+     * no colliders -> identity on the observable state (SURVEY.md a6) */
+
     if (done_out) *done_out = (uint8_t)done;
     if (trunc_out) *trunc_out = (uint8_t)trunc;
-    if (info) { info[0] = reward_potential; info[1] = reward_step; info[2] = reward_done; info[3] = distance; }
 
     if (p->auto_reset && (done || trunc)) orc_reset(p, s, genv, NULL, NULL);
     if (obs) orc_observe(p, s, obs);         /* bullet_env.py:196 */

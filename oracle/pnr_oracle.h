@@ -89,6 +89,13 @@ void orc_reset(const orc_params* p, orc_state* s, uint64_t global_env_id,
 /* observe, pioneer_knm_env.py:184-211 -> float64[137] */
 void orc_observe(const orc_params* p, const orc_state* s, double obs[ORC_OBS]);
 
+/* pieces of step(), exported for the dynamics-mode oracle */
+void orc_integrate(const orc_params* p, orc_state* s, const float action[ORC_DOF]);
+int orc_reward(const orc_params* p, orc_state* s, const double q[ORC_DOF], double* reward, double info[4]);
+void orc_observe_qv(const orc_params* p, const orc_state* s, const double q[ORC_DOF],
+                    const double qd[ORC_DOF], int q_is_f64, double obs[ORC_OBS]);
+void orc_draw_block(const orc_params* p, uint64_t genv, uint32_t episode, uint32_t block, double u[4]);
+
 /* BulletEnv.step, bullet_env.py:192-197: act (pioneer_knm_env.py:111-182) +
  * observe + TimeLimit + optional auto-reset.
  * info[4] = r_pot, r_step, r_done, dist.  Any output pointer may be NULL. */

@@ -1,0 +1,185 @@
+"""CPU tests of the dynamics-mode oracle (PARITY UNPINNED: the reference pins no dynamics).
+
+The ABA of oracle/pnr_dyn_oracle.c (body-coordinate spatial algebra over six merged bodies)
+is checked against an independent Lagrangian formulation written here: per-LINK world-frame
+Jacobians -> mass matrix M(q); Coriolis and gravity terms by numerical differentiation of
+M(q) and of the potential energy.  Plus energy conservation, contact, limits, and the
+reduction to the kinematic (reference) semantics under teleport.
+"""
+import numpy as np
+import pytest
+
+from oracle import COracle, DynOracle
+from oracle.binding import ORC_DEV
+from oracle.numpy_twin import CHAIN, _axis_angle
+
+# URDF link order (tests/golden/urdf_chain.json): world, base, rotator1, hinge1, arm1, arm2,
+# rotator2, hinge2, arm3, rotator3, effector, pointer.  Link l (1-based, skipping world) is the
+# child of CHAIN[l-1].
+
+
+def link_frames(q):
+    """World rotation / origin of every non-world link + each revolute joint's world axis and position."""
+    R, p = np.eye(3), np.zeros(3)
+    frames, joints, qi = [], [], 0
+    for jtype, origin, axis in CHAIN:
+        p = p + R @ np.array(origin, dtype=float)
+        if jtype == "revolute":
+            joints.append((R @ np.array(axis, dtype=float), p.copy(), len(frames)))
+            R = R @ _axis_angle(axis, q[qi]); qi += 1
+        frames.append((R.copy(), p.copy()))
+    return frames, joints
+
+
+def mass_matrix(q, scale):
+    frames, joints = link_frames(q)
+    M = np.zeros((6, 6))
+    for l, (R, p) in enumerate(frames):
+        if l == 0:
+            continue                      # robot:base is fixed to the world
+        m, inertia = 1.0 * scale[l], 1.0 * scale[l]
+        Jv, Jw = np.zeros((3, 6)), np.zeros((3, 6))
+        for j, (z, o, first_link) in enumerate(joints):
+            if first_link <= l:           # joint j is an ancestor of link l
+                Jw[:, j] = z
+                Jv[:, j] = np.cross(z, p - o)
+        M += m * Jv.T @ Jv + inertia * Jw.T @ Jw      # isotropic link inertia: R I R^T = I
+    return M
+
+
+def potential_energy(q, scale, g):
+    frames, _ = link_frames(q)
+    return sum(1.0 * scale[l] * g * p[2] for l, (R, p) in enumerate(frames) if l > 0)
+
+
+def lagrange_qdd(q, qd, tau, scale, g, f_tip=None, h=1e-6):
+    M = mass_matrix(q, scale)
+    dM = np.zeros((6, 6, 6))
+    G = np.zeros(6)
+    for k in range(6):
+        e = np.zeros(6); e[k] = h
+        dM[:, :, k] = (mass_matrix(q + e, scale) - mass_matrix(q - e, scale)) / (2 * h)
+        G[k] = (potential_energy(q + e, scale, g) - potential_energy(q - e, scale, g)) / (2 * h)
+    Cq = np.einsum("ijk,j,k->i", dM, qd, qd) - 0.5 * np.einsum("jki,j,k->i", dM, qd, qd)
+    Q = np.array(tau, dtype=float)
+    if f_tip is not None:
+        frames, joints = link_frames(q)
+        ptip = frames[-1][1]
+        Jv = np.stack([np.cross(z, ptip - o) for (z, o, _) in joints], axis=1)
+        Q = Q + Jv.T @ np.asarray(f_tip, dtype=float)
+    return np.linalg.solve(M, Q - Cq - G)
+
+
+@pytest.fixture(scope="module")
+def dyn(oracle_built):
+    return DynOracle(1)
+
+
+def set_state(o, q, qd, scale=None):
+    o.dstate["q"][0] = q; o.dstate["qd"][0] = qd
+    o.dstate["mass_scale"][0] = np.ones(11) if scale is None else scale
+    o.dstate["friction"][0] = 0; o.dstate["damping"][0] = 0
+
+
+def test_aba_equals_lagrangian(dyn):
+    rng = np.random.RandomState(0)
+    for trial in range(12):
+        q = rng.uniform(dyn.r_lo, dyn.r_hi).astype(np.float64)
+        qd = rng.uniform(-2, 2, 6)
+        tau = rng.uniform(-50, 50, 6)
+        scale = np.ones(11) if trial < 4 else rng.uniform(0.5, 1.5, 11)
+        g = [0.0, 9.81, 3.0][trial % 3]
+        f = None if trial % 2 == 0 else rng.uniform(-20, 20, 3)
+        set_state(dyn, q, qd, scale)
+        got = dyn.aba(tau, gravity=g, f_tip=f)
+        want = lagrange_qdd(q, qd, tau, scale, g, f)
+        assert np.abs(got - want).max() < 2e-6 * max(1.0, np.abs(want).max())
+
+
+def test_energy_matches_lagrangian_and_tip_matches_fk(dyn):
+    rng = np.random.RandomState(1)
+    q = rng.uniform(dyn.r_lo, dyn.r_hi).astype(np.float64); qd = rng.uniform(-1, 1, 6)
+    scale = rng.uniform(0.5, 1.5, 11)
+    set_state(dyn, q, qd, scale)
+    ke, pe = dyn.energy(9.81)
+    assert abs(ke - 0.5 * qd @ mass_matrix(q, scale) @ qd) < 1e-9
+    assert abs(pe - potential_energy(q, scale, 9.81)) < 1e-9
+    pos, vel = dyn.tip()
+    assert np.abs(pos - dyn.fk([q])[0]).max() < 1e-12
+    h = 1e-7
+    num = (dyn.fk([q + h * qd])[0] - dyn.fk([q - h * qd])[0]) / (2 * h)
+    assert np.abs(vel - num).max() < 1e-6
+
+
+def test_energy_conservation_passive(oracle_built):
+    """No torque, gravity on, damping off: E = KE + PE is conserved up to the integrator's O(dt) drift."""
+    o = DynOracle(1, dyn=dict(teleport=1, gravity=9.81, timestep=2e-5))
+    set_state(o, [0.2, 0.3, -0.4, 0.5, 0.3, -0.2], [0.3, -0.2, 0.1, 0.4, -0.3, 0.2])
+    e0 = sum(o.energy(9.81))
+    ke0 = o.energy(9.81)[0]
+    z = np.zeros(6)
+    for _ in range(5000):               # 0.1 s
+        o.substep(z, z)
+    ke1, pe1 = o.energy(9.81)
+    assert abs(ke1 - ke0) > 1.0          # energy really moved between KE and PE
+    assert abs(ke1 + pe1 - e0) < 2e-3 * abs(ke1 - ke0)
+
+
+def test_teleport_zero_gravity_is_kinematic_mode(oracle_built):
+    """with the reference's defaults (gravity 0, teleported joints, no colliders) the
+    dynamics sub-steps are the identity, so dynamics mode reproduces kinematic mode bit for bit."""
+    n = 64
+    kin = COracle(n, seed=4, precision=ORC_DEV, auto_reset=True, max_episode_steps=9)
+    dyn = DynOracle(n, seed=4, precision=ORC_DEV, auto_reset=True, max_episode_steps=9,
+                    dyn=dict(teleport=1, gravity=0.0))
+    assert np.array_equal(kin.reset(), dyn.reset())
+    rng = np.random.RandomState(0)
+    for _ in range(30):
+        a = (rng.uniform(-1, 1, (n, 6)) * kin.a_max).astype(np.float32)
+        ok, rk, dk, tk = kin.step(a)
+        od, rd, dd, td = dyn.step(a)
+        assert np.array_equal(ok, od) and np.array_equal(rk, rd)
+        assert np.array_equal(dk, dd) and np.array_equal(tk, td)
+
+
+def test_pd_tracks_the_kinematic_command(oracle_built):
+    n = 16
+    o = DynOracle(n, seed=2, precision=ORC_DEV, max_episode_steps=0, dyn=dict(kp=4000.0, kd=400.0))
+    o.reset()
+    rng = np.random.RandomState(3)
+    for t in range(120):
+        a = (rng.uniform(-0.05, 0.05, (n, 6)) * o.a_max).astype(np.float32)
+        o.step(a)
+    err = np.abs(o.dstate["q"] - o.state["r"])
+    assert err[:, 3:].max() < 0.15       # light distal joints track tightly
+    assert err.max() < 0.6               # the heavy base joints lag but stay bounded
+    assert np.all(o.dstate["q"] <= o.r_hi + 1e-12) and np.all(o.dstate["q"] >= o.r_lo - 1e-12)
+
+
+def test_ground_contact_pushes_the_pointer_up(oracle_built):
+    """Arm released horizontally (tip at z = 15.9) above a plane at z = 10 under gravity."""
+    z = np.zeros(6)
+    traj = {}
+    for name, gz in (("plane", 10.0), ("free", float("nan"))):
+        o = DynOracle(1, dyn=dict(teleport=1, gravity=9.81, ground_z=gz, contact_kp=2000.0, contact_kd=50.0))
+        set_state(o, np.zeros(6), np.zeros(6))
+        zs = []
+        for _ in range(2400):             # 10 s
+            o.substep(z, z)
+            zs.append(o.tip()[0][2])
+        traj[name] = np.array(zs)
+    assert traj["free"].min() < 10.0 - 5.0            # without the plane the pointer swings far below
+    assert traj["plane"].min() > 10.0 - 1.0           # penetration bounded by the penalty spring
+    assert abs(traj["plane"][-1] - 10.0) < 0.5        # and it comes to rest on the plane
+
+
+def test_randomisation_draws(oracle_built):
+    o = DynOracle(2048, seed=8, dyn=dict(randomize=1))
+    o.reset(want_obs=False)
+    ms, fr, dm = o.dstate["mass_scale"], o.dstate["friction"], o.dstate["damping"]
+    assert ms.min() >= 0.5 and ms.max() <= 1.5 and abs(ms.mean() - 1.0) < 0.02
+    assert fr.min() >= 0 and fr.max() <= 0.1 and dm.min() >= 0 and dm.max() <= 0.1
+    assert np.array_equal(o.dstate["q"], o.state["r"]) and not o.dstate["qd"].any()
+    o2 = DynOracle(1024, seed=8, env_id_offset=1024, dyn=dict(randomize=1))
+    o2.reset(want_obs=False)
+    assert np.array_equal(o2.dstate["mass_scale"], ms[1024:])
