@@ -29,8 +29,8 @@ namespace pnr {
 // step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps.
 // One wave = 32 envs (lane pair per env), one wave per workgroup.
 // ---------------------------------------------------------------------------------
-template <bool OBS_EM, bool ACT_EM>
-__global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
+template <bool OBS_EM, bool ACT_EM, bool DYN>
+__global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynParams D)
 {
     __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
 
@@ -57,34 +57,49 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
     const float vmax[kJpl] = {vmax0, vmax1, vmax2};
 
     for (int t = 0; t < P.T; ++t) {
-        // -- action of this step (this lane's three joints) --------------------------
-        float act[kJpl];
-        if (valid) {
-            const float* A = P.actions + (long long)t * n * kDof;
-            if (ACT_EM) {
-                const float* a3 = A + e * kDof + kJpl * p;      // 12 B per lane, lanes contiguous
-                act[0] = a3[0]; act[1] = a3[1]; act[2] = a3[2];
+        LaneState o;     // what reward / obs see: the kinematic state, or the simulated q, qd in dynamics mode
+        if (!DYN) {
+            // -- action of this step (this lane's three joints) ----------------------
+            float act[kJpl];
+            if (valid) {
+                const float* A = P.actions + (long long)t * n * kDof;
+                if (ACT_EM) {
+                    const float* a3 = A + e * kDof + kJpl * p;      // 12 B per lane, lanes contiguous
+                    act[0] = a3[0]; act[1] = a3[1]; act[2] = a3[2];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kJpl; ++i) act[i] = A[(long long)(kJpl * p + i) * n + e];
+                }
             } else {
 #pragma unroll
-                for (int i = 0; i < kJpl; ++i) act[i] = A[(long long)(kJpl * p + i) * n + e];
+                for (int i = 0; i < kJpl; ++i) act[i] = 0.f;
             }
+            // -- act(): integrate the PREVIOUS action, then latch the new one -------
+#pragma unroll
+            for (int i = 0; i < kJpl; ++i) {
+                const float lim = lane_limit(p, i);
+                integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, P.dt, P.eps, s.v[i], s.r[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < kJpl; ++i) s.a[i] = act[i];           // :144 (quirk Q1)
+            o = s;
         } else {
+            // dyn_substeps_kernel already integrated the command and ran the sub-steps
+            o = s;
 #pragma unroll
-            for (int i = 0; i < kJpl; ++i) act[i] = 0.f;
+            for (int i = 0; i < kJpl; ++i) {
+                const float qi = valid ? D.dyn[(long long)(kJpl * p + i) * n + e] : 0.f;
+                const float qdi = valid ? D.dyn[(long long)(6 + kJpl * p + i) * n + e] : 0.f;
+                o.r[i] = qi;
+                // teleport = reference semantics: obs shows the env's own v (pioneer_knm_env.py:202)
+                o.v[i] = D.teleport ? s.v[i] : qdi;
+            }
         }
-
-        // -- act(): integrate the PREVIOUS action, then latch the new one -----------
         s.step += 1;                                                  // bullet_env.py:193
-#pragma unroll
-        for (int i = 0; i < kJpl; ++i) {
-            const float lim = lane_limit(p, i);
-            integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, P.dt, P.eps, s.v[i], s.r[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < kJpl; ++i) s.a[i] = act[i];               // :144 (quirk Q1)
+        o.step = s.step;
 
         Pose q;
-        compute_pose(s, p, q);
+        compute_pose(o, p, q);
 
         // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
         const float old_pot = s.pot;
@@ -108,9 +123,12 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 
         // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
         // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
+        o.pot = pot;
         if (P.auto_reset && (done || trunc)) {
             reset_env(P, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
-            compute_pose(s, p, q);
+            if (DYN && valid) dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);
+            o = s;
+            compute_pose(o, p, q);
         }
 
         // -- observe() ----------------------------------------------------------------
@@ -118,12 +136,12 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
         if (t > 0) __syncthreads();       // previous flush done before the tile is rewritten
         if (OBS_EM) {
             SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-            if (!diag_noemit) emit_obs(s, q, p, sink);
+            if (!diag_noemit) emit_obs(o, q, p, sink);
             __syncthreads();
             if (!diag_noflush) flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
         } else {
             SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-            emit_obs(s, q, p, sink);
+            emit_obs(o, q, p, sink);
             __syncthreads();
             flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
         }
@@ -138,8 +156,8 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 //      (all rows written), 3 env-major direct rows (masked reset), 4 feature-major
 //      via LDS tile (all columns written).
 // ---------------------------------------------------------------------------------
-template <int MODE, int OBS>
-__global__ __launch_bounds__(kWave) void reset_kernel(const KParams P)
+template <int MODE, int OBS, bool DYN>
+__global__ __launch_bounds__(kWave) void reset_kernel(const KParams P, const DynParams D)
 {
     __shared__ __attribute__((aligned(16))) float tile[(OBS == 2 || OBS == 4) ? kTileFloats : 4];
     const int lane = threadIdx.x;
@@ -162,6 +180,17 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P)
                       P.joint_pos ? P.joint_pos + e * kDof : nullptr,
                       P.target_pos ? P.target_pos + e * 3 : nullptr);
             store_state(P.state, n, rec, p, s);
+            if (DYN) dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);
+        }
+    }
+    if (DYN && !(MODE == 0 && active)) {
+        // observe the simulated joints (a freshly reset env has q = r, qd = 0 already in s)
+#pragma unroll
+        for (int i = 0; i < kJpl; ++i) {
+            const float qi = valid ? D.dyn[(long long)(kJpl * p + i) * n + e] : 0.f;
+            const float qdi = valid ? D.dyn[(long long)(6 + kJpl * p + i) * n + e] : 0.f;
+            s.r[i] = qi;
+            if (!D.teleport) s.v[i] = qdi;
         }
     }
     if (OBS != 0) {
@@ -249,11 +278,12 @@ struct pnr_env_s {
     pnr_config cfg;
     pnr_constants k;
     KParams base;        // constants pre-filled; pointers set per call
+    DynParams dbase;     // dynamics-mode constants (zeroed in kinematic mode)
     long long n;
     unsigned long long env_off;
     int device;
     float4* state;
-    float4* dyn;         // dynamics-mode planes or null
+    float* dyn;          // dynamics-mode planar words [36][n] or null
     int diag;            // PNR_DIAG env var at create time (timing-only ablations; 0 in production)
     char err[512];
 };
@@ -375,6 +405,19 @@ static void fill_base(pnr_handle h)
     P.dt = h->k.dt; P.eps = h->k.eps;
     for (int k = 0; k < 3; ++k) { P.tlo[k] = c.target_lo[k]; P.tspan[k] = c.target_hi[k] - c.target_lo[k]; }
     for (int i = 0; i < kDof; ++i) P.v_max[i] = h->k.v_max[i];
+    DynParams& D = h->dbase;
+    memset(&D, 0, sizeof(D));
+    D.dyn = h->dyn;
+    D.kp = (float)c.pd_kp; D.kd = (float)c.pd_kd; D.tau_max = (float)c.torque_limit;
+    D.gravity = (float)c.gravity; D.dt_sub = (float)c.timestep; D.nsub = c.frame_skip;
+    D.teleport = c.teleport; D.randomize = c.randomize;
+    D.has_ground = (c.ground_z == c.ground_z) ? 1 : 0;
+    D.ground_z = D.has_ground ? (float)c.ground_z : 0.f;
+    D.ckp = (float)c.contact_kp; D.ckd = (float)c.contact_kd;
+    D.joint_damping = (float)c.joint_damping; D.joint_friction = (float)c.joint_friction;
+    D.mass_lo = c.rand_mass_lo; D.mass_span = c.rand_mass_hi - c.rand_mass_lo;
+    D.fric_lo = c.rand_friction_lo; D.fric_span = c.rand_friction_hi - c.rand_friction_lo;
+    D.damp_lo = c.rand_damping_lo; D.damp_span = c.rand_damping_hi - c.rand_damping_lo;
     P.pot_m = (float)(c.award_max - c.award_done);
     P.pot_s = (float)c.award_potential_slope;
     P.penalty = (float)c.penalty_step;
@@ -423,9 +466,10 @@ int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, i
     if (e != hipSuccess) { delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(state) failed: %s", hipGetErrorString(e)); }
     (void)hipMemset(h->state, 0, sizeof(float4) * kStatePlanes * 2 * (size_t)num_envs);
     if (cfg->mode == PNR_MODE_DYNAMIC) {
-        e = hipMalloc((void**)&h->dyn, sizeof(float4) * kDynPlanes * (size_t)num_envs);
+        const size_t bytes = sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)num_envs;
+        e = hipMalloc((void**)&h->dyn, bytes);
         if (e != hipSuccess) { (void)hipFree(h->state); delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(dyn) failed: %s", hipGetErrorString(e)); }
-        (void)hipMemset(h->dyn, 0, sizeof(float4) * kDynPlanes * (size_t)num_envs);
+        (void)hipMemset(h->dyn, 0, bytes);
     }
     { const char* e_ = getenv("PNR_DIAG"); h->diag = e_ ? atoi(e_) : 0; }
     fill_base(h);
@@ -466,13 +510,20 @@ int pnr_reset(pnr_handle h, const uint8_t* mask, const float* joint_pos, const f
     KParams P = h->base;
     P.mask = mask; P.joint_pos = joint_pos; P.target_pos = target_pos; P.obs = obs_out;
     const dim3 grid(grid_for(h->n)), block(kWave);
-    if (!obs_out) hipLaunchKernelGGL((reset_kernel<0, 0>), grid, block, 0, st, P);
-    else if (h->cfg.obs_layout == PNR_FEATURE_MAJOR && mask) hipLaunchKernelGGL((reset_kernel<0, 1>), grid, block, 0, st, P);
-    else if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<0, 4>), grid, block, 0, st, P);
-    else if (!mask) hipLaunchKernelGGL((reset_kernel<0, 2>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((reset_kernel<0, 3>), grid, block, 0, st, P);
+    const DynParams& D = h->dbase;
+    const bool fm = h->cfg.obs_layout == PNR_FEATURE_MAJOR;
+#define PNR_LAUNCH_RESET(OBSK)                                                                     \
+    do {                                                                                           \
+        if (h->dyn) hipLaunchKernelGGL((reset_kernel<0, OBSK, true>), grid, block, 0, st, P, D);   \
+        else hipLaunchKernelGGL((reset_kernel<0, OBSK, false>), grid, block, 0, st, P, D);         \
+    } while (0)
+    if (!obs_out) PNR_LAUNCH_RESET(0);
+    else if (fm && mask) PNR_LAUNCH_RESET(1);
+    else if (fm) PNR_LAUNCH_RESET(4);
+    else if (!mask) PNR_LAUNCH_RESET(2);
+    else PNR_LAUNCH_RESET(3);
+#undef PNR_LAUNCH_RESET
     HIP_TRY(h, hipGetLastError());
-    if (h->cfg.mode == PNR_MODE_DYNAMIC) return dyn_reset_launch(h->dyn, P, h->cfg, st) ? fail(h, PNR_ERR_HIP, "dyn reset launch failed") : PNR_OK;
     return PNR_OK;
 }
 
@@ -484,8 +535,13 @@ int pnr_observe(pnr_handle h, float* obs_out, void* stream)
     KParams P = h->base;
     P.obs = obs_out;
     const dim3 grid(grid_for(h->n)), block(kWave);
-    if (h->cfg.obs_layout == PNR_FEATURE_MAJOR) hipLaunchKernelGGL((reset_kernel<1, 4>), grid, block, 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL((reset_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, P);
+    const DynParams& D = h->dbase;
+    hipStream_t st = (hipStream_t)stream;
+    const bool fm = h->cfg.obs_layout == PNR_FEATURE_MAJOR;
+    if (fm && h->dyn) hipLaunchKernelGGL((reset_kernel<1, 4, true>), grid, block, 0, st, P, D);
+    else if (fm) hipLaunchKernelGGL((reset_kernel<1, 4, false>), grid, block, 0, st, P, D);
+    else if (h->dyn) hipLaunchKernelGGL((reset_kernel<1, 2, true>), grid, block, 0, st, P, D);
+    else hipLaunchKernelGGL((reset_kernel<1, 2, false>), grid, block, 0, st, P, D);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
 }
@@ -507,15 +563,32 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     P.T = T; P.actions = actions; P.obs = obs; P.reward = reward; P.done = done; P.trunc = truncated; P.info = info;
     const dim3 grid(grid_for(h->n)), block(kWave);
     hipStream_t st = (hipStream_t)stream;
+    const DynParams& D = h->dbase;
+    const bool oem = h->cfg.obs_layout == PNR_ENV_MAJOR, aem = h->cfg.action_layout == PNR_ENV_MAJOR;
     if (h->cfg.mode == PNR_MODE_DYNAMIC) {
-        if (dyn_step_launch(h->dyn, P, h->cfg, st)) return fail(h, PNR_ERR_HIP, "dyn step launch failed: %s", hipGetErrorString(hipGetLastError()));
+        // two launches per step: the one-env-per-lane ABA sub-steps, then the pair kernel for
+        // reward / TimeLimit / auto-reset / obs on the simulated joints
+        const dim3 gridA((unsigned)((h->n + kWave - 1) / kWave));
+        for (int t = 0; t < T; ++t) {
+            KParams Pt = P;
+            Pt.T = 1;
+            Pt.actions = actions + (long long)t * h->n * kDof;
+            Pt.obs = obs + (long long)t * h->n * kObsDim;
+            Pt.reward = reward + (long long)t * h->n;
+            Pt.done = done + (long long)t * h->n;
+            Pt.trunc = truncated ? truncated + (long long)t * h->n : nullptr;
+            if (aem) hipLaunchKernelGGL((dyn_substeps_kernel<true>), gridA, block, 0, st, Pt, D, 0);
+            else hipLaunchKernelGGL((dyn_substeps_kernel<false>), gridA, block, 0, st, Pt, D, 0);
+            if (oem) hipLaunchKernelGGL((step_kernel<true, true, true>), grid, block, 0, st, Pt, D);
+            else hipLaunchKernelGGL((step_kernel<false, true, true>), grid, block, 0, st, Pt, D);
+        }
+        HIP_TRY(h, hipGetLastError());
         return PNR_OK;
     }
-    const bool oem = h->cfg.obs_layout == PNR_ENV_MAJOR, aem = h->cfg.action_layout == PNR_ENV_MAJOR;
-    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, st, P);
-    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P);
-    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P);
+    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true, false>), grid, block, 0, st, P, D);
+    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false, false>), grid, block, 0, st, P, D);
+    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true, false>), grid, block, 0, st, P, D);
+    else hipLaunchKernelGGL((step_kernel<false, false, false>), grid, block, 0, st, P, D);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
 }
@@ -567,7 +640,8 @@ int pnr_get_dyn_state(pnr_handle h, float* words_out, void* stream)
     if (!h || !words_out) return fail(h, PNR_ERR_INVALID, "pnr_get_dyn_state: null argument");
     if (!h->dyn) return fail(h, PNR_ERR_UNSUPPORTED, "handle is not in dynamics mode");
     DeviceGuard g(h->device);
-    if (dyn_words_launch(h->dyn, words_out, nullptr, h->n, (hipStream_t)stream)) return fail(h, PNR_ERR_HIP, "launch failed");
+    HIP_TRY(h, hipMemcpyAsync(words_out, h->dyn, sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)h->n,
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PNR_OK;
 }
 
@@ -576,7 +650,8 @@ int pnr_set_dyn_state(pnr_handle h, const float* words_in, void* stream)
     if (!h || !words_in) return fail(h, PNR_ERR_INVALID, "pnr_set_dyn_state: null argument");
     if (!h->dyn) return fail(h, PNR_ERR_UNSUPPORTED, "handle is not in dynamics mode");
     DeviceGuard g(h->device);
-    if (dyn_words_launch(h->dyn, nullptr, words_in, h->n, (hipStream_t)stream)) return fail(h, PNR_ERR_HIP, "launch failed");
+    HIP_TRY(h, hipMemcpyAsync(h->dyn, words_in, sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)h->n,
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PNR_OK;
 }
 

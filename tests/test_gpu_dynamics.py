@@ -1,0 +1,138 @@
+"""GPU dynamics mode (ABA + PD + limits + contact) against the float64 dynamics oracle.
+
+PARITY UNPINNED at the reference (it pins no dynamics): the oracle itself is validated by
+tests/test_dyn_oracle.py.  Tolerances (float32 kernel, 10 sub-steps, vs float64):
+  re-synchronised single steps: |dq| <= 5e-5 rad, |dqd| <= 2e-3 rad/s (relative 1e-4 of the
+  velocity scale ~20 rad/s); free-running 40 steps under PD tracking: |dq| <= 5e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import COracle, DynOracle
+from oracle.binding import ORC_DEV
+
+pytestmark = pytest.mark.gpu
+
+Q_TOL, QD_TOL = 5e-5, 2e-3
+
+
+def make(n, seed=0, auto_reset=False, max_steps=0, layout="env_major", gravity=0.0, **dyn):
+    from pioneer_amd import PioneerVectorEnv, EngineConfig, SimulationConfig
+    ek = dict(dyn)
+    eng = EngineConfig(mode="dynamic", auto_reset=auto_reset, max_episode_steps=max_steps, obs_layout=layout,
+                       pd_kp=ek.pop("kp", 4000.0), pd_kd=ek.pop("kd", 400.0), torque_limit=ek.pop("torque_limit", 0.0),
+                       teleport=bool(ek.pop("teleport", 0)), randomize=bool(ek.pop("randomize", 0)),
+                       joint_damping=ek.pop("joint_damping", 0.0), joint_friction=ek.pop("joint_friction", 0.0),
+                       ground_z=ek.pop("ground_z", float("nan")),
+                       contact_kp=ek.pop("contact_kp", 2000.0), contact_kd=ek.pop("contact_kd", 50.0))
+    assert not ek
+    env = PioneerVectorEnv(n, device="cuda:0", seed=seed, simulation_config=SimulationConfig(gravity=gravity),
+                           engine_config=eng)
+    od = dict(dyn); od["gravity"] = gravity
+    orc = DynOracle(n, seed=seed, precision=ORC_DEV, auto_reset=auto_reset, max_episode_steps=max_steps,
+                    nthreads=8, dyn=od)
+    return env, orc
+
+
+def sync_oracle_from_gpu(env, orc):
+    orc.load_state_words(env.get_state().cpu().numpy().view(np.uint32))
+    orc.load_dyn_words(env.get_dyn_state().cpu().numpy())
+
+
+def test_teleport_zero_gravity_equals_kinematic_kernel():
+    """under the reference's defaults the dynamics sub-steps are the identity."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    n = 1000
+    kin = PioneerVectorEnv(n, device="cuda:0", seed=3, engine_config=EngineConfig(max_episode_steps=7))
+    dyn = PioneerVectorEnv(n, device="cuda:0", seed=3,
+                           engine_config=EngineConfig(mode="dynamic", teleport=True, max_episode_steps=7))
+    assert torch.equal(kin.reset(), dyn.reset())
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for _ in range(20):
+        a = ((torch.rand(n, 6, generator=g) * 2 - 1) * torch.from_numpy(kin.a_max)).cuda()
+        ok, rk, dk, tk = kin.vector_step(a)
+        od, rd, dd, td = dyn.vector_step(a)
+        assert torch.equal(ok, od) and torch.equal(rk, rd) and torch.equal(dk, dd) and torch.equal(tk, td)
+    assert torch.equal(kin.get_state(), dyn.get_state())
+    kin.close(); dyn.close()
+
+
+@pytest.mark.parametrize("scenario", ["pd", "gravity_friction", "randomized", "ground", "torque_limited"])
+def test_single_step_parity_resynced(scenario):
+    cfg = {
+        "pd": dict(),
+        "gravity_friction": dict(gravity=9.81, joint_damping=0.05, joint_friction=0.08),
+        "randomized": dict(gravity=9.81, randomize=1),
+        "ground": dict(gravity=9.81, ground_z=8.0),
+        "torque_limited": dict(gravity=3.0, torque_limit=500.0),
+    }[scenario]
+    n = 2048
+    env, orc = make(n, seed=5, **cfg)
+    obs = env.reset(); oobs = orc.reset()
+    assert np.abs(obs.double().cpu().numpy() - oobs).max() < 3e-5
+    assert np.array_equal(env.get_dyn_state().cpu().numpy()[:35], orc.dyn_words()[:35])   # q=r, qd=0, draws
+    rng = np.random.RandomState(1)
+    for t in range(25):
+        act = (rng.uniform(-0.3, 0.3, (n, 6)) * env.a_max).astype(np.float32)
+        sync_oracle_from_gpu(env, orc)
+        obs, rew, done, trunc = env.vector_step(torch.from_numpy(act).cuda())
+        oobs, orew, odone, otrunc = orc.step(act)
+        w = env.get_dyn_state().cpu().numpy().astype(np.float64)
+        assert np.abs(w[0:6].T - orc.dstate["q"]).max() <= Q_TOL
+        assert np.abs(w[6:12].T - orc.dstate["qd"]).max() <= QD_TOL
+        o = obs.double().cpu().numpy()
+        assert np.abs(o[:, 0:6] - oobs[:, 0:6]).max() <= Q_TOL
+        assert np.abs(o[:, 126:129] - oobs[:, 126:129]).max() <= 1e-3      # pointer: 30-unit arm x 2e-5 rad
+        assert np.abs(o[:, 90:96] - oobs[:, 90:96]).max() <= QD_TOL
+        # the kinematic command state stays bit-exact
+        assert np.array_equal(env.get_state().cpu().numpy().view(np.uint32)[:21], orc.state_words()[:21])
+    st = env.get_dyn_state().cpu().numpy()
+    assert np.all(st[0:6].T <= env.r_hi) and np.all(st[0:6].T >= env.r_lo)
+    env.close()
+
+
+def test_free_running_tracking_and_autoreset():
+    n = 1024
+    env, orc = make(n, seed=9, auto_reset=True, max_steps=15, gravity=9.81, randomize=1)
+    env.reset(); orc.reset()
+    rng = np.random.RandomState(2)
+    for t in range(40):
+        act = (rng.uniform(-0.2, 0.2, (n, 6)) * env.a_max).astype(np.float32)
+        obs, rew, done, trunc = env.vector_step(torch.from_numpy(act).cuda())
+        oobs, orew, odone, otrunc = orc.step(act)
+        assert np.array_equal(trunc.cpu().numpy(), otrunc)
+        w = env.get_dyn_state().cpu().numpy().astype(np.float64)
+        assert np.abs(w[0:6].T - orc.dstate["q"]).max() <= 5e-4
+        assert np.array_equal(w[12:35], orc.dyn_words()[12:35].astype(np.float64))   # per-env parameters after resets
+    assert np.array_equal(env.get_state().cpu().numpy().view(np.uint32)[22:], orc.state_words()[22:])
+    env.close()
+
+
+def test_dynamic_rollout_and_feature_major_match_steps():
+    n, T = 512, 6
+    e1, _ = make(n, seed=4, gravity=9.81, auto_reset=True, max_steps=4)
+    e2, _ = make(n, seed=4, gravity=9.81, auto_reset=True, max_steps=4, layout="feature_major")
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    acts = ((torch.rand(T, n, 6, generator=g) * 2 - 1) * 0.3 * torch.from_numpy(e1.a_max)).cuda()
+    obs_r, rew_r, done_r, trunc_r = e1.rollout(acts)
+    for t in range(T):
+        o, r, d, tr = e2.vector_step(acts[t])
+        assert torch.equal(o.t().contiguous(), obs_r[t]) and torch.equal(r, rew_r[t]) and torch.equal(tr, trunc_r[t])
+    e1.close(); e2.close()
+
+
+def test_full_size_65536_limits_and_finite():
+    n = 65536
+    env, _ = make(n, seed=1, auto_reset=True, max_steps=500, gravity=9.81, randomize=1, ground_z=0.0)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    amax = torch.from_numpy(env.a_max).cuda()
+    lo, hi = torch.from_numpy(env.r_lo).cuda(), torch.from_numpy(env.r_hi).cuda()
+    for t in range(20):
+        act = (torch.rand(n, 6, generator=g, device="cuda") * 2 - 1) * amax
+        obs, rew, done, trunc = env.vector_step(act)
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
+        assert bool(((obs[:, 0:6] >= lo) & (obs[:, 0:6] <= hi)).all())
+    env.close()
