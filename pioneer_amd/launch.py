@@ -1,0 +1,101 @@
+"""train(): the host-side counterpart of pioneer/launch/pioneer_knm_train.py:14-76.
+
+Same arguments (results_dir, checkpoint_freq, num_samples, num_workers, monitor) and the same
+result columns (episode_reward_{max,min,mean}, episode_len_mean, episodes_total, plus
+experiment_id / trial_id as cli.py:32-38 selects them).  Ray Tune's trial fan-out becomes a
+sequential loop of ``num_samples`` trials (each samples its entropy-coefficient start value
+log-uniformly in [1e-3, 1e-1], pioneer_knm_train.py:32-41,63); RLlib's rollout workers become
+one device-resident env batch per GPU (``num_workers`` scales the batch: workers x envs_per_worker).
+Launch with torch.distributed.run for several GPUs.
+"""
+import json
+import os
+import time
+import uuid
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import dist as pdist
+from .config import EngineConfig, PioneerKinematicConfig
+from .ppo import PPOConfig, PPOTrainer, sample_entropy_start
+from .vector_env import PioneerVectorEnv
+
+ENV_CONFIG = {"award_potential_slope": 10.0, "award_done": 5.0, "penalty_step": 1 / 100}  # pioneer_knm_train.py:53-57
+RESULT_COLUMNS = ["experiment_id", "trial_id", "episode_reward_max", "episode_reward_min",
+                  "episode_reward_mean", "episode_len_mean", "episodes_total"]                 # cli.py:32-38
+
+
+def train(results_dir: str,
+          checkpoint_freq: int,
+          num_samples: int,
+          num_workers: int,
+          monitor: bool = False,
+          training_iterations: int = 1000,          # stop={'training_iteration': 1000}, :68-70
+          envs_per_worker: int = 4096,
+          ppo_config: Optional[PPOConfig] = None,
+          mode: str = "kinematic",
+          log_every: int = 10):
+    """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list."""
+    rank, local_rank, world = pdist.world_info()
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    pdist.init_distributed(device=device)
+    results_dir = os.path.expanduser(results_dir)
+    experiment_id = uuid.uuid4().hex
+    rows: List[Dict] = []
+    total_envs = max(1, num_workers) * envs_per_worker * world
+    start, count = pdist.shard_range(total_envs, world, rank)
+
+    for trial in range(num_samples):
+        trial_id = f"{trial:05d}"
+        tdir = os.path.join(results_dir, f"PPO_Pioneer-v1_{trial_id}")
+        if rank == 0:
+            os.makedirs(tdir, exist_ok=True)
+        cfg = ppo_config or PPOConfig()
+        ent_rng = np.random.RandomState(cfg.seed + 7919 * trial)
+        cfg = PPOConfig(**{**cfg.__dict__, "entropy_coeff_start": sample_entropy_start(ent_rng),
+                           "seed": cfg.seed + trial})
+        pioneer_config = PioneerKinematicConfig(                      # prepare_env, :20-27
+            award_potential_slope=float(ENV_CONFIG["award_potential_slope"]),
+            award_done=float(ENV_CONFIG["award_done"]),
+            penalty_step=float(ENV_CONFIG["penalty_step"]))
+        env = PioneerVectorEnv(count, device=device, seed=cfg.seed, env_id_offset=start,
+                               pioneer_config=pioneer_config,
+                               engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=mode))
+        trainer = PPOTrainer(env, cfg)
+        last = {}
+        log = open(os.path.join(tdir, "result.json"), "a") if rank == 0 else None
+        t0 = time.time()
+        for it in range(1, training_iterations + 1):
+            last = trainer.train()
+            last.update({"experiment_id": experiment_id, "trial_id": trial_id, "time_total_s": time.time() - t0})
+            if log:
+                log.write(json.dumps({k: v for k, v in last.items()}) + "\n"); log.flush()
+                if monitor and it % log_every == 0:
+                    print(f"[{trial_id}] iter {it} reward_mean {last['episode_reward_mean']:.2f} "
+                          f"len {last['episode_len_mean']:.1f} steps/s {last['env_steps_per_s']:.3g}", flush=True)
+            if checkpoint_freq and it % checkpoint_freq == 0:
+                trainer.save(os.path.join(tdir, f"checkpoint_{it}.pt"))
+        trainer.save(os.path.join(tdir, "checkpoint_final.pt"))      # checkpoint_at_end=True, :73
+        if log:
+            log.close()
+        rows.append(last)
+        env.close()
+    try:
+        import pandas as pd
+        return pd.DataFrame(rows)
+    except Exception:
+        return rows
+
+
+def dump(rows, cols=RESULT_COLUMNS) -> str:
+    """pioneer/util.py:45-63: a github-style table of the chosen columns."""
+    try:
+        import pandas as pd
+        from tabulate import tabulate
+        df = rows if isinstance(rows, pd.DataFrame) else pd.DataFrame(rows)
+        return tabulate(df[[c for c in cols if c in df.columns]], headers="keys", showindex=False, tablefmt="github")
+    except Exception:
+        return "\n".join(str({c: r.get(c) for c in cols}) for r in rows)

@@ -1,0 +1,410 @@
+"""Thin PyTorch-ROCm PPO host driver.
+
+Replaces what RLlib's PPOTrainer + rollout workers do for pioneer/launch/pioneer_knm_train.py:
+the sampling loop calls ``env.vector_step`` with device-resident tensors (no Ray object store,
+no host copies), the learner is data-parallel over GPUs with ONE flat gradient all-reduce per
+minibatch (RCCL over xGMI).  Hyper-parameter names and defaults follow the reference's config
+dict (pioneer_knm_train.py:45-67) and the RLlib-0.8.x PPO defaults it did not override
+(SURVEY.md Appendix D).  Works on CPU tensors too (gloo tests use synthetic rollouts).
+"""
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import dist as pdist
+
+
+@dataclass
+class PPOConfig:
+    # model (pioneer_knm_train.py:59-61; RLlib defaults: tanh, vf_share_layers False)
+    fcnet_hiddens: Sequence[int] = (256, 256)
+    obs_dim: int = 137
+    act_dim: int = 6
+    # optimisation (pioneer_knm_train.py:62-65)
+    lr: float = 2e-5
+    num_sgd_iter: int = 20
+    sgd_minibatch_size: int = 128
+    train_batch_size: int = 8000          # informational: T * num_envs * world replaces it here
+    rollout_fragment_length: int = 32     # T steps per env per iteration
+    # PPO defaults of the era (Appendix D)
+    gamma: float = 0.99
+    lambda_: float = 1.0
+    clip_param: float = 0.3
+    kl_coeff: float = 0.2
+    kl_target: float = 0.01
+    vf_loss_coeff: float = 1.0
+    vf_clip_param: float = 10.0
+    clip_actions: bool = True
+    grad_clip: Optional[float] = None
+    # entropy_coeff_schedule [(0, x), (decay_steps, 0)] (pioneer_knm_train.py:32-41, :63)
+    entropy_coeff_start: float = 1e-2
+    entropy_decay_steps: int = 1_000_000
+    # 'observation_filter': 'ConcurrentMeanStdFilter' (pioneer_knm_train.py:66)
+    observation_filter: str = "MeanStdFilter"
+    filter_clip: float = 10.0
+    seed: int = 0
+
+
+def sample_entropy_start(rng: np.random.RandomState, min_start: float = 1e-3, max_start: float = 1e-1,
+                         base: float = 10.0) -> float:
+    """entropy_coeff_schedule's log-uniform start value (pioneer_knm_train.py:32-41)."""
+    logmin = np.log(min_start) / np.log(base)
+    logmax = np.log(max_start) / np.log(base)
+    return float(base ** rng.uniform(logmin, logmax))
+
+
+class MeanStdFilter:
+    """Running mean/std observation normaliser with RLlib MeanStdFilter semantics
+    ((x - mean) / (std + 1e-8), clipped), kept on the device; per-iteration deltas are
+    all-reduced so every rank holds the same statistics (ConcurrentMeanStdFilter's role)."""
+
+    def __init__(self, dim: int, device, clip: float = 10.0):
+        self.n = torch.zeros((), dtype=torch.float64, device=device)
+        self.mean = torch.zeros(dim, dtype=torch.float64, device=device)
+        self.m2 = torch.zeros(dim, dtype=torch.float64, device=device)
+        self.clip = clip
+        self._dn = torch.zeros((), dtype=torch.float64, device=device)
+        self._dsum = torch.zeros(dim, dtype=torch.float64, device=device)
+        self._dsq = torch.zeros(dim, dtype=torch.float64, device=device)
+
+    def observe(self, x: torch.Tensor) -> None:
+        """Accumulate a batch [B, dim] into the pending delta."""
+        xd = x.double()
+        self._dn += xd.shape[0]
+        self._dsum += xd.sum(0)
+        self._dsq += (xd * xd).sum(0)
+
+    def sync(self) -> None:
+        """Merge the pending deltas of all ranks into the running statistics (Chan et al.)."""
+        packed = torch.cat([self._dn.reshape(1), self._dsum, self._dsq])
+        pdist.allreduce_sum_(packed)
+        dn, dsum, dsq = packed[0], packed[1:1 + self.mean.numel()], packed[1 + self.mean.numel():]
+        if float(dn) > 0:
+            bmean = dsum / dn
+            bm2 = dsq - dn * bmean * bmean
+            tot = self.n + dn
+            delta = bmean - self.mean
+            self.mean = self.mean + delta * (dn / tot)
+            self.m2 = self.m2 + bm2 + delta * delta * (self.n * dn / tot)
+            self.n = tot
+        self._dn.zero_(); self._dsum.zero_(); self._dsq.zero_()
+
+    @property
+    def std(self) -> torch.Tensor:
+        var = self.m2 / torch.clamp(self.n - 1, min=1.0)
+        return torch.sqrt(torch.clamp(var, min=0.0))
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if float(self.n) < 2:
+            return x
+        y = (x - self.mean.to(x.dtype)) / (self.std.to(x.dtype) + 1e-8)
+        return torch.clamp(y, -self.clip, self.clip) if self.clip else y
+
+    def state_dict(self):
+        return {"n": self.n, "mean": self.mean, "m2": self.m2}
+
+    def load_state_dict(self, sd):
+        self.n, self.mean, self.m2 = sd["n"].to(self.n), sd["mean"].to(self.mean), sd["m2"].to(self.m2)
+
+
+class NoFilter:
+    def observe(self, x): pass
+    def sync(self): pass
+    def __call__(self, x): return x
+    def state_dict(self): return {}
+    def load_state_dict(self, sd): pass
+
+
+def _mlp(sizes: Sequence[int], out_dim: int, out_gain: float) -> nn.Sequential:
+    layers: List[nn.Module] = []
+    for a, b in zip(sizes[:-1], sizes[1:]):
+        lin = nn.Linear(a, b)
+        nn.init.orthogonal_(lin.weight, gain=math.sqrt(2)); nn.init.zeros_(lin.bias)
+        layers += [lin, nn.Tanh()]
+    head = nn.Linear(sizes[-1], out_dim)
+    nn.init.orthogonal_(head.weight, gain=out_gain); nn.init.zeros_(head.bias)
+    layers.append(head)
+    return nn.Sequential(*layers)
+
+
+class ActorCritic(nn.Module):
+    """Separate policy and value MLPs [137 -> 256 -> 256 -> 12 | 1], tanh (RLlib FullyConnectedNetwork
+    with vf_share_layers False).  The policy head emits the Gaussian's 6 means and 6 log-stds:
+    104 204 + 101 377 = 205 581 parameters."""
+
+    def __init__(self, cfg: PPOConfig):
+        super().__init__()
+        sizes = [cfg.obs_dim, *cfg.fcnet_hiddens]
+        self.policy = _mlp(sizes, 2 * cfg.act_dim, 0.01)
+        self.value = _mlp(sizes, 1, 1.0)
+        self.act_dim = cfg.act_dim
+
+    def dist_params(self, obs):
+        out = self.policy(obs)
+        mean, log_std = out[..., :self.act_dim], out[..., self.act_dim:]
+        return mean, torch.clamp(log_std, -20.0, 2.0)
+
+    def forward(self, obs):
+        mean, log_std = self.dist_params(obs)
+        return mean, log_std, self.value(obs).squeeze(-1)
+
+
+def gaussian_logp(x, mean, log_std):
+    z = (x - mean) * torch.exp(-log_std)
+    return (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+
+
+def gaussian_entropy(log_std):
+    return (log_std + 0.5 * math.log(2 * math.pi * math.e)).sum(-1)
+
+
+def gaussian_kl(mean0, log_std0, mean1, log_std1):
+    """KL(N0 || N1) for diagonal Gaussians."""
+    var0, var1 = torch.exp(2 * log_std0), torch.exp(2 * log_std1)
+    return (log_std1 - log_std0 + (var0 + (mean0 - mean1) ** 2) / (2 * var1) - 0.5).sum(-1)
+
+
+def compute_gae(rewards, values, last_value, terminals, gamma, lam):
+    """rewards/values/terminals [T, N]; terminals = done | truncated (RLlib of that era treats the
+    TimeLimit cut as terminal).  Returns advantages, value targets [T, N]."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    nxt_v, nxt_a = last_value, torch.zeros_like(last_value)
+    for t in range(T - 1, -1, -1):
+        live = 1.0 - terminals[t]
+        delta = rewards[t] + gamma * nxt_v * live - values[t]
+        nxt_a = delta + gamma * lam * live * nxt_a
+        adv[t] = nxt_a
+        nxt_v = values[t]
+    return adv, adv + values
+
+
+class EpisodeStats:
+    """episode_reward_{max,min,mean}, episode_len_mean, episodes_total (cli.py:32-38), on device."""
+
+    def __init__(self, n, device):
+        self.ret = torch.zeros(n, device=device)
+        self.len = torch.zeros(n, device=device)
+        self.total = 0
+        self._reset_window(device)
+
+    def _reset_window(self, device=None):
+        device = device or self.ret.device
+        self.w_sum = torch.zeros((), dtype=torch.float64, device=device)
+        self.w_len = torch.zeros((), dtype=torch.float64, device=device)
+        self.w_cnt = torch.zeros((), dtype=torch.float64, device=device)
+        self.w_max = torch.full((), -float("inf"), device=device)
+        self.w_min = torch.full((), float("inf"), device=device)
+
+    def step(self, reward, terminal):
+        self.ret += reward
+        self.len += 1
+        m = terminal > 0
+        cnt = m.sum()
+        self.w_cnt += cnt
+        self.w_sum += torch.where(m, self.ret, torch.zeros_like(self.ret)).sum().double()
+        self.w_len += torch.where(m, self.len, torch.zeros_like(self.len)).sum().double()
+        self.w_max = torch.maximum(self.w_max, torch.where(m, self.ret, torch.full_like(self.ret, -float("inf"))).max())
+        self.w_min = torch.minimum(self.w_min, torch.where(m, self.ret, torch.full_like(self.ret, float("inf"))).min())
+        self.ret = torch.where(m, torch.zeros_like(self.ret), self.ret)
+        self.len = torch.where(m, torch.zeros_like(self.len), self.len)
+
+    def summarize(self) -> Dict[str, float]:
+        packed = torch.stack([self.w_sum, self.w_len, self.w_cnt])
+        pdist.allreduce_sum_(packed)
+        mx = pdist.allreduce_max_(self.w_max.clone()); mn = pdist.allreduce_min_(self.w_min.clone())
+        s, l, c = (float(x) for x in packed)
+        self.total += int(c)
+        out = {"episode_reward_mean": s / c if c else float("nan"),
+               "episode_len_mean": l / c if c else float("nan"),
+               "episode_reward_max": float(mx) if c else float("nan"),
+               "episode_reward_min": float(mn) if c else float("nan"),
+               "episodes_this_iter": int(c), "episodes_total": self.total}
+        self._reset_window()
+        return out
+
+
+class PPOLearner:
+    """The learn phase alone (usable on CPU with any rollout tensors): minibatch SGD on the clipped
+    surrogate + adaptive KL + clipped value loss - entropy bonus, gradients averaged over ranks."""
+
+    def __init__(self, cfg: PPOConfig, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.manual_seed(cfg.seed)
+        self.model = ActorCritic(cfg).to(self.device)
+        pdist.broadcast_module_(self.model)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr)
+        self.kl_coeff = cfg.kl_coeff
+        self.timesteps_total = 0
+
+    def entropy_coeff(self) -> float:
+        frac = min(1.0, self.timesteps_total / max(1, self.cfg.entropy_decay_steps))
+        return self.cfg.entropy_coeff_start * (1.0 - frac)
+
+    def loss(self, mb: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        cfg = self.cfg
+        mean, log_std, v = self.model(mb["obs"])
+        logp = gaussian_logp(mb["actions"], mean, log_std)
+        ratio = torch.exp(logp - mb["logp"])
+        adv = mb["adv"]
+        surr = torch.minimum(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_param, 1 + cfg.clip_param))
+        kl = gaussian_kl(mb["mean"], mb["log_std"], mean, log_std)
+        ent = gaussian_entropy(log_std)
+        vf1 = (v - mb["vtarg"]) ** 2
+        v_clipped = mb["values"] + torch.clamp(v - mb["values"], -cfg.vf_clip_param, cfg.vf_clip_param)
+        vf = torch.maximum(vf1, (v_clipped - mb["vtarg"]) ** 2)
+        total = (-surr + self.kl_coeff * kl + cfg.vf_loss_coeff * vf - self.entropy_coeff() * ent).mean()
+        return total, {"policy_loss": -surr.mean().detach(), "vf_loss": vf.mean().detach(),
+                       "kl": kl.mean().detach(), "entropy": ent.mean().detach(), "total_loss": total.detach()}
+
+    def update(self, batch: Dict[str, torch.Tensor], generator: Optional[torch.Generator] = None) -> Dict[str, float]:
+        """batch tensors are flat [B, ...] (this rank's share).  Every rank must run the same number
+        of minibatches (equal shard sizes)."""
+        cfg = self.cfg
+        B = batch["obs"].shape[0]
+        mbs = min(cfg.sgd_minibatch_size, B)
+        adv = batch["adv"]
+        # standardise advantages over the GLOBAL batch
+        stats = torch.stack([adv.sum().double(), (adv.double() ** 2).sum(), torch.tensor(float(B), dtype=torch.float64, device=adv.device)])
+        pdist.allreduce_sum_(stats)
+        mu = stats[0] / stats[2]
+        sd = torch.sqrt(torch.clamp(stats[1] / stats[2] - mu * mu, min=1e-12))
+        batch = dict(batch, adv=((adv - mu.float()) / (sd.float() + 1e-8)))
+        agg: Dict[str, torch.Tensor] = {}
+        nmb = 0
+        for _ in range(cfg.num_sgd_iter):
+            perm = torch.randperm(B, device=adv.device, generator=generator)
+            for s in range(0, B - mbs + 1, mbs):
+                idx = perm[s:s + mbs]
+                mb = {k: v[idx] for k, v in batch.items()}
+                loss, info = self.loss(mb)
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                pdist.allreduce_mean_grads(self.model.parameters())   # one flat 0.82 MB bucket
+                if cfg.grad_clip:
+                    nn.utils.clip_grad_norm_(self.model.parameters(), cfg.grad_clip)
+                self.opt.step()
+                for k, v in info.items():
+                    agg[k] = agg.get(k, 0) + v
+                nmb += 1
+        out = {k: float(v) / max(1, nmb) for k, v in agg.items()}
+        # adaptive KL (RLlib PPO: update_kl)
+        kl_t = torch.tensor([out.get("kl", 0.0)], dtype=torch.float64, device=adv.device)
+        pdist.allreduce_sum_(kl_t)
+        kl = float(kl_t) / (pdist.dist.get_world_size() if pdist.is_dist() else 1)
+        if kl > 2.0 * cfg.kl_target:
+            self.kl_coeff *= 1.5
+        elif kl < 0.5 * cfg.kl_target:
+            self.kl_coeff *= 0.5
+        out["kl"] = kl
+        out["cur_kl_coeff"] = self.kl_coeff
+        out["entropy_coeff"] = self.entropy_coeff()
+        return out
+
+
+class PPOTrainer:
+    """Rollout + learn loop over a PioneerVectorEnv shard (one process per GPU)."""
+
+    def __init__(self, env, cfg: Optional[PPOConfig] = None):
+        self.env = env
+        self.cfg = cfg or PPOConfig()
+        self.device = env.device
+        self.rank, _, self.world = pdist.world_info()
+        self.learner = PPOLearner(self.cfg, self.device)
+        self.filter = (MeanStdFilter(self.cfg.obs_dim, self.device, self.cfg.filter_clip)
+                       if self.cfg.observation_filter in ("MeanStdFilter", "ConcurrentMeanStdFilter") else NoFilter())
+        self.stats = EpisodeStats(env.num_envs, self.device)
+        self.gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed * 1000003 + self.rank)
+        self.a_max = torch.from_numpy(env.a_max).to(self.device)
+        self.iteration = 0
+        self.raw_obs = env.reset()
+        T, N = self.cfg.rollout_fragment_length, env.num_envs
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.buf = {
+            "raw_obs": torch.empty((T, N, self.cfg.obs_dim), **f32),   # written in place by pnr_step
+            "actions": torch.empty((T, N, self.cfg.act_dim), **f32),
+            "mean": torch.empty((T, N, self.cfg.act_dim), **f32),
+            "log_std": torch.empty((T, N, self.cfg.act_dim), **f32),
+            "logp": torch.empty((T, N), **f32), "values": torch.empty((T, N), **f32),
+            "reward": torch.empty((T, N), **f32),
+            "done": torch.empty((T, N), dtype=torch.uint8, device=self.device),
+            "trunc": torch.empty((T, N), dtype=torch.uint8, device=self.device),
+        }
+
+    @torch.no_grad()
+    def collect(self) -> Dict[str, torch.Tensor]:
+        cfg, buf, model = self.cfg, self.buf, self.learner.model
+        T = cfg.rollout_fragment_length
+        obs_in = []
+        raw = self.raw_obs
+        for t in range(T):
+            self.filter.observe(raw)
+            x = self.filter(raw)
+            obs_in.append(x)
+            mean, log_std, v = model(x)
+            act = mean + torch.exp(log_std) * torch.randn(mean.shape, generator=self.gen, device=self.device)
+            buf["actions"][t] = act; buf["mean"][t] = mean; buf["log_std"][t] = log_std
+            buf["logp"][t] = gaussian_logp(act, mean, log_std); buf["values"][t] = v
+            env_act = torch.maximum(torch.minimum(act, self.a_max), -self.a_max) if cfg.clip_actions else act
+            out = {"obs": buf["raw_obs"][t], "reward": buf["reward"][t], "done": buf["done"][t], "truncated": buf["trunc"][t]}
+            self.env.vector_step(env_act, out=out)
+            raw = buf["raw_obs"][t]
+            term = (buf["done"][t] | buf["trunc"][t]).float()
+            self.stats.step(buf["reward"][t], term)
+        self.raw_obs = raw.clone()
+        last_v = model(self.filter(raw))[2]
+        terminals = (buf["done"] | buf["trunc"]).float()
+        adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, terminals, cfg.gamma, cfg.lambda_)
+        obs = torch.stack(obs_in)
+        flat = lambda x: x.reshape(-1, *x.shape[2:])  # noqa: E731
+        return {"obs": flat(obs), "actions": flat(buf["actions"]), "mean": flat(buf["mean"]),
+                "log_std": flat(buf["log_std"]), "logp": flat(buf["logp"]), "values": flat(buf["values"]),
+                "adv": flat(adv), "vtarg": flat(vtarg)}
+
+    def train(self) -> Dict[str, float]:
+        t0 = time.perf_counter()
+        batch = self.collect()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        self.filter.sync()
+        steps = batch["obs"].shape[0] * self.world
+        self.learner.timesteps_total += steps
+        info = self.learner.update(batch, self.gen)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t2 = time.perf_counter()
+        self.iteration += 1
+        res = self.stats.summarize()
+        res.update(info)
+        res.update({"training_iteration": self.iteration, "timesteps_total": self.learner.timesteps_total,
+                    "timesteps_this_iter": steps, "sample_time_s": t1 - t0, "learn_time_s": t2 - t1,
+                    "time_this_iter_s": t2 - t0, "env_steps_per_s": steps / (t2 - t0)})
+        return res
+
+    # -- checkpoint / resume (Tune's checkpoint_freq / checkpoint_at_end, pioneer_knm_train.py:72-73) --
+    def save(self, path: str) -> str:
+        if self.rank == 0:
+            torch.save({"model": self.learner.model.state_dict(), "opt": self.learner.opt.state_dict(),
+                        "filter": self.filter.state_dict(), "kl_coeff": self.learner.kl_coeff,
+                        "timesteps_total": self.learner.timesteps_total, "iteration": self.iteration,
+                        "episodes_total": self.stats.total, "env_state": self.env.get_state().cpu(),
+                        "cfg": self.cfg.__dict__}, path)
+        pdist.barrier()
+        return path
+
+    def restore(self, path: str, restore_env: bool = False) -> None:
+        ck = torch.load(path, map_location=self.device, weights_only=False)   # our own file
+        self.learner.model.load_state_dict(ck["model"]); self.learner.opt.load_state_dict(ck["opt"])
+        self.filter.load_state_dict(ck["filter"]); self.learner.kl_coeff = ck["kl_coeff"]
+        self.learner.timesteps_total = ck["timesteps_total"]; self.iteration = ck["iteration"]
+        self.stats.total = ck["episodes_total"]
+        if restore_env and ck["env_state"].shape[1] == self.env.num_envs:
+            self.env.set_state(ck["env_state"].to(self.device))
+            self.raw_obs = self.env.observe()
