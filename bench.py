@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--fused", type=int, default=1,
                     help="steps per kernel launch (1 = pnr_step per step; T>1 = pnr_rollout of T steps)")
     ap.add_argument("--ring", type=int, default=32, help="obs ring depth (rollout-buffer slices)")
+    ap.add_argument("--fused-leg", type=int, default=32,
+                    help="also report the fused pnr_rollout rate with this many steps per launch (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--mode", default="kinematic", choices=["kinematic", "dynamic"])
@@ -136,13 +138,16 @@ def main():
     # synthetic inputs, resident in HBM before the timed region
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     amax = torch.from_numpy(env.a_max).to(dev)
-    n_act = max(16, T)
+    n_act = max(16, T, args.fused_leg if (T == 1 and args.mode == "kinematic") else 0)
     if args.action_layout == "env_major":
         acts = (torch.rand(n_act, n, 6, generator=g, device=dev) * 2 - 1) * amax
     else:
         acts = (torch.rand(n_act, 6, n, generator=g, device=dev) * 2 - 1) * amax[:, None]
     ring = max(args.ring, T)
     ring -= ring % T
+    if T == 1 and args.fused_leg > 1 and args.mode == "kinematic":
+        ring = max(ring, args.fused_leg)
+        ring -= ring % args.fused_leg
     obs = torch.empty((ring,) + tuple(env.obs_shape), dtype=torch.float32, device=dev)
     rew = torch.empty((ring, n), dtype=torch.float32, device=dev)
     done = torch.empty((ring, n), dtype=torch.uint8, device=dev)
@@ -153,59 +158,74 @@ def main():
     sp = C.c_void_p(stream.cuda_stream)
     P = lambda t, i: C.c_void_p(t[i].data_ptr())  # noqa: E731
 
-    if T == 1:
-        calls = [(P(acts, i % n_act), P(obs, i % ring), P(rew, i % ring), P(done, i % ring), P(trunc, i % ring))
-                 for i in range(math.lcm(n_act, ring))]
-
-        def run(k):
-            m = len(calls)
-            for i in range(k):
-                a, o, r, d, tr = calls[i % m]
-                rc = lib.pnr_step(h, a, o, r, d, tr, None, sp)
-                if rc:
-                    _lib.check(rc, h)
-    else:
-        nslots = ring // T
-        calls = [(P(acts, 0), P(obs, s * T), P(rew, s * T), P(done, s * T), P(trunc, s * T)) for s in range(nslots)]
-
-        def run(k):
-            assert k % T == 0, "--steps/--warmup must be multiples of --fused"
-            for i in range(k // T):
-                a, o, r, d, tr = calls[i % nslots]
-                rc = lib.pnr_rollout(h, T, a, o, r, d, tr, sp)
-                if rc:
-                    _lib.check(rc, h)
-
-    K, W = args.steps, args.warmup
-    if T > 1:
-        K -= K % T
-        W -= W % T
-    run(W)
-
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    ev0.record(stream)       # torch's current stream == the stream pnr_step launches on
-    run(K)
-    ev1.record(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    def timed(T, K, W):
+        """K env-steps (after W warm-up steps) with T steps per kernel launch.  Returns
+        (wall seconds max over ranks, HIP-event ms on the launch stream, K)."""
+        if T == 1:
+            calls = [(P(acts, i % n_act), P(obs, i % ring), P(rew, i % ring), P(done, i % ring), P(trunc, i % ring))
+                     for i in range(math.lcm(n_act, ring))]
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+            def run(k):
+                m = len(calls)
+                for i in range(k):
+                    a, o, r, d, tr = calls[i % m]
+                    rc = lib.pnr_step(h, a, o, r, d, tr, None, sp)
+                    if rc:
+                        _lib.check(rc, h)
+        else:
+            nslots = ring // T
+            # operand shapes must cover what one launch touches: T action slices, T output slices per slot
+            assert acts.shape[0] >= T and nslots >= 1 and nslots * T <= obs.shape[0] == rew.shape[0] == done.shape[0] == trunc.shape[0], \
+                (acts.shape, obs.shape, T)
+            calls = [(P(acts, 0), P(obs, s * T), P(rew, s * T), P(done, s * T), P(trunc, s * T)) for s in range(nslots)]
+            K -= K % T
+            W -= W % T
 
+            def run(k):
+                for i in range(k // T):
+                    a, o, r, d, tr = calls[i % nslots]
+                    rc = lib.pnr_rollout(h, T, a, o, r, d, tr, sp)
+                    if rc:
+                        _lib.check(rc, h)
+        run(W)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record(stream)       # torch's current stream == the stream pnr_step launches on
+        run(K)
+        ev1.record(stream)
+        barrier()
+        el = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, ev_ms, K
+
+    elapsed, ev_ms, K = timed(T, args.steps, args.warmup)
+    W = args.warmup - (args.warmup % T)
     total_env_steps = float(n) * world * K
     value = total_env_steps / elapsed
+
+    fused = None
+    if T == 1 and args.fused_leg > 1 and args.mode == "kinematic":
+        Tf = min(args.fused_leg, ring)
+        fel, fev, fK = timed(Tf, max(Tf, args.steps), max(Tf, args.warmup))
+        fl_ms = fev / (fK // Tf)
+        fb = n * (STEP_IO_BYTES * Tf + STATE_BYTES)
+        fused = {"value": float(n) * world * fK / fel, "unit": "env-steps/s", "steps_per_launch": Tf, "steps": fK,
+                 "ms_per_step": fel / fK * 1e3, "avg_launch_ms": fl_ms,
+                 "algorithmic_bytes_per_launch": fb, "achieved_GBps": fb / (fl_ms * 1e-3) / 1e9,
+                 "frac": fb / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "note": "pnr_rollout: same kernel, T steps per launch with open-loop actions; state stays in registers"}
 
     ppo_loop = None
     if args.ppo_iters > 0:
@@ -258,6 +278,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": launch_ms, "timing": "HIP events on the launch stream around the timed region / launches"},
         }
+        if fused:
+            out["fused_rollout"] = fused
         if ppo_loop:
             out["ppo_loop"] = ppo_loop
         if not args.no_cpu_baseline:

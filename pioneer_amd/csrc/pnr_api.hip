@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
 {
     __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
 
+    if (P.diag & 64) return;                // empty-launch floor
     const int lane = threadIdx.x;
     const int p = lane & 1;                 // which half of the env's joints
     const int el = lane >> 1;               // env within the wave's tile
@@ -50,6 +51,8 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
     LaneState s;
     if (valid) load_state(P.state, n, rec, p, s);   // the pair shares `valid`, so DPP partners are live
     else zero_state(s);
+
+    if (P.diag & 16) { if (valid) P.reward[e] = s.pot; return; }   // launch + state-load floor
 
     const float vmax0 = p ? P.v_max[kJpl + 0] : P.v_max[0];
     const float vmax1 = p ? P.v_max[kJpl + 1] : P.v_max[1];
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
 #pragma unroll
             for (int i = 0; i < kJpl; ++i) {
                 const float lim = lane_limit(p, i);
-                integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, P.dt, P.eps, s.v[i], s.r[i]);
+                if (!(P.diag & 32)) integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, P.dt, P.eps, s.v[i], s.r[i]);
             }
 #pragma unroll
             for (int i = 0; i < kJpl; ++i) s.a[i] = act[i];           // :144 (quirk Q1)
