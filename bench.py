@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--fused", type=int, default=1,
                     help="steps per kernel launch (1 = pnr_step per step; T>1 = pnr_rollout of T steps)")
     ap.add_argument("--ring", type=int, default=32, help="obs ring depth (rollout-buffer slices)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the per-step launches from a hipGraph")
     ap.add_argument("--fused-leg", type=int, default=32,
                     help="also report the fused pnr_rollout rate with this many steps per launch (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,13 +172,31 @@ def main():
             calls = [(P(acts, i % n_act), P(obs, i % ring), P(rew, i % ring), P(done, i % ring), P(trunc, i % ring))
                      for i in range(math.lcm(n_act, ring))]
 
-            def run(k):
+            def run_eager(k, spx=sp):
                 m = len(calls)
                 for i in range(k):
                     a, o, r, d, tr = calls[i % m]
-                    rc = lib.pnr_step(h, a, o, r, d, tr, None, sp)
+                    rc = lib.pnr_step(h, a, o, r, d, tr, None, spx)
                     if rc:
                         _lib.check(rc, h)
+
+            run = run_eager
+            if args.graph:
+                # the step loop is launch-bound on the host: capture one pass over the obs ring
+                # (len(calls) launches of pnr_step) in a hipGraph and replay it
+                m = len(calls)
+                run_eager(m)
+                torch.cuda.synchronize(dev)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    run_eager(m, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+
+                def run(k):   # noqa: F811
+                    assert k % m == 0, f"--steps/--warmup must be multiples of {m} with --graph"
+                    for _ in range(k // m):
+                        g_.replay()
+                K -= K % m
+                W = max(m, W - W % m)
         else:
             nslots = ring // T
             # operand shapes must cover what one launch touches: T action slices, T output slices per slot
@@ -208,17 +227,16 @@ def main():
             tmax = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
-        return el, ev_ms, K
+        return el, ev_ms, K, W
 
-    elapsed, ev_ms, K = timed(T, args.steps, args.warmup)
-    W = args.warmup - (args.warmup % T)
+    elapsed, ev_ms, K, W = timed(T, args.steps, args.warmup)
     total_env_steps = float(n) * world * K
     value = total_env_steps / elapsed
 
     fused = None
     if T == 1 and args.fused_leg > 1 and args.mode == "kinematic":
         Tf = min(args.fused_leg, ring)
-        fel, fev, fK = timed(Tf, max(Tf, args.steps), max(Tf, args.warmup))
+        fel, fev, fK, _ = timed(Tf, max(Tf, args.steps), max(Tf, args.warmup))
         fl_ms = fev / (fK // Tf)
         fb = n * (STEP_IO_BYTES * Tf + STATE_BYTES)
         fused = {"value": float(n) * world * fK / fel, "unit": "env-steps/s", "steps_per_launch": Tf, "steps": fK,
@@ -232,9 +250,9 @@ def main():
         from pioneer_amd.ppo import PPOConfig, PPOTrainer
         penv = PioneerVectorEnv(args.ppo_envs, device=dev, seed=0, env_id_offset=rank * args.ppo_envs,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=args.mode))
-        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=32768)
-        tr = PPOTrainer(penv, pcfg)
-        tr.train()                                   # warm-up iteration (allocator, RCCL)
+        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=131072, amp_bf16=True)
+        tr = PPOTrainer(penv, pcfg, use_graph=True)
+        tr.train(); tr.train()                       # warm-up: eager iteration, then the graph-captured one
         barrier()
         tp = time.perf_counter()
         rs = [tr.train() for _ in range(args.ppo_iters)]
@@ -242,7 +260,8 @@ def main():
         tp = time.perf_counter() - tp
         steps = args.ppo_iters * 32 * args.ppo_envs * world
         ppo_loop = {"value": steps / tp, "unit": "env-steps/s", "envs_per_gpu": args.ppo_envs, "rollout_T": 32,
-                    "num_sgd_iter": 4, "sgd_minibatch_size": 32768, "iters": args.ppo_iters,
+                    "num_sgd_iter": 4, "sgd_minibatch_size": 131072, "mlp_dtype": "bf16 autocast", "hip_graph_sampling": True,
+                    "iters": args.ppo_iters,
                     "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                     "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
         penv.close()
@@ -272,7 +291,7 @@ def main():
                                    f"(integrate+FK+reward+TimeLimit(500)+auto-reset+obs[137]), random actions U(-a_max,a_max) resident in HBM",
                        "envs_per_gpu": n, "total_envs": n * world, "mode": args.mode,
                        "obs_layout": args.obs_layout, "action_layout": args.action_layout,
-                       "steps_per_launch": T, "obs_ring_slices": ring, "parallelism": f"env-shard x{world}"},
+                       "steps_per_launch": T, "hip_graph": bool(args.graph and T == 1), "obs_ring_slices": ring, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,

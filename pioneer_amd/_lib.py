@@ -119,6 +119,14 @@ def load_library():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  pioneer_amd has no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as ROCm's).  If this
+    # library were loaded first it would pull in /opt/rocm's copy, torch would then load its own, and
+    # the two runtimes would not see each other's devices/streams.  Importing torch first makes our
+    # DT_NEEDED libamdhip64.so.7 resolve to the copy torch already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

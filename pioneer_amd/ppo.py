@@ -48,6 +48,8 @@ class PPOConfig:
     observation_filter: str = "MeanStdFilter"
     filter_clip: float = 10.0
     seed: int = 0
+    # engine options (no reference counterpart)
+    amp_bf16: bool = False                # run the MLP GEMMs in bf16 (MFMA) under autocast; losses stay fp32
 
 
 def sample_entropy_start(rng: np.random.RandomState, min_start: float = 1e-3, max_start: float = 1e-1,
@@ -80,18 +82,21 @@ class MeanStdFilter:
         self._dsq += (xd * xd).sum(0)
 
     def sync(self) -> None:
-        """Merge the pending deltas of all ranks into the running statistics (Chan et al.)."""
+        """Merge the pending deltas of all ranks into the running statistics (Chan et al.).
+        In place and without host synchronisation, so a captured hipGraph keeps seeing them."""
         packed = torch.cat([self._dn.reshape(1), self._dsum, self._dsq])
         pdist.allreduce_sum_(packed)
-        dn, dsum, dsq = packed[0], packed[1:1 + self.mean.numel()], packed[1 + self.mean.numel():]
-        if float(dn) > 0:
-            bmean = dsum / dn
-            bm2 = dsq - dn * bmean * bmean
-            tot = self.n + dn
-            delta = bmean - self.mean
-            self.mean = self.mean + delta * (dn / tot)
-            self.m2 = self.m2 + bm2 + delta * delta * (self.n * dn / tot)
-            self.n = tot
+        d = self.mean.numel()
+        dn, dsum, dsq = packed[0], packed[1:1 + d], packed[1 + d:]
+        dn_safe = torch.clamp(dn, min=1.0)
+        bmean = dsum / dn_safe
+        bm2 = dsq - dn * bmean * bmean
+        tot = self.n + dn
+        tot_safe = torch.clamp(tot, min=1.0)
+        delta = bmean - self.mean
+        self.m2.add_(bm2 + delta * delta * (self.n * dn / tot_safe))
+        self.mean.add_(delta * (dn / tot_safe))
+        self.n.copy_(tot)
         self._dn.zero_(); self._dsum.zero_(); self._dsq.zero_()
 
     @property
@@ -100,16 +105,16 @@ class MeanStdFilter:
         return torch.sqrt(torch.clamp(var, min=0.0))
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        if float(self.n) < 2:
-            return x
         y = (x - self.mean.to(x.dtype)) / (self.std.to(x.dtype) + 1e-8)
-        return torch.clamp(y, -self.clip, self.clip) if self.clip else y
+        if self.clip:
+            y = torch.clamp(y, -self.clip, self.clip)
+        return torch.where(self.n < 2, x, y)      # identity until two samples exist (no host sync)
 
     def state_dict(self):
         return {"n": self.n, "mean": self.mean, "m2": self.m2}
 
     def load_state_dict(self, sd):
-        self.n, self.mean, self.m2 = sd["n"].to(self.n), sd["mean"].to(self.mean), sd["m2"].to(self.m2)
+        self.n.copy_(sd["n"]); self.mean.copy_(sd["mean"]); self.m2.copy_(sd["m2"])
 
 
 class NoFilter:
@@ -149,9 +154,15 @@ class ActorCritic(nn.Module):
         mean, log_std = out[..., :self.act_dim], out[..., self.act_dim:]
         return mean, torch.clamp(log_std, -20.0, 2.0)
 
-    def forward(self, obs):
-        mean, log_std = self.dist_params(obs)
-        return mean, log_std, self.value(obs).squeeze(-1)
+    def forward(self, obs, amp_bf16: bool = False):
+        if amp_bf16 and obs.is_cuda:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out, v = self.policy(obs), self.value(obs)
+            out, v = out.float(), v.float()
+        else:
+            out, v = self.policy(obs), self.value(obs)
+        mean, log_std = out[..., :self.act_dim], torch.clamp(out[..., self.act_dim:], -20.0, 2.0)
+        return mean, log_std, v.squeeze(-1)
 
 
 def gaussian_logp(x, mean, log_std):
@@ -249,7 +260,7 @@ class PPOLearner:
 
     def loss(self, mb: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         cfg = self.cfg
-        mean, log_std, v = self.model(mb["obs"])
+        mean, log_std, v = self.model(mb["obs"], cfg.amp_bf16)
         logp = gaussian_logp(mb["actions"], mean, log_std)
         ratio = torch.exp(logp - mb["logp"])
         adv = mb["adv"]
@@ -309,9 +320,13 @@ class PPOLearner:
 
 
 class PPOTrainer:
-    """Rollout + learn loop over a PioneerVectorEnv shard (one process per GPU)."""
+    """Rollout + learn loop over a PioneerVectorEnv shard (one process per GPU).
 
-    def __init__(self, env, cfg: Optional[PPOConfig] = None):
+    ``use_graph=True`` captures the whole T-step sampling loop (obs filter, policy forward, action
+    sampling, ``pnr_step``, episode statistics, GAE) into ONE hipGraph after an eager warm-up
+    iteration: the loop is launch-bound (~60 small kernels around a 5 us env kernel per step)."""
+
+    def __init__(self, env, cfg: Optional[PPOConfig] = None, use_graph: bool = False):
         self.env = env
         self.cfg = cfg or PPOConfig()
         self.device = env.device
@@ -323,32 +338,39 @@ class PPOTrainer:
         self.gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed * 1000003 + self.rank)
         self.a_max = torch.from_numpy(env.a_max).to(self.device)
         self.iteration = 0
-        self.raw_obs = env.reset()
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self._graph = None
         T, N = self.cfg.rollout_fragment_length, env.num_envs
         f32 = dict(dtype=torch.float32, device=self.device)
+        self.raw_obs = torch.empty((N, self.cfg.obs_dim), **f32)       # static: the obs the next rollout starts from
+        self.raw_obs.copy_(env.reset())
         self.buf = {
             "raw_obs": torch.empty((T, N, self.cfg.obs_dim), **f32),   # written in place by pnr_step
+            "obs": torch.empty((T, N, self.cfg.obs_dim), **f32),       # filtered, what the nets saw
             "actions": torch.empty((T, N, self.cfg.act_dim), **f32),
             "mean": torch.empty((T, N, self.cfg.act_dim), **f32),
             "log_std": torch.empty((T, N, self.cfg.act_dim), **f32),
             "logp": torch.empty((T, N), **f32), "values": torch.empty((T, N), **f32),
             "reward": torch.empty((T, N), **f32),
+            "adv": torch.empty((T, N), **f32), "vtarg": torch.empty((T, N), **f32),
             "done": torch.empty((T, N), dtype=torch.uint8, device=self.device),
             "trunc": torch.empty((T, N), dtype=torch.uint8, device=self.device),
         }
 
     @torch.no_grad()
-    def collect(self) -> Dict[str, torch.Tensor]:
+    def _collect_impl(self) -> None:
+        """T steps into the static buffers; pure device work (capturable)."""
         cfg, buf, model = self.cfg, self.buf, self.learner.model
         T = cfg.rollout_fragment_length
-        obs_in = []
         raw = self.raw_obs
         for t in range(T):
             self.filter.observe(raw)
             x = self.filter(raw)
-            obs_in.append(x)
-            mean, log_std, v = model(x)
-            act = mean + torch.exp(log_std) * torch.randn(mean.shape, generator=self.gen, device=self.device)
+            buf["obs"][t] = x
+            mean, log_std, v = model(x, cfg.amp_bf16)
+            noise = (torch.randn(mean.shape, device=self.device) if self._capturing
+                     else torch.randn(mean.shape, generator=self.gen, device=self.device))
+            act = mean + torch.exp(log_std) * noise
             buf["actions"][t] = act; buf["mean"][t] = mean; buf["log_std"][t] = log_std
             buf["logp"][t] = gaussian_logp(act, mean, log_std); buf["values"][t] = v
             env_act = torch.maximum(torch.minimum(act, self.a_max), -self.a_max) if cfg.clip_actions else act
@@ -357,15 +379,34 @@ class PPOTrainer:
             raw = buf["raw_obs"][t]
             term = (buf["done"][t] | buf["trunc"][t]).float()
             self.stats.step(buf["reward"][t], term)
-        self.raw_obs = raw.clone()
-        last_v = model(self.filter(raw))[2]
+        self.raw_obs.copy_(raw)
+        last_v = model(self.filter(raw), cfg.amp_bf16)[2]
         terminals = (buf["done"] | buf["trunc"]).float()
         adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, terminals, cfg.gamma, cfg.lambda_)
-        obs = torch.stack(obs_in)
+        buf["adv"].copy_(adv); buf["vtarg"].copy_(vtarg)
+
+    _capturing = False
+
+    def collect(self) -> Dict[str, torch.Tensor]:
+        if self.use_graph and self._graph is None and self.iteration >= 1:
+            # capture after one eager iteration (allocator and library warm-up done)
+            torch.cuda.synchronize(self.device)
+            self._capturing = True              # in-graph noise comes from the default (graph-safe) generator
+            torch.cuda.manual_seed(self.cfg.seed * 7919 + self.rank + 1)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._collect_impl()
+            self._graph = g
+            # the capture pass itself only recorded work: run it for real below
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._collect_impl()
+        buf = self.buf
         flat = lambda x: x.reshape(-1, *x.shape[2:])  # noqa: E731
-        return {"obs": flat(obs), "actions": flat(buf["actions"]), "mean": flat(buf["mean"]),
+        return {"obs": flat(buf["obs"]), "actions": flat(buf["actions"]), "mean": flat(buf["mean"]),
                 "log_std": flat(buf["log_std"]), "logp": flat(buf["logp"]), "values": flat(buf["values"]),
-                "adv": flat(adv), "vtarg": flat(vtarg)}
+                "adv": flat(buf["adv"]), "vtarg": flat(buf["vtarg"])}
 
     def train(self) -> Dict[str, float]:
         t0 = time.perf_counter()
@@ -407,4 +448,4 @@ class PPOTrainer:
         self.stats.total = ck["episodes_total"]
         if restore_env and ck["env_state"].shape[1] == self.env.num_envs:
             self.env.set_state(ck["env_state"].to(self.device))
-            self.raw_obs = self.env.observe()
+            self.raw_obs.copy_(self.env.observe())
