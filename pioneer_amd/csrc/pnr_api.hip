@@ -39,48 +39,83 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
     const int p = lane & 1;                 // which half of the env's joints
     const int el = lane >> 1;               // env within the wave's tile
     const long long n = P.n;
-    const long long tile0 = (long long)blockIdx.x * kEnvsPerWave;
-    const long long e = tile0 + el;
-    const long long rec = 2 * tile0 + lane; // state record index (2e + p)
-    const bool valid = e < n;
-    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
+    const long long ntiles = (n + kEnvsPerWave - 1) / kEnvsPerWave;
 
     // PNR_DIAG timing-only ablations (outputs are wrong when set; see DESIGN.md "Where the time goes")
     const bool diag_noflush = P.diag & 2, diag_noemit = P.diag & 4, diag_nostate = P.diag & 8;
-
-    LaneState s;
-    if (valid) load_state(P.state, n, rec, p, s);   // the pair shares `valid`, so DPP partners are live
-    else zero_state(s);
-
-    if (P.diag & 16) { if (valid) P.reward[e] = s.pot; return; }   // launch + state-load floor
 
     const float vmax0 = p ? P.v_max[kJpl + 0] : P.v_max[0];
     const float vmax1 = p ? P.v_max[kJpl + 1] : P.v_max[1];
     const float vmax2 = p ? P.v_max[kJpl + 2] : P.v_max[2];
     const float vmax[kJpl] = {vmax0, vmax1, vmax2};
+    const LaneConsts K = lane_consts(p);
+
+    // Persistent tile loop: the grid is capped (host: <= 8 waves per CU) and every wave strides over
+    // tiles.  The NEXT tile's state and first action are requested before the current tile is
+    // processed, so they never queue behind this CU's own obs stores.
+    const auto load_act0 = [&](long long e_, float (&a_)[kJpl]) {
+        if (DYN) { a_[0] = a_[1] = a_[2] = 0.f; return; }
+        if (ACT_EM) {
+            const float* a3 = P.actions + e_ * kDof + kJpl * p;         // 12 B per lane, lanes contiguous
+            a_[0] = a3[0]; a_[1] = a3[1]; a_[2] = a3[2];
+        } else {
+#pragma unroll
+            for (int i = 0; i < kJpl; ++i) a_[i] = P.actions[(long long)(kJpl * p + i) * n + e_];
+        }
+    };
+
+    long long tix = blockIdx.x;
+    RawState raw = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float act0[kJpl] = {0.f, 0.f, 0.f};
+    if (tix < ntiles && tix * kEnvsPerWave + el < n) {
+        raw = load_state_raw(P.state, n, 2 * tix * kEnvsPerWave + lane);
+        load_act0(tix * kEnvsPerWave + el, act0);
+    }
+    bool first_tile = true;
+
+    for (; tix < ntiles; tix += gridDim.x) {
+    const long long tile0 = tix * kEnvsPerWave;
+    const long long e = tile0 + el;
+    const long long rec = 2 * tile0 + lane; // state record index (2e + p)
+    const bool valid = e < n;               // the pair shares `valid`, so DPP partners are live
+    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
+
+    LaneState s;
+    unpack_state(raw, p, s);                // all-zero records for lanes past the end
+    float act_first[kJpl] = {act0[0], act0[1], act0[2]};
+
+    // prefetch the next tile
+    {
+        const long long nt = tix + gridDim.x;
+        if (nt < ntiles && nt * kEnvsPerWave + el < n) {
+            raw = load_state_raw(P.state, n, 2 * nt * kEnvsPerWave + lane);
+            load_act0(nt * kEnvsPerWave + el, act0);
+        } else {
+            raw = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        }
+    }
+
+    if (P.diag & 16) { if (valid) P.reward[e] = s.pot; continue; }   // launch + state-load floor
 
     for (int t = 0; t < P.T; ++t) {
         LaneState o;     // what reward / obs see: the kinematic state, or the simulated q, qd in dynamics mode
         if (!DYN) {
             // -- action of this step (this lane's three joints) ----------------------
-            float act[kJpl];
-            if (valid) {
+            float act[kJpl] = {act_first[0], act_first[1], act_first[2]};   // t = 0: prefetched
+            if (t > 0 && valid) {
                 const float* A = P.actions + (long long)t * n * kDof;
                 if (ACT_EM) {
-                    const float* a3 = A + e * kDof + kJpl * p;      // 12 B per lane, lanes contiguous
+                    const float* a3 = A + e * kDof + kJpl * p;
                     act[0] = a3[0]; act[1] = a3[1]; act[2] = a3[2];
                 } else {
 #pragma unroll
                     for (int i = 0; i < kJpl; ++i) act[i] = A[(long long)(kJpl * p + i) * n + e];
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < kJpl; ++i) act[i] = 0.f;
             }
             // -- act(): integrate the PREVIOUS action, then latch the new one -------
 #pragma unroll
             for (int i = 0; i < kJpl; ++i) {
-                const float lim = lane_limit(p, i);
+                const float lim = K.lim[i];
                 if (!(P.diag & 32)) integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, P.dt, P.eps, s.v[i], s.r[i]);
             }
 #pragma unroll
@@ -128,29 +163,32 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
         // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
         o.pot = pot;
         if (P.auto_reset && (done || trunc)) {
-            reset_env(P, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
+            reset_env(P, K, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
             if (DYN && valid) dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);
             o = s;
             compute_pose(o, p, q);
         }
 
+        // state goes out before the obs is packed: its stores drain under the LDS emit
+        if (t == P.T - 1 && valid && !diag_nostate) store_state(P.state, n, rec, p, s);
+
         // -- observe() ----------------------------------------------------------------
         float* obs_t = P.obs + (long long)t * n * kObsDim;
-        if (t > 0) __syncthreads();       // previous flush done before the tile is rewritten
+        if (t > 0 || !first_tile) wave_lds_sync();   // previous flush done before the tile is rewritten
         if (OBS_EM) {
             SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-            if (!diag_noemit) emit_obs(o, q, p, sink);
-            __syncthreads();
+            if (!diag_noemit) emit_obs(K, o, q, p, sink);
+            wave_lds_sync();
             if (!diag_noflush) flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
         } else {
             SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-            emit_obs(o, q, p, sink);
-            __syncthreads();
+            emit_obs(K, o, q, p, sink);
+            wave_lds_sync();
             flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
         }
     }
-
-    if (valid && !diag_nostate) store_state(P.state, n, rec, p, s);
+    first_tile = false;
+    }   // tile loop
 }
 
 // ---------------------------------------------------------------------------------
@@ -172,6 +210,7 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P, const Dyn
     const bool valid = e < n;
     const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
 
+    const LaneConsts K = lane_consts(p);
     LaneState s;
     if (valid) load_state(P.state, n, rec, p, s);
     else zero_state(s);
@@ -179,7 +218,7 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P, const Dyn
     if (MODE == 0) {
         if (valid && P.mask) active = P.mask[e] != 0;
         if (active) {   // both lanes of a pair take the same branch
-            reset_env(P, s, p, P.env_off + (unsigned long long)e,
+            reset_env(P, K, s, p, P.env_off + (unsigned long long)e,
                       P.joint_pos ? P.joint_pos + e * kDof : nullptr,
                       P.target_pos ? P.target_pos + e * 3 : nullptr);
             store_state(P.state, n, rec, p, s);
@@ -201,20 +240,20 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P, const Dyn
         compute_pose(s, p, q);   // every lane takes part: the DPP exchange needs live partners
         if (OBS == 1) {
             SinkDirect sink{P.obs + e, n, kJpl * p, p, active};
-            emit_obs(s, q, p, sink);
+            emit_obs(K, s, q, p, sink);
         } else if (OBS == 2) {
             SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-            emit_obs(s, q, p, sink);
-            __syncthreads();
+            emit_obs(K, s, q, p, sink);
+            wave_lds_sync();
             flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
         } else if (OBS == 4) {
             SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-            emit_obs(s, q, p, sink);
-            __syncthreads();
+            emit_obs(K, s, q, p, sink);
+            wave_lds_sync();
             flush_feature_tile(tile, P.obs + tile0, n, nvalid, lane);
         } else {
             SinkDirect sink{P.obs + e * kObsDim, 1, kJpl * p, p, active};
-            emit_obs(s, q, p, sink);
+            emit_obs(K, s, q, p, sink);
         }
     }
 }
@@ -504,6 +543,15 @@ const char* pnr_last_error(pnr_handle h) { return h ? h->err : g_err; }
 
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kEnvsPerWave - 1) / kEnvsPerWave); }
 
+// step kernels are persistent over tiles: at most 8 one-wave workgroups per CU (256 CUs)
+static inline unsigned step_grid_for(long long n)
+{
+    static int cap = -1;
+    if (cap < 0) { const char* e_ = getenv("PNR_GRID_CAP"); cap = e_ ? atoi(e_) : 2048; if (cap < 1) cap = 2048; }
+    const unsigned tiles = grid_for(n);
+    return tiles < (unsigned)cap ? tiles : (unsigned)cap;
+}
+
 int pnr_reset(pnr_handle h, const uint8_t* mask, const float* joint_pos, const float* target_pos,
               float* obs_out, void* stream)
 {
@@ -564,7 +612,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     KParams P = h->base;
     P.diag = h->diag;
     P.T = T; P.actions = actions; P.obs = obs; P.reward = reward; P.done = done; P.trunc = truncated; P.info = info;
-    const dim3 grid(grid_for(h->n)), block(kWave);
+    const dim3 grid(step_grid_for(h->n)), block(kWave);
     hipStream_t st = (hipStream_t)stream;
     const DynParams& D = h->dbase;
     const bool oem = h->cfg.obs_layout == PNR_ENV_MAJOR, aem = h->cfg.action_layout == PNR_ENV_MAJOR;

@@ -66,6 +66,18 @@ struct LaneState {
     uint32_t step, episode;
 };
 
+// LDS hand-off between the lanes of ONE wave (every workgroup here is a single wave).  A wave's DS
+// instructions execute in issue order, so a ds_write followed by another lane's ds_read needs no
+// s_barrier and, unlike __syncthreads(), no s_waitcnt vmcnt(0): outstanding global stores (the
+// previous tile's obs flush) keep draining while the next tile is packed.  The fences only pin
+// the compiler's ordering of LDS accesses.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // partner lane's value (lane ^ 1) by DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ float xchg(float x)
 {
@@ -77,10 +89,17 @@ __device__ __forceinline__ float xchg(float x)
 //   plane 1: v[3p+1] v[3p+2] r[3p] r[3p+1]
 //   plane 2: r[3p+2] C0 C1 C2     p = 0: C = target xyz; p = 1: C = potential, step_index, episode
 // so a wave reads/writes each plane with one lane-contiguous 1-KiB dwordx4.
-__device__ __forceinline__ void load_state(const float4* __restrict__ st, long long n, long long rec, int p, LaneState& s)
+struct RawState { float4 p0, p1, p2; };
+
+__device__ __forceinline__ RawState load_state_raw(const float4* __restrict__ st, long long n, long long rec)
 {
     const long long n2 = 2 * n;
-    const float4 p0 = st[rec], p1 = st[n2 + rec], p2 = st[2 * n2 + rec];
+    return {st[rec], st[n2 + rec], st[2 * n2 + rec]};
+}
+
+__device__ __forceinline__ void unpack_state(const RawState& raw, int p, LaneState& s)
+{
+    const float4 p0 = raw.p0, p1 = raw.p1, p2 = raw.p2;
     s.a[0] = p0.x; s.a[1] = p0.y; s.a[2] = p0.z; s.v[0] = p0.w;
     s.v[1] = p1.x; s.v[2] = p1.y; s.r[0] = p1.z; s.r[1] = p1.w;
     s.r[2] = p2.x;
@@ -89,6 +108,11 @@ __device__ __forceinline__ void load_state(const float4* __restrict__ st, long l
     s.pot = p ? p2.y : o1;
     s.step = __float_as_uint(p ? p2.z : o2);
     s.episode = __float_as_uint(p ? p2.w : o3);
+}
+
+__device__ __forceinline__ void load_state(const float4* __restrict__ st, long long n, long long rec, int p, LaneState& s)
+{
+    unpack_state(load_state_raw(st, n, rec), p, s);
 }
 
 __device__ __forceinline__ void store_state(float4* __restrict__ st, long long n, long long rec, int p, const LaneState& s)
@@ -107,10 +131,28 @@ __device__ __forceinline__ void zero_state(LaneState& s)
     s.tgt[0] = s.tgt[1] = s.tgt[2] = 0.f; s.pot = 0.f; s.step = 0; s.episode = 0;
 }
 
-// per-joint constants of this lane's joint i (joint 3p + i)
-__device__ __forceinline__ float lane_limit(int p, int i) { return p ? limit_hi(kJpl + i) : limit_hi(i); }
-__device__ __forceinline__ float lane_limit_cos(int p, int i) { return p ? kLimitCos[kJpl + i] : kLimitCos[i]; }
-__device__ __forceinline__ float lane_limit_sin(int p, int i) { return p ? kLimitSin[kJpl + i] : kLimitSin[i]; }
+// Per-joint constants of this lane's joints (joint 3p + i), built ONCE per kernel from constexpr
+// locals.  Written this way on purpose: `p ? table[3 + i] : table[i]` makes LLVM fold the select
+// into a dynamically indexed load from the constant array — a global load plus s_waitcnt vmcnt(0)
+// (which also waits for every outstanding store) in the middle of the hot loop.
+struct LaneConsts {
+    float lim[kJpl];   // r_hi (= -r_lo)
+    float lc[kJpl];    // cos(r_hi)
+    float ls[kJpl];    // sin(r_hi)
+};
+
+__device__ __forceinline__ LaneConsts lane_consts(int p)
+{
+    constexpr float l0 = limit_hi(0), l1 = limit_hi(1), l2 = limit_hi(2), l3 = limit_hi(3), l4 = limit_hi(4), l5 = limit_hi(5);
+    constexpr float c0 = kLimitCos[0], c1 = kLimitCos[1], c2 = kLimitCos[2], c3 = kLimitCos[3], c4 = kLimitCos[4], c5 = kLimitCos[5];
+    constexpr float s0 = kLimitSin[0], s1 = kLimitSin[1], s2 = kLimitSin[2], s3 = kLimitSin[3], s4 = kLimitSin[4], s5 = kLimitSin[5];
+    static_assert(kJpl == 3, "lane_consts is written for three joints per lane");
+    LaneConsts k;
+    k.lim[0] = p ? l3 : l0; k.lim[1] = p ? l4 : l1; k.lim[2] = p ? l5 : l2;
+    k.lc[0] = p ? c3 : c0;  k.lc[1] = p ? c4 : c1;  k.lc[2] = p ? c5 : c2;
+    k.ls[0] = p ? s3 : s0;  k.ls[1] = p ? s4 : s1;  k.ls[2] = p ? s5 : s2;
+    return k;
+}
 
 // ---- sin/cos -------------------------------------------------------------------------
 // np.sin / np.cos of the float32 observation pieces (pioneer_knm_env.py:195-203).
@@ -231,8 +273,8 @@ __device__ __forceinline__ double u01(uint32_t x) { return (double)(x >> 8) * (1
 // step_index = 0.  jp / tp (this ENV's rows) override the draws, as
 // reset_world's joint_positions / target_position arguments do.  Both lanes of
 // a pair run this and keep their own three joints.
-__device__ __forceinline__ void reset_env(const KParams& P, LaneState& s, int p, unsigned long long genv,
-                                          const float* jp, const float* tp)
+__device__ __forceinline__ void reset_env(const KParams& P, const LaneConsts& K, LaneState& s, int p,
+                                          unsigned long long genv, const float* jp, const float* tp)
 {
     uint32_t w[12];
 #pragma unroll
@@ -243,7 +285,7 @@ __device__ __forceinline__ void reset_env(const KParams& P, LaneState& s, int p,
     }
 #pragma unroll
     for (int i = 0; i < kJpl; ++i) {
-        const double hi = (double)lane_limit(p, i), lo = -hi;
+        const double hi = (double)K.lim[i], lo = -hi;
         const uint32_t word = p ? w[kJpl + i] : w[i];
         const float drawn = (float)(lo + (hi - lo) * u01(word));             // :80-81
         s.r[i] = jp ? jp[kJpl * p + i] : drawn;                              // :94 (stored as float32)
@@ -291,12 +333,12 @@ __device__ __forceinline__ void compute_pose(const LaneState& s, int p, Pose& q)
 // (lane 1).  Tail pieces (126..136): lane 0 writes pointer + target, lane 1
 // diff + distance + potential.
 template <class Sink>
-__device__ __forceinline__ void emit_obs(const LaneState& s, const Pose& q, int p, Sink& out)
+__device__ __forceinline__ void emit_obs(const LaneConsts& K, const LaneState& s, const Pose& q, int p, Sink& out)
 {
 #pragma unroll
     for (int i = 0; i < kJpl; ++i) {
         float sn, cs;
-        const float lim = lane_limit(p, i), lc = lane_limit_cos(p, i), ls = lane_limit_sin(p, i);
+        const float lim = K.lim[i], lc = K.lc[i], ls = K.ls[i];
         // [0:18]  r, cos r, sin r
         out.putj(0 + i, s.r[i]); out.putj(6 + i, q.c[i]); out.putj(12 + i, q.s[i]);
         // [18:54] limits and their cos/sin (compile-time constants)
