@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--fused", type=int, default=1,
                     help="steps per kernel launch (1 = pnr_step per step; T>1 = pnr_rollout of T steps)")
     ap.add_argument("--ring", type=int, default=32, help="obs ring depth (rollout-buffer slices)")
+    ap.add_argument("--large-envs", type=int, default=262144,
+                    help="also time pnr_step on this many envs per GPU and report it as \"large_batch\" (0 = skip)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the per-step launches from a hipGraph")
     ap.add_argument("--fused-leg", type=int, default=32,
                     help="also report the fused pnr_rollout rate with this many steps per launch (0 = skip)")
@@ -245,6 +247,42 @@ def main():
                  "frac": fb / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  "note": "pnr_rollout: same kernel, T steps per launch with open-loop actions; state stays in registers"}
 
+    # the same kernel on a larger batch per launch (amortises the ~3.5 us launch + first-load floor)
+    large = None
+    if T == 1 and args.large_envs > n and args.mode == "kinematic":
+        nl = args.large_envs
+        lenv = PioneerVectorEnv(nl, device=dev, seed=0, env_id_offset=world * n + rank * nl,
+                                engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
+                                                           obs_layout=args.obs_layout, action_layout=args.action_layout))
+        lenv.reset()
+        lring = 8
+        lacts = (torch.rand((4,) + tuple(lenv.action_shape), generator=g, device=dev) * 2 - 1) * \
+            (amax if args.action_layout == "env_major" else amax[:, None])
+        lobs = torch.empty((lring,) + tuple(lenv.obs_shape), dtype=torch.float32, device=dev)
+        lrew = torch.empty((lring, nl), dtype=torch.float32, device=dev)
+        ldone = torch.empty((lring, nl), dtype=torch.uint8, device=dev)
+        ltr = torch.empty((lring, nl), dtype=torch.uint8, device=dev)
+        lh = lenv._h
+
+        def lrun(k):
+            for i in range(k):
+                rc = lib.pnr_step(lh, P(lacts, i % 4), P(lobs, i % lring), P(lrew, i % lring), P(ldone, i % lring),
+                                  P(ltr, i % lring), None, sp)
+                if rc:
+                    _lib.check(rc, lh)
+        lrun(32)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record(stream); lrun(256); e1.record(stream)
+        barrier()
+        lms = e0.elapsed_time(e1) / 256
+        large = {"envs_per_gpu": nl, "steps": 256, "avg_launch_ms": lms, "env_steps_per_s_per_gpu": nl / (lms * 1e-3),
+                 "achieved_GBps": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9,
+                 "frac": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "note": "pnr_step, one launch per step, same kernel as `value`; rank 0's HIP-event timing"}
+        lenv.close()
+        del lobs, lacts
+
     ppo_loop = None
     if args.ppo_iters > 0:
         from pioneer_amd.ppo import PPOConfig, PPOTrainer
@@ -299,6 +337,8 @@ def main():
         }
         if fused:
             out["fused_rollout"] = fused
+        if large:
+            out["large_batch"] = large
         if ppo_loop:
             out["ppo_loop"] = ppo_loop
         if not args.no_cpu_baseline:
