@@ -105,7 +105,15 @@ def cpu_baseline(n_envs, seconds):
             best, best_t = c, t
     k = max(5, min(20000, int(seconds / max(best_t, 1e-6))))
     dt = run(k, best)
-    return {"value": n * k / dt, "unit": "env-steps/s", "cores": best, "kind": "port",
+    # BASELINE.md plan B1: PyBullet single-process replay, only if pybullet exists on this host
+    try:
+        import subprocess
+        pyb = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pybullet_replay.py"),
+                                         "--steps", "3000"], capture_output=True, text=True,
+                                        timeout=120).stdout.strip().splitlines()[-1])
+    except Exception as exc:                       # never fabricate a number
+        pyb = {"pybullet": f"replay failed: {type(exc).__name__}"}
+    return {"pybullet_single_process": pyb, "value": n * k / dt, "unit": "env-steps/s", "cores": best, "kind": "port",
             "sample": f"{n} envs x {k} steps, float64 C oracle (oracle/pnr_oracle.c), OpenMP over envs, "
                       f"{best} threads (host advertises {os.cpu_count()}), {dt:.1f} s"}
 
@@ -124,11 +132,18 @@ def main():
     import torch.distributed as dist
     from pioneer_amd import PioneerVectorEnv, EngineConfig, _lib
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; PNR_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box) maps every rank to the
+    # devices that exist and uses gloo, because RCCL refuses two ranks on one device
+    share = os.environ.get("PNR_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     n = args.envs
     T = max(1, args.fused)
