@@ -101,15 +101,17 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
         LaneState o;     // what reward / obs see: the kinematic state, or the simulated q, qd in dynamics mode
         if (!DYN) {
             // -- action of this step (this lane's three joints) ----------------------
-            float act[kJpl] = {act_first[0], act_first[1], act_first[2]};   // t = 0: prefetched
-            if (t > 0 && valid) {
-                const float* A = P.actions + (long long)t * n * kDof;
+            // this step's action was requested one step (or one tile) ago; request the next one now,
+            // ahead of this step's obs stores (VMEM ops of a wave retire in order)
+            float act[kJpl] = {act_first[0], act_first[1], act_first[2]};
+            if (t + 1 < P.T && valid) {
+                const float* A = P.actions + (long long)(t + 1) * n * kDof;
                 if (ACT_EM) {
                     const float* a3 = A + e * kDof + kJpl * p;
-                    act[0] = a3[0]; act[1] = a3[1]; act[2] = a3[2];
+                    act_first[0] = a3[0]; act_first[1] = a3[1]; act_first[2] = a3[2];
                 } else {
 #pragma unroll
-                    for (int i = 0; i < kJpl; ++i) act[i] = A[(long long)(kJpl * p + i) * n + e];
+                    for (int i = 0; i < kJpl; ++i) act_first[i] = A[(long long)(kJpl * p + i) * n + e];
                 }
             }
             // -- act(): integrate the PREVIOUS action, then latch the new one -------
