@@ -317,8 +317,13 @@ void orc_dyn_step(const orc_dyn_params* d, const orc_params* p, orc_state* ks, o
          * not Bullet's joint velocity (which resetJointState zeroes) */
         if (d->teleport) qdf[i] = (double)ks->v[i];
     }
-    int flags = orc_reward(p, ks, qf, reward, info);
+    double info_local[4];
+    int flags = orc_reward(p, ks, qf, reward, info ? info : info_local);
     int done = flags & 1, trunc = (flags >> 1) & 1;
+    {   /* a diverged (non-finite) simulation is cut like a time-out */
+        double dist = (info ? info : info_local)[3];
+        if (!(dist == dist && fabs(dist) <= 3.0e38)) trunc = !done;
+    }
     if (done_out) *done_out = (uint8_t)done;
     if (trunc_out) *trunc_out = (uint8_t)trunc;
     if (p->auto_reset && (done || trunc)) {

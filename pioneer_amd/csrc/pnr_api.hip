@@ -151,7 +151,11 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
         const float rw = (r_pot + r_step) + r_done;                   // :165
         s.pot = pot;
         // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
-        const bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
+        bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
+        // dynamics mode: a lane whose simulation diverged (non-finite pose) is cut like a time-out, so
+        // auto-reset recovers it instead of carrying NaNs forever (kinematic mode keeps the reference's
+        // NaN-propagating behaviour)
+        if (DYN && !(q.dist == q.dist && __builtin_fabsf(q.dist) <= 3.0e38f)) trunc = !done;
 
         if (valid && p == 0) {
             const long long o = (long long)t * n + e;

@@ -136,3 +136,21 @@ def test_full_size_65536_limits_and_finite():
         assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
         assert bool(((obs[:, 0:6] >= lo) & (obs[:, 0:6] <= hi)).all())
     env.close()
+
+
+def test_diverged_lanes_are_cut_and_recovered():
+    """A lane whose simulated joints became non-finite is flagged truncated and re-drawn by auto-reset."""
+    n = 256
+    env, _ = make(n, seed=2, auto_reset=True, max_steps=0, gravity=9.81)
+    env.reset()
+    w = env.get_dyn_state()
+    bad = torch.zeros(n, dtype=torch.bool, device="cuda"); bad[::7] = True
+    w[0, bad] = float("nan")                      # q[0] of every 7th env
+    env.set_dyn_state(w)
+    obs, rew, done, trunc = env.vector_step(torch.zeros(n, 6).cuda())
+    assert torch.equal(trunc.bool(), bad) and not bool(done.any())
+    assert bool(torch.isfinite(obs).all())        # the returned obs is the fresh episode's
+    assert bool(torch.isfinite(env.get_dyn_state()[:35]).all())
+    st = env.state_dict()
+    assert (st["episode"][bad.cpu().numpy()] == 2).all() and (st["episode"][~bad.cpu().numpy()] == 1).all()
+    env.close()

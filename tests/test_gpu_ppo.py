@@ -47,3 +47,22 @@ def test_ppo_learns_to_approach_the_target():
     hist = [tr.train()["episode_reward_mean"] for _ in range(12)]
     assert hist[-1] > hist[0] + 1.0, hist
     env.close()
+
+
+def test_launch_train_mirrors_reference_signature(tmp_path):
+    """train(results_dir, checkpoint_freq, num_samples, num_workers, monitor) -> Tune-style rows
+    (pioneer_knm_train.py:14-76; columns of cli.py:32-38) + checkpoints (checkpoint_freq, at_end)."""
+    import os
+    from pioneer_amd.launch import RESULT_COLUMNS, dump, train
+    from pioneer_amd.ppo import PPOConfig
+    df = train(results_dir=str(tmp_path), checkpoint_freq=2, num_samples=2, num_workers=1, monitor=False,
+               training_iterations=3, envs_per_worker=512,
+               ppo_config=PPOConfig(rollout_fragment_length=8, num_sgd_iter=1, sgd_minibatch_size=2048))
+    assert len(df) == 2
+    for c in RESULT_COLUMNS:
+        assert c in df.columns
+    assert list(df["trial_id"]) == ["00000", "00001"] and df["training_iteration"].tolist() == [3, 3]
+    for t in ("00000", "00001"):
+        d = tmp_path / f"PPO_Pioneer-v1_{t}"
+        assert (d / "checkpoint_2.pt").exists() and (d / "checkpoint_final.pt").exists() and (d / "result.json").exists()
+    assert "episode_reward_mean" in dump(df)
