@@ -266,3 +266,62 @@ def test_errors_are_loud():
     env.close()
     with pytest.raises(RuntimeError):
         env.vector_step(torch.zeros(8, 6).cuda())
+
+
+def test_non_default_configs():
+    """Every tunable of PioneerKinematicConfig / SimulationConfig that enters the arithmetic."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig, PioneerKinematicConfig, SimulationConfig
+    n = 2048
+    pk = dict(max_v_to_r=3.5, max_a_to_v=4.0, done_distance=6.0, award_max=50.0, award_done=7.5,
+              award_potential_slope=3.0, penalty_step=0.05, target_lo=(5, -4, 1), target_hi=(12, 9, 20))
+    env = PioneerVectorEnv(n, device="cuda:0", seed=17, pioneer_config=PioneerKinematicConfig(**pk),
+                           simulation_config=SimulationConfig(timestep=1 / 120, frame_skip=7),
+                           engine_config=EngineConfig(auto_reset=True, max_episode_steps=11))
+    orc = COracle(n, seed=17, precision=ORC_DEV, auto_reset=True, max_episode_steps=11, nthreads=8,
+                  timestep=1 / 120, frame_skip=7, **pk)
+    assert env.dt == orc.dt == (1 / 120) * 7 and np.array_equal(env.v_max, orc.v_max) and np.array_equal(env.a_max, orc.a_max)
+    check_obs(env.reset().double().cpu().numpy(), orc.reset())
+    rng = np.random.RandomState(0)
+    n_done = 0
+    for t in range(40):
+        act = (rng.uniform(-1, 1, (n, 6)) * env.a_max).astype(np.float32)
+        obs, rew, done, trunc, info = env.vector_step(torch.from_numpy(act).cuda(), want_info=True)
+        oobs, orew, odone, otrunc, oinfo = orc.step(act, want_info=True)
+        border = np.abs(oinfo[:, 3] - 6.0) < POS_TOL
+        if border.any() and not np.array_equal(done.cpu().numpy(), odone):
+            pytest.skip("done flipped on a borderline env")
+        assert np.array_equal(done.cpu().numpy(), odone) and np.array_equal(trunc.cpu().numpy(), otrunc)
+        assert np.abs(rew.double().cpu().numpy() - orew).max() <= REW_TOL
+        check_obs(obs.double().cpu().numpy(), oobs)
+        n_done += int(odone.sum())
+    assert n_done > 50            # the large done_distance makes real terminal resets happen (award_done path)
+    check_state_exact(env, orc)
+    env.close()
+
+
+def test_four_million_envs_one_launch_vs_oracle_shards():
+    """Sized for 288 GB of HBM: 4 194 304 envs in one launch (2.3 GB of observations per step);
+    shards of it (first, middle, last 4096 envs) are checked against the oracle by global env id."""
+    n = 1 << 22
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    env = PioneerVectorEnv(n, device="cuda:0", seed=99, engine_config=EngineConfig(max_episode_steps=3))
+    obs = env.reset()
+    shards = [0, n // 2 - 2048, n - 4096]
+    orcs = [COracle(4096, seed=99, precision=ORC_DEV, auto_reset=True, max_episode_steps=3, env_id_offset=o, nthreads=8)
+            for o in shards]
+    for o, orc in zip(shards, orcs):
+        check_obs(obs[o:o + 4096].double().cpu().numpy(), orc.reset())
+    g = torch.Generator(device="cuda").manual_seed(5)
+    amax = torch.from_numpy(env.a_max).cuda()
+    for t in range(5):
+        act = (torch.rand(n, 6, generator=g, device="cuda") * 2 - 1) * amax
+        obs, rew, done, trunc = env.vector_step(act)
+        for o, orc in zip(shards, orcs):
+            oobs, orew, odone, otrunc = orc.step(act[o:o + 4096].cpu().numpy())
+            check_obs(obs[o:o + 4096].double().cpu().numpy(), oobs)
+            assert np.array_equal(trunc[o:o + 4096].cpu().numpy(), otrunc)
+        assert bool(torch.isfinite(obs).all())
+    w = env.get_state()
+    for o, orc in zip(shards, orcs):
+        assert np.array_equal(w[:21, o:o + 4096].cpu().numpy().view(np.uint32), orc.state_words()[:21])
+    env.close()
