@@ -1,44 +1,66 @@
 #!/usr/bin/env python3
-"""CLI mirroring the reference's cli.py:12-40 (`pioneer-train-kinem`): same options, same
-config.yaml keys, same result table; the training itself is pioneer_amd.launch.train (PPO on the
-HIP env, one process per GPU; launch under torch.distributed.run for several GPUs)."""
+"""Command line for the PPO driver.
+
+Keeps the reference CLI's surface (cli.py:12-40 there: sub-command ``pioneer-train-kinem`` with
+``-e/--experiment``, ``-c/--checkpoint-freq``, ``-n/--num-samples``, ``-w/--num-workers``,
+``--no-monitor``; ``tracking.training_root`` and a ``logging`` dictConfig read from an optional
+``config.yaml`` next to this file) on top of ``pioneer_amd.launch.train``.  For several GPUs run it
+under ``python -m torch.distributed.run --nproc-per-node N cli.py pioneer-train-kinem ...``.
+"""
+import argparse
+import logging
 import logging.config
 import os
+import sys
 
-import click
-import yaml
-
-from pioneer_amd.launch import RESULT_COLUMNS, dump, train
-
-
-@click.command(name='pioneer-train-kinem')
-@click.option('-e', '--experiment', 'experiment', required=True, type=str, help='experiment name')
-@click.option('-c', '--checkpoint-freq', 'checkpoint_freq', default=10, type=int, help='checkpoint frequency (default: 10)')
-@click.option('-n', '--num-samples', 'num_samples', default=128, type=int, help='number of search samples (default: 128)')
-@click.option('-w', '--num-workers', 'num_workers', default=1, type=int, help='number of rollout workers (default: 1)')
-@click.option('--no-monitor', 'no_monitor', is_flag=True, help='disable monitoring')
-@click.option('--iterations', 'iterations', default=1000, type=int, help='training iterations per trial (reference: 1000)')
-@click.option('--envs-per-worker', 'envs_per_worker', default=4096, type=int, help='device-resident envs per worker')
-@click.option('--mode', 'mode', default='kinematic', type=click.Choice(['kinematic', 'dynamic']))
-def cli_pioneer_train_kinem(experiment, checkpoint_freq, num_samples, num_workers, no_monitor, iterations,
-                            envs_per_worker, mode):
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'config.yaml'), 'r') as config_file:
-        config = yaml.safe_load(config_file)
-        logging.config.dictConfig(config['logging'])
-    experiment_dir = os.path.join(config['tracking']['training_root'], experiment)
-    df = train(results_dir=experiment_dir, checkpoint_freq=checkpoint_freq, num_samples=num_samples,
-               num_workers=num_workers, monitor=not no_monitor, training_iterations=iterations,
-               envs_per_worker=envs_per_worker, mode=mode)
-    if int(os.environ.get('RANK', '0')) == 0:
-        print(f'Results: \n\n{dump(df, RESULT_COLUMNS)}\n\n\n')
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULTS = {"tracking": {"training_root": os.path.join(HERE, "pioneer_runs")}, "logging": None}
 
 
-@click.group()
-def cli():
-    pass
+def load_settings() -> dict:
+    settings = {k: (dict(v) if isinstance(v, dict) else v) for k, v in DEFAULTS.items()}
+    path = os.path.join(HERE, "config.yaml")
+    if os.path.exists(path):
+        import yaml
+        with open(path) as fh:
+            user = yaml.safe_load(fh) or {}
+        settings["tracking"].update(user.get("tracking") or {})
+        settings["logging"] = user.get("logging")
+    if settings["logging"]:
+        logging.config.dictConfig(settings["logging"])
+    else:
+        logging.basicConfig(level=logging.INFO, stream=sys.stderr,
+                            format="%(asctime)s %(levelname)-8s [%(name)s] - %(message)s")
+    return settings
 
 
-cli.add_command(cli_pioneer_train_kinem)
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="cli.py")
+    sub = ap.add_subparsers(dest="command", required=True)
+    tr = sub.add_parser("pioneer-train-kinem", help="PPO on the Pioneer kinematic env (HIP engine)")
+    tr.add_argument("-e", "--experiment", required=True, help="experiment name")
+    tr.add_argument("-c", "--checkpoint-freq", type=int, default=10)
+    tr.add_argument("-n", "--num-samples", type=int, default=128, help="number of trials")
+    tr.add_argument("-w", "--num-workers", type=int, default=1, help="scales the env batch: workers x envs-per-worker")
+    tr.add_argument("--no-monitor", action="store_true")
+    tr.add_argument("--iterations", type=int, default=1000)
+    tr.add_argument("--envs-per-worker", type=int, default=4096)
+    tr.add_argument("--mode", choices=["kinematic", "dynamic"], default="kinematic")
+    return ap
 
-if __name__ == '__main__':
-    cli()
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    settings = load_settings()
+    from pioneer_amd.launch import RESULT_COLUMNS, dump, train
+    out_dir = os.path.join(settings["tracking"]["training_root"], args.experiment)
+    rows = train(results_dir=out_dir, checkpoint_freq=args.checkpoint_freq, num_samples=args.num_samples,
+                 num_workers=args.num_workers, monitor=not args.no_monitor,
+                 training_iterations=args.iterations, envs_per_worker=args.envs_per_worker, mode=args.mode)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("Results:\n\n" + dump(rows, RESULT_COLUMNS) + "\n")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
