@@ -625,7 +625,9 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     if (h->cfg.mode == PNR_MODE_DYNAMIC) {
         // two launches per step: the one-env-per-lane ABA sub-steps, then the pair kernel for
         // reward / TimeLimit / auto-reset / obs on the simulated joints
-        const dim3 gridA((unsigned)((h->n + kWave - 1) / kWave));
+        static int dyn_block = -1;
+        if (dyn_block < 0) { const char* e_ = getenv("PNR_DYN_BLOCK"); dyn_block = e_ ? atoi(e_) : kWave; if (dyn_block < 1 || dyn_block > 1024) dyn_block = kWave; }
+        const dim3 gridA((unsigned)((h->n + dyn_block - 1) / dyn_block)), blockA(dyn_block);
         for (int t = 0; t < T; ++t) {
             KParams Pt = P;
             Pt.T = 1;
@@ -634,8 +636,8 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
             Pt.reward = reward + (long long)t * h->n;
             Pt.done = done + (long long)t * h->n;
             Pt.trunc = truncated ? truncated + (long long)t * h->n : nullptr;
-            if (aem) hipLaunchKernelGGL((dyn_substeps_kernel<true>), gridA, block, 0, st, Pt, D, 0);
-            else hipLaunchKernelGGL((dyn_substeps_kernel<false>), gridA, block, 0, st, Pt, D, 0);
+            if (aem) hipLaunchKernelGGL((dyn_substeps_kernel<true>), gridA, blockA, 0, st, Pt, D, 0);
+            else hipLaunchKernelGGL((dyn_substeps_kernel<false>), gridA, blockA, 0, st, Pt, D, 0);
             if (oem) hipLaunchKernelGGL((step_kernel<true, true, true>), grid, block, 0, st, Pt, D);
             else hipLaunchKernelGGL((step_kernel<false, true, true>), grid, block, 0, st, Pt, D);
         }

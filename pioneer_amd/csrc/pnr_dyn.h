@@ -21,6 +21,11 @@
 #include "../../include/pioneer_amd.h"
 #include "pnr_device.h"
 
+// The dynamics arithmetic has no bit-exactness contract (float32 vs a float64 oracle, tolerance-
+// checked), so let a*b+c fuse here; integrate_joint (pnr_device.h) keeps its per-instruction
+// no-contract flags when it is inlined into these kernels.  Restored at the end of this header.
+#pragma clang fp contract(fast)
+
 namespace pnr {
 
 struct DynParams {
@@ -313,10 +318,10 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
 // step_kernel<..., DYN = true>.
 // ---------------------------------------------------------------------------------
 template <bool ACT_EM>
-__global__ __launch_bounds__(kWave) void dyn_substeps_kernel(const KParams P, const DynParams D, int t)
+__global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, const DynParams D, int t)
 {
     const long long n = P.n;
-    const long long e = (long long)blockIdx.x * kWave + threadIdx.x;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
 
     // kinematic state: both half-records of this env
@@ -438,3 +443,5 @@ __device__ __forceinline__ void dyn_reset_lane(const KParams& P, const DynParams
 }
 
 }  // namespace pnr
+
+#pragma clang fp contract(off)
