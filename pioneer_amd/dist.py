@@ -23,7 +23,10 @@ def init_distributed(backend: str = None, device: torch.device = None) -> Tuple[
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
+            # PNR_DIST_BACKEND=gloo: rehearsal of the N>1 path with several ranks sharing one GPU
+            # (RCCL refuses two ranks on one device)
+            backend = os.environ.get("PNR_DIST_BACKEND") or \
+                ("nccl" if (device is not None and device.type == "cuda") else "gloo")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device

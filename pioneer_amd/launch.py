@@ -39,6 +39,8 @@ def train(results_dir: str,
           log_every: int = 10):
     """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list."""
     rank, local_rank, world = pdist.world_info()
+    if os.environ.get("PNR_DIST_BACKEND") == "gloo":        # rehearsal: ranks may share the visible GPUs
+        local_rank %= max(1, torch.cuda.device_count())
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     pdist.init_distributed(device=device)
