@@ -48,7 +48,7 @@ enum pnr_status {
 /* Memory layout of a [num_envs x F] batch. */
 enum pnr_layout {
     PNR_ENV_MAJOR = 0,     /* row-major [num_envs][F] — what gym/RLlib see      */
-    PNR_FEATURE_MAJOR = 1  /* [F][num_envs] — coalesced without an LDS transpose */
+    PNR_FEATURE_MAJOR = 1  /* [F][num_envs] — feature planes (first Linear as W . X^T)      */
 };
 
 enum pnr_mode {
@@ -131,7 +131,10 @@ int pnr_get_constants(const pnr_config* cfg, pnr_constants* out);
  * num_envs independent envs on HIP device `device_id`.  `env_id_offset` is the
  * global index of local env 0: the reset RNG is keyed by (seed, global env
  * id, episode#), so trajectories do not depend on how a batch is sharded
- * across GPUs.  State is undefined until the first pnr_reset.
+ * across GPUs.  The envs hold no valid state until the first full pnr_reset (mask == NULL) or
+ * pnr_set_state: pnr_step / pnr_rollout / pnr_observe before that fail with PNR_ERR_INVALID
+ * (the reference's constructor calls reset_world() itself, pioneer_knm_env.py:69; the Python
+ * façade PioneerKinematicEnv does the same).
  */
 int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset,
                int device_id, uint64_t seed, pnr_handle* out);

@@ -333,6 +333,8 @@ struct pnr_env_s {
     float4* state;
     float* dyn;          // dynamics-mode planar words [36][n] or null
     int diag;            // PNR_DIAG env var at create time (timing-only ablations; 0 in production)
+    bool ready;          // a full reset has happened, or the state was set explicitly
+    bool kin_set, dyn_set;  // pnr_set_state / pnr_set_dyn_state seen (both needed in dynamics mode)
     char err[512];
 };
 
@@ -574,6 +576,9 @@ int pnr_reset(pnr_handle h, const uint8_t* mask, const float* joint_pos, const f
         if (h->dyn) hipLaunchKernelGGL((reset_kernel<0, OBSK, true>), grid, block, 0, st, P, D);   \
         else hipLaunchKernelGGL((reset_kernel<0, OBSK, false>), grid, block, 0, st, P, D);         \
     } while (0)
+    if (mask && !h->ready)
+        return fail(h, PNR_ERR_INVALID, "the first pnr_reset must be a full one (mask == NULL)");
+    if (!mask) h->ready = true;
     if (!obs_out) PNR_LAUNCH_RESET(0);
     else if (fm && mask) PNR_LAUNCH_RESET(1);
     else if (fm) PNR_LAUNCH_RESET(4);
@@ -588,6 +593,7 @@ int pnr_observe(pnr_handle h, float* obs_out, void* stream)
 {
     if (!h) return fail(nullptr, PNR_ERR_INVALID, "null handle");
     if (!obs_out) return fail(h, PNR_ERR_INVALID, "pnr_observe: null obs_out");
+    if (!h->ready) return fail(h, PNR_ERR_INVALID, "pnr_observe before the first pnr_reset");
     DeviceGuard g(h->device);
     KParams P = h->base;
     P.obs = obs_out;
@@ -610,6 +616,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     if (!actions || !obs || !reward || !done)
         return fail(h, PNR_ERR_INVALID, "actions, obs, reward and done must be non-null");
     if (T < 1) return fail(h, PNR_ERR_INVALID, "T must be >= 1 (got %d)", T);
+    if (!h->ready) return fail(h, PNR_ERR_INVALID, "pnr_step before the first pnr_reset (or pnr_set_state)");
     if (info && (reinterpret_cast<uintptr_t>(info) & 15u))
         return fail(h, PNR_ERR_INVALID, "info must be 16-byte aligned");
     if (h->cfg.action_layout == PNR_ENV_MAJOR && (reinterpret_cast<uintptr_t>(actions) & 7u))
@@ -688,6 +695,8 @@ int pnr_set_state(pnr_handle h, const uint32_t* words_in, void* stream)
 {
     if (!h || !words_in) return fail(h, PNR_ERR_INVALID, "pnr_set_state: null argument");
     DeviceGuard g(h->device);
+    h->kin_set = true;
+    if (!h->dyn || h->dyn_set) h->ready = true;
     hipLaunchKernelGGL(words_to_state_kernel, dim3((unsigned)((2 * h->n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, h->state, words_in, h->n);
     HIP_TRY(h, hipGetLastError());
@@ -709,6 +718,8 @@ int pnr_set_dyn_state(pnr_handle h, const float* words_in, void* stream)
     if (!h || !words_in) return fail(h, PNR_ERR_INVALID, "pnr_set_dyn_state: null argument");
     if (!h->dyn) return fail(h, PNR_ERR_UNSUPPORTED, "handle is not in dynamics mode");
     DeviceGuard g(h->device);
+    h->dyn_set = true;
+    if (h->kin_set) h->ready = true;
     HIP_TRY(h, hipMemcpyAsync(h->dyn, words_in, sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)h->n,
                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PNR_OK;

@@ -258,6 +258,10 @@ def test_single_env_facade_matches_oracle():
 def test_errors_are_loud():
     from pioneer_amd import PioneerVectorEnv, PnrError
     env = PioneerVectorEnv(8, device="cuda:0")
+    with pytest.raises(PnrError, match="before the first pnr_reset"):
+        env.vector_step(torch.zeros(8, 6).cuda())
+    with pytest.raises(PnrError, match="first pnr_reset must be a full one"):
+        env.reset(mask=torch.ones(8, dtype=torch.uint8).cuda(), out=torch.zeros(8, 137).cuda())
     env.reset()
     with pytest.raises(AssertionError):
         env.vector_step(torch.zeros(7, 6).cuda())
