@@ -138,7 +138,15 @@ class PioneerKinematicEnv:
     def render(self, mode="human"):                                        # bullet_env.py:156-185
         if mode == "human":
             return None
-        raise AssertionError(f'Render mode "{mode}" is not supported')     # no rasteriser in this engine
+        elif mode == "rgb_array":
+            from .render import render_rgb                                 # host-side stick-figure rasteriser
+            st = self._state()
+            q = st["r"][0]
+            if self._vec.engine_config.mode == "dynamic":                  # the simulated joints, not the command
+                q = self._vec.get_dyn_state()[0:6, 0].cpu().numpy()
+            return render_rgb(q, st["target"][0], self.render_config, self.config.target_radius)
+        else:
+            raise AssertionError(f'Render mode "{mode}" is not supported')
 
     @staticmethod
     def observation_to_space(observation: Observation) -> Box:             # :238-242

@@ -329,3 +329,15 @@ def test_four_million_envs_one_launch_vs_oracle_shards():
     for o, orc in zip(shards, orcs):
         assert np.array_equal(w[:21, o:o + 4096].cpu().numpy().view(np.uint32), orc.state_words()[:21])
     env.close()
+
+
+def test_render_rgb_array_through_the_facade():
+    from pioneer_amd import PioneerKinematicEnv, RenderConfig
+    env = PioneerKinematicEnv(device="cuda:0", render_config=RenderConfig(render_width=160, render_height=100, camera_distance=70))
+    env.reset()
+    assert env.render("human") is None
+    img = env.render("rgb_array")
+    assert img.shape == (100, 160, 3) and img.dtype == np.uint8 and (img != 255).any()
+    with pytest.raises(AssertionError):
+        env.render("ansi")
+    env.close()
