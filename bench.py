@@ -356,7 +356,7 @@ def main():
             out["large_batch"] = large
         if ppo_loop:
             out["ppo_loop"] = ppo_loop
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
