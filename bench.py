@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--mode", default="kinematic", choices=["kinematic", "dynamic"])
+    ap.add_argument("--randomize", action="store_true",
+                    help="dynamics mode: per-env link-mass / friction / damping draws at every reset (BASELINE config[4])")
+    ap.add_argument("--gravity", type=float, default=0.0, help="dynamics mode: gravity (reference default 0)")
     ap.add_argument("--ppo-iters", type=int, default=0,
                     help="also time N iterations of the full rollout+learn PPO loop (BASELINE config[2]/[3]) and report it as \"ppo_loop\"")
     ap.add_argument("--ppo-envs", type=int, default=16384)
@@ -147,10 +150,13 @@ def main():
 
     n = args.envs
     T = max(1, args.fused)
+    from pioneer_amd import SimulationConfig
     env = PioneerVectorEnv(n, device=dev, seed=0, env_id_offset=rank * n,
+                           simulation_config=SimulationConfig(gravity=args.gravity),
                            engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
                                                       obs_layout=args.obs_layout,
-                                                      action_layout=args.action_layout, mode=args.mode))
+                                                      action_layout=args.action_layout, mode=args.mode,
+                                                      randomize=args.randomize))
     env.reset()
 
     # synthetic inputs, resident in HBM before the timed region
@@ -343,6 +349,7 @@ def main():
             "config": {"workload": f"{n} Pioneer-arm envs per GPU, physics-only step "
                                    f"(integrate+FK+reward+TimeLimit(500)+auto-reset+obs[137]), random actions U(-a_max,a_max) resident in HBM",
                        "envs_per_gpu": n, "total_envs": n * world, "mode": args.mode,
+                       "randomize": bool(args.randomize), "gravity": args.gravity,
                        "obs_layout": args.obs_layout, "action_layout": args.action_layout,
                        "steps_per_launch": T, "hip_graph": bool(args.graph and T == 1), "obs_ring_slices": ring, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -66,3 +66,16 @@ def test_launch_train_mirrors_reference_signature(tmp_path):
         d = tmp_path / f"PPO_Pioneer-v1_{t}"
         assert (d / "checkpoint_2.pt").exists() and (d / "checkpoint_final.pt").exists() and (d / "result.json").exists()
     assert "episode_reward_mean" in dump(df)
+
+
+def test_plumbing_one_env_ppo_iteration():
+    """BASELINE config[0] shape: ONE env behind the same driver (plumbing: runs, shapes/dtypes right)."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    from pioneer_amd.ppo import PPOConfig, PPOTrainer
+    env = PioneerVectorEnv(1, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=50))
+    tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=120, num_sgd_iter=2, sgd_minibatch_size=128))
+    r1 = tr.train(); r2 = tr.train()
+    assert r2["timesteps_total"] == 240 and r1["episodes_this_iter"] == 2 and r2["episodes_total"] == 4
+    assert tr.buf["raw_obs"].shape == (120, 1, 137) and tr.buf["raw_obs"].dtype == torch.float32
+    assert tr.buf["actions"].shape == (120, 1, 6) and math.isfinite(r2["total_loss"])
+    env.close()
