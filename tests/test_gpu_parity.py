@@ -341,3 +341,29 @@ def test_render_rgb_array_through_the_facade():
     with pytest.raises(AssertionError):
         env.render("ansi")
     env.close()
+
+
+def test_vector_env_api_bits():
+    """RLlib VectorEnv-shaped helpers: reset_at, seed(), observe(), num_envs, spaces."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    n = 100
+    env = PioneerVectorEnv(n, device="cuda:0", seed=42, engine_config=EngineConfig(auto_reset=False))
+    o1 = env.vector_reset()
+    assert env.num_envs == n and o1.shape == (n, 137) and env.get_unwrapped() == []
+    assert env.action_space.shape == (6,) and env.observation_space.shape == (137,)
+    assert torch.equal(env.observe(), o1)
+    act = torch.from_numpy(np.tile(env.a_max, (n, 1))).cuda()
+    env.vector_step(act); obs, *_ = env.vector_step(act)
+    row = env.reset_at(17)
+    now = env.observe()
+    assert torch.equal(now[17], row) and row[136] == 0 and torch.equal(row[90:96], torch.zeros(6, device="cuda"))
+    keep = torch.arange(n, device="cuda") != 17
+    assert torch.equal(now[keep], obs[keep])                    # other envs untouched
+    # seed(): same seed + same episode counters -> same draws; a different seed -> different draws
+    a = PioneerVectorEnv(n, device="cuda:0", seed=1); b = PioneerVectorEnv(n, device="cuda:0", seed=2)
+    assert b.seed(1) == [1]
+    assert torch.equal(a.reset(), b.reset())
+    b.seed(3)
+    assert not torch.equal(a.reset(), b.reset())
+    for e in (env, a, b):
+        e.close()
