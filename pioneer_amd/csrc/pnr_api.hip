@@ -159,10 +159,10 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
 
         if (valid && p == 0) {
             const long long o = (long long)t * n + e;
-            P.reward[o] = rw;
-            P.done[o] = (uint8_t)done;
-            if (P.trunc) P.trunc[o] = (uint8_t)trunc;
-            if (P.info) reinterpret_cast<float4*>(P.info)[o] = make_float4(r_pot, r_step, r_done, q.dist);
+            stream_store(P.reward + o, rw);
+            stream_store(P.done + o, (uint8_t)done);
+            if (P.trunc) stream_store(P.trunc + o, (uint8_t)trunc);
+            if (P.info) stream_store(reinterpret_cast<float4*>(P.info) + o, make_float4(r_pot, r_step, r_done, q.dist));
         }
 
         // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----

@@ -397,6 +397,18 @@ struct SinkDirect {
     __device__ __forceinline__ void putt0(int f0, float v) { if (on && !p) base[(long long)f0 * stride] = v; }
 };
 
+// Streaming outputs (observations, rewards, flags) are written once and read by another kernel much
+// later: non-temporal stores keep them from displacing the state planes in L2 and were worth 8 % at
+// 65 536 envs and 31 % at 1 M envs per launch (178 -> 122 us).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(float4* dst, const float4& v)
+{
+    v4f_t x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<v4f_t*>(dst));
+}
+__device__ __forceinline__ void stream_store(float* dst, float v) { __builtin_nontemporal_store(v, dst); }
+__device__ __forceinline__ void stream_store(uint8_t* dst, uint8_t v) { __builtin_nontemporal_store(v, dst); }
+
 // Copy a wave's LDS tile (rows [0, nvalid) of 137 floats) to its contiguous
 // place in an env-major obs batch with 16-byte lane-linear stores.
 __device__ __forceinline__ void flush_tile(const float* __restrict__ lds, float* __restrict__ dst,
@@ -407,10 +419,10 @@ __device__ __forceinline__ void flush_tile(const float* __restrict__ lds, float*
         const int nvec = total >> 2;
         const float4* src4 = reinterpret_cast<const float4*>(lds);
         float4* dst4 = reinterpret_cast<float4*>(dst);
-        for (int j = lane; j < nvec; j += kWave) dst4[j] = src4[j];
-        for (int j = (nvec << 2) + lane; j < total; j += kWave) dst[j] = lds[j];
+        for (int j = lane; j < nvec; j += kWave) stream_store(dst4 + j, src4[j]);
+        for (int j = (nvec << 2) + lane; j < total; j += kWave) stream_store(dst + j, lds[j]);
     } else {
-        for (int j = lane; j < total; j += kWave) dst[j] = lds[j];
+        for (int j = lane; j < total; j += kWave) stream_store(dst + j, lds[j]);
     }
 }
 
@@ -425,13 +437,13 @@ __device__ __forceinline__ void flush_feature_tile(const float* __restrict__ lds
             const int f = f0 + sub;
             if (f < kObsDim) {
                 const float4 v = *reinterpret_cast<const float4*>(lds + f * kEnvsPerWave + col4);
-                *reinterpret_cast<float4*>(dst + (long long)f * n + col4) = v;
+                stream_store(reinterpret_cast<float4*>(dst + (long long)f * n + col4), v);
             }
         }
     } else {
         const int col = lane & (kEnvsPerWave - 1), half = lane >> 5;
         for (int f = half; f < kObsDim; f += 2)
-            if (col < nvalid) dst[(long long)f * n + col] = lds[f * kEnvsPerWave + col];
+            if (col < nvalid) stream_store(dst + (long long)f * n + col, lds[f * kEnvsPerWave + col]);
     }
 }
 
