@@ -75,11 +75,13 @@ class MeanStdFilter:
         self._dsq = torch.zeros(dim, dtype=torch.float64, device=device)
 
     def observe(self, x: torch.Tensor) -> None:
-        """Accumulate a batch [B, dim] into the pending delta."""
-        xd = x.double()
-        self._dn += xd.shape[0]
-        self._dsum += xd.sum(0)
-        self._dsq += (xd * xd).sum(0)
+        """Accumulate a batch [..., dim] into the pending delta.  Partial sums over the last-but-one
+        axis run in float32 (<= 1e-5 relative on 16 384 terms), the accumulation across them and
+        across calls in float64."""
+        x = x.reshape(-1, x.shape[-2], x.shape[-1]) if x.dim() > 2 else x.unsqueeze(0)
+        self._dn += x.shape[0] * x.shape[1]
+        self._dsum += x.sum(1).double().sum(0)
+        self._dsq += (x * x).sum(1).double().sum(0)
 
     def sync(self) -> None:
         """Merge the pending deltas of all ranks into the running statistics (Chan et al.).
@@ -154,13 +156,26 @@ class ActorCritic(nn.Module):
         mean, log_std = out[..., :self.act_dim], out[..., self.act_dim:]
         return mean, torch.clamp(log_std, -20.0, 2.0)
 
+    @staticmethod
+    def _run(net: nn.Sequential, x_pad, pad: int):
+        """First layer on a K padded to a multiple of 16 (137 -> 144): the BLAS library's kernels for an
+        unaligned K = 137 run at ~3 TFLOP/s (391 us for a 16384 x 137 x 256 GEMM); the zero columns are
+        appended to input and weight on the fly, so the parameters are the reference's."""
+        first = net[0]
+        h = nn.functional.linear(x_pad, nn.functional.pad(first.weight, (0, pad)), first.bias)
+        for layer in list(net)[1:]:
+            h = layer(h)
+        return h
+
     def forward(self, obs, amp_bf16: bool = False):
+        pad = (-obs.shape[-1]) % 16
+        x = nn.functional.pad(obs, (0, pad)) if pad else obs
         if amp_bf16 and obs.is_cuda:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                out, v = self.policy(obs), self.value(obs)
+                out, v = self._run(self.policy, x, pad), self._run(self.value, x, pad)
             out, v = out.float(), v.float()
         else:
-            out, v = self.policy(obs), self.value(obs)
+            out, v = self._run(self.policy, x, pad), self._run(self.value, x, pad)
         mean, log_std = out[..., :self.act_dim], torch.clamp(out[..., self.act_dim:], -20.0, 2.0)
         return mean, log_std, v.squeeze(-1)
 
@@ -363,8 +378,8 @@ class PPOTrainer:
         cfg, buf, model = self.cfg, self.buf, self.learner.model
         T = cfg.rollout_fragment_length
         raw = self.raw_obs
+        self.filter.observe(raw)                       # the start observation; the rest after the loop, in one pass
         for t in range(T):
-            self.filter.observe(raw)
             x = self.filter(raw)
             buf["obs"][t] = x
             mean, log_std, v = model(x, cfg.amp_bf16)
@@ -379,6 +394,10 @@ class PPOTrainer:
             raw = buf["raw_obs"][t]
             term = (buf["done"][t] | buf["trunc"][t]).float()
             self.stats.step(buf["reward"][t], term)
+        # the filter only changes at sync(), so observing the T-1 later inputs here is identical to
+        # observing them one by one inside the loop (32 small float64 column reductions per rollout)
+        if T > 1:
+            self.filter.observe(buf["raw_obs"][:T - 1])
         self.raw_obs.copy_(raw)
         last_v = model(self.filter(raw), cfg.amp_bf16)[2]
         terminals = (buf["done"] | buf["trunc"]).float()
