@@ -273,3 +273,16 @@ def test_state_words_roundtrip(oracle_built):
     oa = a.step(np.ones((33, 6), np.float32))
     ob = b.step(np.ones((33, 6), np.float32))
     assert np.array_equal(oa[0], ob[0]) and np.array_equal(oa[1], ob[1])
+
+
+def test_oracle_reproduces_its_frozen_trajectory(oracle_built):
+    """tests/golden/oracle_traj_v1.npz (made by make_oracle_traj.py from the oracle itself) bit for bit."""
+    z = np.load(os.path.join(GOLD, "oracle_traj_v1.npz"))
+    n = z["actions"].shape[1]
+    o = COracle(n, seed=int(z["seed"]), precision=ORC_REF, auto_reset=True, max_episode_steps=int(z["max_episode_steps"]))
+    assert np.array_equal(o.reset(), z["obs0"])
+    for t in range(z["actions"].shape[0]):
+        ob, r, d, tr = o.step(z["actions"][t])
+        assert np.array_equal(ob, z["obs"][t]) and np.array_equal(r, z["reward"][t])
+        assert np.array_equal(d, z["done"][t]) and np.array_equal(tr, z["truncated"][t])
+    assert np.array_equal(o.state_words(), z["state_words"])
