@@ -393,3 +393,29 @@ def test_soak_600_steps_through_timelimit():
     assert n_trunc >= n            # every env was cut at step 500 (unless it terminated earlier)
     check_state_exact(env, orc)
     env.close()
+
+
+def test_against_frozen_reference_precision_fixture():
+    """The committed golden trajectory (oracle in REFERENCE-exact precision: float64 r/target right
+    after each reset, quirk Q5) replayed on the GPU: the only differences are the float32 storage of
+    r/target at reset (<= 1 ulp on r, test_dev_vs_ref_precision_is_benign) and float32 FK/trig."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_traj_v1.npz"))
+    n = z["actions"].shape[1]
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    env = PioneerVectorEnv(n, device="cuda:0", seed=int(z["seed"]),
+                           engine_config=EngineConfig(auto_reset=True, max_episode_steps=int(z["max_episode_steps"])))
+    obs = env.reset().double().cpu().numpy()
+    assert np.abs(obs - z["obs0"]).max() < 1e-5
+    for t in range(z["actions"].shape[0]):
+        o, r, d, tr = env.vector_step(torch.from_numpy(z["actions"][t]).cuda())
+        assert np.array_equal(d.cpu().numpy(), z["done"][t]) and np.array_equal(tr.cpu().numpy(), z["truncated"][t])
+        got = o.double().cpu().numpy()
+        assert np.abs(got[:, TRIG_IDX] - z["obs"][t][:, TRIG_IDX]).max() < 1e-6
+        assert np.abs(got[:, np.r_[0:6, 90:96]] - z["obs"][t][:, np.r_[0:6, 90:96]]).max() < 5e-7      # r (<= 1 ulp), v
+        assert np.abs(got[:, POS_IDX] - z["obs"][t][:, POS_IDX]).max() < 5e-5
+        assert np.abs(r.double().cpu().numpy() - z["reward"][t]).max() < REW_TOL
+    w = env.get_state().cpu().numpy().view(np.uint32)
+    assert np.array_equal(w[22:], z["state_words"][22:])          # step_index, episode
+    assert np.array_equal(w[6:12], z["state_words"][6:12])        # v bit-exact even across precisions
+    env.close()
