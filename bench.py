@@ -51,8 +51,9 @@ def parse_args():
     ap.add_argument("--randomize", action="store_true",
                     help="dynamics mode: per-env link-mass / friction / damping draws at every reset (BASELINE config[4])")
     ap.add_argument("--gravity", type=float, default=0.0, help="dynamics mode: gravity (reference default 0)")
-    ap.add_argument("--ppo-iters", type=int, default=0,
-                    help="also time N iterations of the full rollout+learn PPO loop (BASELINE config[2]/[3]) and report it as \"ppo_loop\"")
+    ap.add_argument("--ppo-iters", type=int, default=-1,
+                    help="also time N iterations of the full rollout+learn PPO loop (BASELINE config[2]/[3]) and report it as "
+                         "\"ppo_loop\"; default: 3 at --gpus 1, 0 otherwise (pass it explicitly for the multi-GPU all-reduce leg)")
     ap.add_argument("--ppo-envs", type=int, default=16384)
     return ap.parse_args()
 
@@ -304,8 +305,8 @@ def main():
         lenv.close()
         del lobs, lacts
 
-    ppo_loop = None
-    if args.ppo_iters > 0:
+    def ppo_leg(iters):
+        """BASELINE config[2]/[3]: the full rollout + learn loop on a 16 384-env shard per GPU."""
         from pioneer_amd.ppo import PPOConfig, PPOTrainer
         penv = PioneerVectorEnv(args.ppo_envs, device=dev, seed=0, env_id_offset=rank * args.ppo_envs,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=args.mode))
@@ -314,16 +315,25 @@ def main():
         tr.train(); tr.train()                       # warm-up: eager iteration, then the graph-captured one
         barrier()
         tp = time.perf_counter()
-        rs = [tr.train() for _ in range(args.ppo_iters)]
+        rs = [tr.train() for _ in range(iters)]
         barrier()
         tp = time.perf_counter() - tp
-        steps = args.ppo_iters * 32 * args.ppo_envs * world
-        ppo_loop = {"value": steps / tp, "unit": "env-steps/s", "envs_per_gpu": args.ppo_envs, "rollout_T": 32,
-                    "num_sgd_iter": 4, "sgd_minibatch_size": 131072, "mlp_dtype": "bf16 autocast", "hip_graph_sampling": True,
-                    "iters": args.ppo_iters,
-                    "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
-                    "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
         penv.close()
+        steps = iters * 32 * args.ppo_envs * world
+        return {"value": steps / tp, "unit": "env-steps/s", "envs_per_gpu": args.ppo_envs, "rollout_T": 32,
+                "num_sgd_iter": 4, "sgd_minibatch_size": 131072, "mlp_dtype": "bf16 autocast",
+                "hip_graph_sampling": True, "iters": iters,
+                "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
+                "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
+
+    ppo_loop = None
+    if args.ppo_iters < 0:
+        args.ppo_iters = 3 if (world == 1 and args.mode == "kinematic") else 0
+    if args.ppo_iters > 0:
+        try:
+            ppo_loop = ppo_leg(args.ppo_iters)
+        except Exception as exc:      # the extra leg must never take the main result down
+            ppo_loop = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if rank == 0:
         launches = K // T
