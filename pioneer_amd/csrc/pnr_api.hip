@@ -73,6 +73,10 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
     }
     bool first_tile = true;
 
+    // the 36 constant obs entries of this lane's tile slots: once per kernel, under the load latency
+    if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K, sink); }
+    else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K, sink); }
+
     for (; tix < ntiles; tix += gridDim.x) {
     const long long tile0 = tix * kEnvsPerWave;
     const long long e = tile0 + el;
@@ -183,12 +187,12 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
         if (t > 0 || !first_tile) wave_lds_sync();   // previous flush done before the tile is rewritten
         if (OBS_EM) {
             SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-            if (!diag_noemit) emit_obs(K, o, q, p, sink);
+            if (!diag_noemit) emit_obs<false>(K, o, q, p, sink);
             wave_lds_sync();
             if (!diag_noflush) flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
         } else {
             SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-            emit_obs(K, o, q, p, sink);
+            emit_obs<false>(K, o, q, p, sink);
             wave_lds_sync();
             flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
         }

@@ -332,18 +332,30 @@ __device__ __forceinline__ void compute_pose(const LaneState& s, int p, Pose& q)
 // sink adds 3p); Sink::putt(f0, f1, v) writes tail feature f0 (lane 0) or f1
 // (lane 1).  Tail pieces (126..136): lane 0 writes pointer + target, lane 1
 // diff + distance + potential.
+// [18:54]: r_lo, cos r_lo, sin r_lo, r_hi, cos r_hi, sin r_hi — the same 36 numbers for every env
+// and every step.  With an LDS-tile sink they are written ONCE per kernel (the tile slots are never
+// overwritten by anything else), at kernel start while the state loads are in flight.
 template <class Sink>
-__device__ __forceinline__ void emit_obs(const LaneConsts& K, const LaneState& s, const Pose& q, int p, Sink& out)
+__device__ __forceinline__ void emit_obs_const(const LaneConsts& K, Sink& out)
 {
 #pragma unroll
     for (int i = 0; i < kJpl; ++i) {
-        float sn, cs;
         const float lim = K.lim[i], lc = K.lc[i], ls = K.ls[i];
-        // [0:18]  r, cos r, sin r
-        out.putj(0 + i, s.r[i]); out.putj(6 + i, q.c[i]); out.putj(12 + i, q.s[i]);
-        // [18:54] limits and their cos/sin (compile-time constants)
         out.putj(18 + i, -lim); out.putj(24 + i, lc); out.putj(30 + i, -ls);
         out.putj(36 + i, lim);  out.putj(42 + i, lc); out.putj(48 + i, ls);
+    }
+}
+
+template <bool WITH_CONST = true, class Sink>
+__device__ __forceinline__ void emit_obs(const LaneConsts& K, const LaneState& s, const Pose& q, int p, Sink& out)
+{
+    if (WITH_CONST) emit_obs_const(K, out);
+#pragma unroll
+    for (int i = 0; i < kJpl; ++i) {
+        float sn, cs;
+        const float lim = K.lim[i];
+        // [0:18]  r, cos r, sin r
+        out.putj(0 + i, s.r[i]); out.putj(6 + i, q.c[i]); out.putj(12 + i, q.s[i]);
         // [54:72] r - r_lo (float32 subtraction, :191)
         const float dlo = s.r[i] - (-lim);
         sincos_bounded(dlo, sn, cs);
