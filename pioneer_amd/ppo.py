@@ -139,6 +139,47 @@ def _mlp(sizes: Sequence[int], out_dim: int, out_gain: float) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b with a split-K weight gradient.
+
+    For the PPO minibatches dW = dy^T x has a tiny output (<= 256 x 256) and K = the minibatch size
+    (131 072): the BLAS library runs it as <= 16 workgroups on a 256-CU chip (368 us per call, a third
+    of the learn phase in rocprof).  Slicing the batch axis into S chunks turns it into one batched
+    GEMM with S x more workgroups plus a small sum."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)   # casts only when autocast is on
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy.to(weight.dtype) @ weight if ctx.needs_input_grad[0] else None
+        B = x.shape[0]
+        S = 1
+        # measured on MI355X at B = 131 072 (tools/gemm_probe.py): bf16 42 us at S = 64 (plain 360 us),
+        # fp32 95 us at S = 32 (plain 320 us)
+        for cand in ((64, 32, 16, 8, 4, 2) if dy.dtype == torch.bfloat16 else (32, 16, 8, 4, 2)):
+            if B % cand == 0 and B // cand >= 512:
+                S = cand
+                break
+        x2 = x.reshape(B, -1).to(dy.dtype)
+        if S > 1:
+            out = dy.shape[1]
+            # a bf16 batched GEMM with a single output row (the value head) takes ~11 ms of HOST time per
+            # call in the BLAS library (tools/gemm_probe2.py): pad tiny heads to 8 rows and slice
+            dyp = nn.functional.pad(dy, (0, 8 - out)) if out < 8 else dy
+            dw = torch.bmm(dyp.view(S, B // S, -1).transpose(1, 2), x2.view(S, B // S, -1)).float().sum(0)[:out]
+        else:
+            dw = (dy.t() @ x2).float()
+        db = dy.float().sum(0)
+        return dx, dw.to(weight.dtype), db.to(weight.dtype)
+
+
 class ActorCritic(nn.Module):
     """Separate policy and value MLPs [137 -> 256 -> 256 -> 12 | 1], tanh (RLlib FullyConnectedNetwork
     with vf_share_layers False).  The policy head emits the Gaussian's 6 means and 6 log-stds:
@@ -162,9 +203,9 @@ class ActorCritic(nn.Module):
         unaligned K = 137 run at ~3 TFLOP/s (391 us for a 16384 x 137 x 256 GEMM); the zero columns are
         appended to input and weight on the fly, so the parameters are the reference's."""
         first = net[0]
-        h = nn.functional.linear(x_pad, nn.functional.pad(first.weight, (0, pad)), first.bias)
+        h = _LinearSplitK.apply(x_pad, nn.functional.pad(first.weight, (0, pad)), first.bias)
         for layer in list(net)[1:]:
-            h = layer(h)
+            h = _LinearSplitK.apply(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
         return h
 
     def forward(self, obs, amp_bf16: bool = False):
@@ -259,15 +300,24 @@ class PPOLearner:
     """The learn phase alone (usable on CPU with any rollout tensors): minibatch SGD on the clipped
     surrogate + adaptive KL + clipped value loss - entropy bonus, gradients averaged over ranks."""
 
-    def __init__(self, cfg: PPOConfig, device):
+    def __init__(self, cfg: PPOConfig, device, use_graph: bool = False):
         self.cfg = cfg
         self.device = torch.device(device)
         torch.manual_seed(cfg.seed)
         self.model = ActorCritic(cfg).to(self.device)
         pdist.broadcast_module_(self.model)
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr)
+        # hipGraph capture of one minibatch update (loss -> backward -> Adam): single rank, GPU, no grad clip
+        self.use_graph = bool(use_graph) and self.device.type == "cuda" and not pdist.is_dist() and not cfg.grad_clip
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr, capturable=self.use_graph)
         self.kl_coeff = cfg.kl_coeff
         self.timesteps_total = 0
+        # loss coefficients as device scalars so a captured graph sees their current values
+        self._kl_c = torch.tensor(float(cfg.kl_coeff), device=self.device)
+        self._ent_c = torch.tensor(float(cfg.entropy_coeff_start), device=self.device)
+        self._graph = None
+        self._static = None
+        self._static_info = None
+        self._eager_updates = 0
 
     def entropy_coeff(self) -> float:
         frac = min(1.0, self.timesteps_total / max(1, self.cfg.entropy_decay_steps))
@@ -285,7 +335,7 @@ class PPOLearner:
         vf1 = (v - mb["vtarg"]) ** 2
         v_clipped = mb["values"] + torch.clamp(v - mb["values"], -cfg.vf_clip_param, cfg.vf_clip_param)
         vf = torch.maximum(vf1, (v_clipped - mb["vtarg"]) ** 2)
-        total = (-surr + self.kl_coeff * kl + cfg.vf_loss_coeff * vf - self.entropy_coeff() * ent).mean()
+        total = (-surr + self._kl_c * kl + cfg.vf_loss_coeff * vf - self._ent_c * ent).mean()
         return total, {"policy_loss": -surr.mean().detach(), "vf_loss": vf.mean().detach(),
                        "kl": kl.mean().detach(), "entropy": ent.mean().detach(), "total_loss": total.detach()}
 
@@ -302,20 +352,36 @@ class PPOLearner:
         mu = stats[0] / stats[2]
         sd = torch.sqrt(torch.clamp(stats[1] / stats[2] - mu * mu, min=1e-12))
         batch = dict(batch, adv=((adv - mu.float()) / (sd.float() + 1e-8)))
+        self._kl_c.fill_(self.kl_coeff)
+        self._ent_c.fill_(self.entropy_coeff())
         agg: Dict[str, torch.Tensor] = {}
         nmb = 0
+
+        def eager_step(mb):
+            loss, info = self.loss(mb)
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+            pdist.allreduce_mean_grads(self.model.parameters())   # one flat 0.82 MB bucket
+            if cfg.grad_clip:
+                nn.utils.clip_grad_norm_(self.model.parameters(), cfg.grad_clip)
+            self.opt.step()
+            return info
+
+        graph_ok = self.use_graph and (self._static is None or self._static["obs"].shape[0] == mbs)
         for _ in range(cfg.num_sgd_iter):
             perm = torch.randperm(B, device=adv.device, generator=generator)
             for s in range(0, B - mbs + 1, mbs):
                 idx = perm[s:s + mbs]
-                mb = {k: v[idx] for k, v in batch.items()}
-                loss, info = self.loss(mb)
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
-                pdist.allreduce_mean_grads(self.model.parameters())   # one flat 0.82 MB bucket
-                if cfg.grad_clip:
-                    nn.utils.clip_grad_norm_(self.model.parameters(), cfg.grad_clip)
-                self.opt.step()
+                if graph_ok and self._graph is None and self._eager_updates >= 3:
+                    self._capture(batch, idx)                       # after a few eager updates (warm-up)
+                if graph_ok and self._graph is not None:
+                    for k, v in batch.items():
+                        torch.index_select(v, 0, idx, out=self._static[k])
+                    self._graph.replay()
+                    info = self._static_info
+                else:
+                    info = eager_step({k: v[idx] for k, v in batch.items()})
+                    self._eager_updates += 1
                 for k, v in info.items():
                     agg[k] = agg.get(k, 0) + v
                 nmb += 1
@@ -334,6 +400,26 @@ class PPOLearner:
         return out
 
 
+def _learner_capture(self, batch, idx):
+    """Capture loss -> backward -> Adam on static minibatch buffers into one hipGraph."""
+    try:
+        self._static = {k: v[idx].clone() for k, v in batch.items()}
+        torch.cuda.synchronize(self.device)
+        self.opt.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, info = self.loss(self._static)
+            loss.backward()
+            self.opt.step()
+        self._graph, self._static_info = g, info
+    except Exception:            # capture not possible here: stay eager
+        self._graph, self._static, self.use_graph = None, None, False
+        torch.cuda.synchronize(self.device)
+
+
+PPOLearner._capture = _learner_capture
+
+
 class PPOTrainer:
     """Rollout + learn loop over a PioneerVectorEnv shard (one process per GPU).
 
@@ -346,7 +432,7 @@ class PPOTrainer:
         self.cfg = cfg or PPOConfig()
         self.device = env.device
         self.rank, _, self.world = pdist.world_info()
-        self.learner = PPOLearner(self.cfg, self.device)
+        self.learner = PPOLearner(self.cfg, self.device, use_graph=use_graph)
         self.filter = (MeanStdFilter(self.cfg.obs_dim, self.device, self.cfg.filter_clip)
                        if self.cfg.observation_filter in ("MeanStdFilter", "ConcurrentMeanStdFilter") else NoFilter())
         self.stats = EpisodeStats(env.num_envs, self.device)
