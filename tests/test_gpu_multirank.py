@@ -2,6 +2,7 @@
 sharded PPO loop — env shards by global env id, flat gradient all-reduce, obs-filter merge."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -33,9 +34,10 @@ json.dump({"rank": rank, "timesteps_total": int(row["timesteps_total"]), "episod
 def test_two_ranks_train_in_lock_step(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     env = dict(os.environ, PNR_ROOT=ROOT, PNR_OUT=str(tmp_path), PNR_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     r0 = json.load(open(tmp_path / "rank0.json")); r1 = json.load(open(tmp_path / "rank1.json"))
