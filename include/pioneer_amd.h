@@ -105,6 +105,11 @@ typedef struct pnr_config {
     double rand_damping_lo, rand_damping_hi;   /* per-joint viscous damping          */
     double ground_z;              /* contact plane height for the pointer; NaN = no plane */
     double contact_kp, contact_kd;/* penalty contact stiffness / damping  */
+    /* static box obstacle for the pointer sphere (the reference demo's create_body_box,
+     * pioneer_knm_env.py:249-255: half extents (0.5,0.5,5) at (10,5,0)); half extent <= 0 = none */
+    double obstacle_position[3];
+    double obstacle_half_extents[3];
+    double pointer_radius;        /* 0.2: the pointer's sphere (urdf:190-196) */
 } pnr_config;
 
 typedef struct pnr_env_s* pnr_handle;

@@ -189,6 +189,8 @@ class OrcDynParams(C.Structure):
         ("rand_friction_lo", C.c_double), ("rand_friction_hi", C.c_double),
         ("rand_damping_lo", C.c_double), ("rand_damping_hi", C.c_double),
         ("ground_z", C.c_double), ("contact_kp", C.c_double), ("contact_kd", C.c_double),
+        ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
+        ("pointer_radius", C.c_double),
     ]
 
 
@@ -213,7 +215,11 @@ class DynOracle(COracle):
         self.d.frame_skip = self.p.frame_skip
         for k, v in (dyn or {}).items():
             assert hasattr(self.d, k), k
-            setattr(self.d, k, v)
+            if k in ("obstacle_position", "obstacle_half_extents"):
+                for i in range(3):
+                    getattr(self.d, k)[i] = float(v[i])
+            else:
+                setattr(self.d, k, v)
         self.dstate = np.zeros(self.n, dtype=DYN_STATE_DTYPE)
         self.dstate["mass_scale"] = 1.0
 

@@ -233,6 +233,47 @@ void orc_dyn_tip(const orc_dyn_state* s, double pos[3], double vel[3])
     }
 }
 
+int orc_dyn_contact_force(const orc_dyn_params* d, const double pos[3], const double vel[3], double f[3])
+{
+    int active = 0;
+    f[0] = f[1] = f[2] = 0.0;
+    if (d->ground_z == d->ground_z) {                      /* plane z = ground_z, normal +z, pointer centre */
+        double depth = d->ground_z - pos[2];
+        if (depth > 0) {
+            double fz = d->contact_kp * depth - d->contact_kd * vel[2];
+            if (fz > 0) { f[2] += fz; active = 1; }
+        }
+    }
+    if (d->obstacle_half_extents[0] > 0 && d->obstacle_half_extents[1] > 0 && d->obstacle_half_extents[2] > 0) {
+        /* signed distance of the pointer centre to the axis-aligned box, outward normal n */
+        double q[3], o[3], n[3] = {0, 0, 0}, dd[3];
+        double out2 = 0, qmax = -1e300; int kmax = 0;
+        for (int k = 0; k < 3; k++) {
+            dd[k] = pos[k] - d->obstacle_position[k];
+            q[k] = fabs(dd[k]) - d->obstacle_half_extents[k];
+            o[k] = q[k] > 0 ? q[k] : 0.0;
+            out2 += o[k] * o[k];
+            if (q[k] > qmax) { qmax = q[k]; kmax = k; }
+        }
+        double sdf;
+        if (out2 > 0) {
+            double len = sqrt(out2);
+            sdf = len;
+            for (int k = 0; k < 3; k++) n[k] = (dd[k] < 0 ? -o[k] : o[k]) / len;
+        } else {
+            sdf = qmax;                                    /* inside: push out through the nearest face */
+            n[kmax] = dd[kmax] < 0 ? -1.0 : 1.0;
+        }
+        double depth = d->pointer_radius - sdf;
+        if (depth > 0) {
+            double vn = vel[0] * n[0] + vel[1] * n[1] + vel[2] * n[2];
+            double fn = d->contact_kp * depth - d->contact_kd * vn;
+            if (fn > 0) { for (int k = 0; k < 3; k++) f[k] += fn * n[k]; active = 1; }
+        }
+    }
+    return active;
+}
+
 void orc_dyn_params_default(orc_dyn_params* d)
 {
     memset(d, 0, sizeof(*d));
@@ -244,6 +285,9 @@ void orc_dyn_params_default(orc_dyn_params* d)
     d->rand_friction_lo = 0.0; d->rand_friction_hi = 0.1;
     d->rand_damping_lo = 0.0; d->rand_damping_hi = 0.1;
     d->ground_z = NAN; d->contact_kp = 2000.0; d->contact_kd = 50.0;
+    d->obstacle_position[0] = 10.0; d->obstacle_position[1] = 5.0; d->obstacle_position[2] = 0.0;   /* pioneer_knm_env.py:253 */
+    d->obstacle_half_extents[0] = d->obstacle_half_extents[1] = d->obstacle_half_extents[2] = 0.0;  /* disabled */
+    d->pointer_radius = 0.2;                                                                          /* urdf:193 */
 }
 
 void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state* s,
@@ -261,15 +305,10 @@ void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state
         t -= s->friction[i] * s->qd[i] / sqrt(s->qd[i] * s->qd[i] + FRICTION_EPS * FRICTION_EPS);
         tau[i] = t;
     }
-    if (d->ground_z == d->ground_z) {
+    if (d->ground_z == d->ground_z || d->obstacle_half_extents[0] > 0) {
         double pos[3], vel[3];
         orc_dyn_tip(s, pos, vel);
-        double depth = d->ground_z - pos[2];
-        if (depth > 0) {
-            double fz = d->contact_kp * depth - d->contact_kd * vel[2];
-            ftip[2] = fz > 0 ? fz : 0.0;
-            fext = ftip;
-        }
+        if (orc_dyn_contact_force(d, pos, vel, ftip)) fext = ftip;
     }
     orc_dyn_aba(s, tau, d->gravity, fext, qdd);
     for (int i = 0; i < ORC_DOF; i++) {          /* semi-implicit Euler + inelastic joint limits */

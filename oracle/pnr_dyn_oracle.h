@@ -41,6 +41,8 @@ typedef struct orc_dyn_params {
     double rand_damping_lo, rand_damping_hi;
     double ground_z;          /* NaN = no contact plane */
     double contact_kp, contact_kd;
+    double obstacle_position[3], obstacle_half_extents[3];   /* half extent <= 0: no box */
+    double pointer_radius;
 } orc_dyn_params;
 
 typedef struct orc_dyn_state {
@@ -58,6 +60,10 @@ void orc_dyn_aba(const orc_dyn_state* s, const double tau[ORC_DOF], double gravi
 
 /* kinetic energy and gravitational potential energy (for conservation tests) */
 void orc_dyn_energy(const orc_dyn_state* s, double gravity, double* kinetic, double* potential);
+
+/* penalty contact force on the pointer (world frame) from the ground plane and the box obstacle;
+ * returns 1 if any contact is active */
+int orc_dyn_contact_force(const orc_dyn_params* d, const double pos[3], const double vel[3], double f[3]);
 
 /* pointer position and linear velocity in the world frame */
 void orc_dyn_tip(const orc_dyn_state* s, double pos[3], double vel[3]);

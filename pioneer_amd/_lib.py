@@ -49,6 +49,8 @@ class PnrConfig(C.Structure):
         ("rand_friction_lo", C.c_double), ("rand_friction_hi", C.c_double),
         ("rand_damping_lo", C.c_double), ("rand_damping_hi", C.c_double),
         ("ground_z", C.c_double), ("contact_kp", C.c_double), ("contact_kd", C.c_double),
+        ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
+        ("pointer_radius", C.c_double),
     ]
 
 

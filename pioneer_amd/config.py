@@ -82,6 +82,11 @@ class EngineConfig:
     ground_z: float = float("nan")
     contact_kp: float = 2000.0
     contact_kd: float = 50.0
+    # static box obstacle for the pointer sphere (the reference demo's obstacle:1, pioneer_knm_env.py:249-255);
+    # half extents <= 0 disable it
+    obstacle_position: Tuple[float, float, float] = (10.0, 5.0, 0.0)
+    obstacle_half_extents: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    pointer_radius: float = 0.2
 
 
 _LAYOUTS = {"env_major": _lib.ENV_MAJOR, "feature_major": _lib.FEATURE_MAJOR}
@@ -121,4 +126,8 @@ def to_c_config(pioneer: PioneerKinematicConfig, sim: SimulationConfig, engine: 
     c.rand_damping_lo, c.rand_damping_hi = map(float, engine.rand_damping)
     c.ground_z = float(engine.ground_z)
     c.contact_kp, c.contact_kd = float(engine.contact_kp), float(engine.contact_kd)
+    for k in range(3):
+        c.obstacle_position[k] = float(engine.obstacle_position[k])
+        c.obstacle_half_extents[k] = float(engine.obstacle_half_extents[k])
+    c.pointer_radius = float(engine.pointer_radius)
     return c

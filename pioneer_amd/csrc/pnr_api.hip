@@ -402,6 +402,9 @@ int pnr_config_default(pnr_config* c)
     c->rand_friction_lo = 0.0; c->rand_friction_hi = 0.1;
     c->rand_damping_lo = 0.0; c->rand_damping_hi = 0.1;
     c->ground_z = NAN; c->contact_kp = 2000.0; c->contact_kd = 50.0;
+    c->obstacle_position[0] = 10.0; c->obstacle_position[1] = 5.0; c->obstacle_position[2] = 0.0;  // pioneer_knm_env.py:253
+    c->obstacle_half_extents[0] = c->obstacle_half_extents[1] = c->obstacle_half_extents[2] = 0.0; // disabled
+    c->pointer_radius = 0.2;
     return PNR_OK;
 }
 
@@ -468,6 +471,9 @@ static void fill_base(pnr_handle h)
     D.has_ground = (c.ground_z == c.ground_z) ? 1 : 0;
     D.ground_z = D.has_ground ? (float)c.ground_z : 0.f;
     D.ckp = (float)c.contact_kp; D.ckd = (float)c.contact_kd;
+    D.has_box = (c.obstacle_half_extents[0] > 0 && c.obstacle_half_extents[1] > 0 && c.obstacle_half_extents[2] > 0) ? 1 : 0;
+    for (int k = 0; k < 3; ++k) { D.box_c[k] = (float)c.obstacle_position[k]; D.box_h[k] = (float)c.obstacle_half_extents[k]; }
+    D.ptr_radius = (float)c.pointer_radius;
     D.joint_damping = (float)c.joint_damping; D.joint_friction = (float)c.joint_friction;
     D.mass_lo = c.rand_mass_lo; D.mass_span = c.rand_mass_hi - c.rand_mass_lo;
     D.fric_lo = c.rand_friction_lo; D.fric_span = c.rand_friction_hi - c.rand_friction_lo;

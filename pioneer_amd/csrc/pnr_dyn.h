@@ -37,7 +37,9 @@ struct DynParams {
     int teleport;
     int randomize;
     int has_ground;
+    int has_box;
     float ground_z, ckp, ckd;
+    float box_c[3], box_h[3], ptr_radius;   // static box obstacle for the pointer sphere
     float joint_damping, joint_friction;
     double mass_lo, mass_span, fric_lo, fric_span, damp_lo, damp_span;
 };
@@ -261,9 +263,10 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
     vel_outward<4>(v[3], c[4], s[4], qd[4], v[4]);
     vel_outward<5>(v[4], c[5], s[5], qd[5], v[5]);
 
-    // external force on the pointer (body 6 coordinates)
+    // external force on the pointer (body 6 coordinates): penalty contacts with the ground plane
+    // and the static box (the reference demo's scene extras, pioneer_knm_env.py:249-261)
     SV fext = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    if (D.has_ground) {
+    if (D.has_ground || D.has_box) {
         M3 R = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, Rn;
         V3 p = {0.f, 0.f, 0.f}, pn;
         pose_outward<0>(R, p, c[0], s[0], Rn, pn); R = Rn; p = pn;
@@ -273,13 +276,37 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
         pose_outward<4>(R, p, c[4], s[4], Rn, pn); R = Rn; p = pn;
         pose_outward<5>(R, p, c[5], s[5], Rn, pn); R = Rn; p = pn;
         const V3 t = {(float)kTipX, (float)kTipY, (float)kTipZ};
-        const float ztip = p.z + dot(R.r2, t);
+        const V3 tip = p + mul(R, t);                         // world position of the pointer
         const V3 vb = v[5].l + cross(v[5].a, t);
-        const float vz = dot(R.r2, vb);
-        const float depth = D.ground_z - ztip;
-        float fz = D.ckp * depth - D.ckd * vz;
-        fz = (depth > 0.f && fz > 0.f) ? fz : 0.f;
-        const V3 fb = fz * R.r2;                  // R^T (0,0,fz)
+        const V3 vw = mul(R, vb);                             // world velocity of the pointer
+        V3 F = {0.f, 0.f, 0.f};
+        if (D.has_ground) {
+            const float depth = D.ground_z - tip.z;
+            const float fz = D.ckp * depth - D.ckd * vw.z;
+            if (depth > 0.f && fz > 0.f) F.z += fz;
+        }
+        if (D.has_box) {
+            // signed distance of the pointer centre to the axis-aligned box and its outward normal
+            const V3 dd = {tip.x - D.box_c[0], tip.y - D.box_c[1], tip.z - D.box_c[2]};
+            const V3 q = {fabsf(dd.x) - D.box_h[0], fabsf(dd.y) - D.box_h[1], fabsf(dd.z) - D.box_h[2]};
+            const V3 o = {fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f)};
+            const float out2 = dot(o, o);
+            V3 nrm; float sdf;
+            if (out2 > 0.f) {
+                const float len = sqrtf(out2);
+                sdf = len;
+                nrm = {(dd.x < 0.f ? -o.x : o.x) / len, (dd.y < 0.f ? -o.y : o.y) / len, (dd.z < 0.f ? -o.z : o.z) / len};
+            } else {                                          // inside: out through the nearest face
+                const int km = (q.x >= q.y && q.x >= q.z) ? 0 : (q.y >= q.z ? 1 : 2);
+                sdf = comp(q, km);
+                nrm = {km == 0 ? (dd.x < 0.f ? -1.f : 1.f) : 0.f, km == 1 ? (dd.y < 0.f ? -1.f : 1.f) : 0.f,
+                       km == 2 ? (dd.z < 0.f ? -1.f : 1.f) : 0.f};
+            }
+            const float depth = D.ptr_radius - sdf;
+            const float fn = D.ckp * depth - D.ckd * dot(vw, nrm);
+            if (depth > 0.f && fn > 0.f) F = F + fn * nrm;
+        }
+        const V3 fb = mulT(R, F);                             // R^T F
         fext.a = cross(t, fb);
         fext.l = fb;
     }

@@ -183,3 +183,31 @@ def test_randomisation_draws(oracle_built):
     o2 = DynOracle(1024, seed=8, env_id_offset=1024, dyn=dict(randomize=1))
     o2.reset(want_obs=False)
     assert np.array_equal(o2.dstate["mass_scale"], ms[1024:])
+
+
+def test_box_contact_force_geometry(oracle_built):
+    """Penalty force of the static box (the reference demo's obstacle:1 geometry) on the pointer sphere."""
+    import ctypes as C
+    o = DynOracle(1, dyn=dict(obstacle_position=(10.0, 5.0, 0.0), obstacle_half_extents=(0.5, 0.5, 5.0),
+                              pointer_radius=0.2, contact_kp=2000.0, contact_kd=50.0))
+    o.lib.orc_dyn_contact_force.restype = C.c_int
+
+    def force(pos, vel=(0, 0, 0)):
+        p = np.array(pos, dtype=np.float64); v = np.array(vel, dtype=np.float64); f = np.zeros(3)
+        act = o.lib.orc_dyn_contact_force(C.byref(o.d), p.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p),
+                                          f.ctypes.data_as(C.c_void_p))
+        return act, f
+    assert force((12.0, 5.0, 1.0))[0] == 0                                     # clear of the box
+    act, f = force((10.6, 5.0, 1.0))                                           # 0.1 outside the +x face: depth 0.1
+    assert act == 1 and np.allclose(f, [2000.0 * 0.1, 0, 0])
+    act, f = force((10.6, 5.0, 1.0), vel=(-1.0, 0, 0))                         # approaching: damping adds
+    assert np.allclose(f, [2000.0 * 0.1 + 50.0, 0, 0])
+    act, f = force((10.6, 5.0, 1.0), vel=(10.0, 0, 0))                         # separating fast: no pull
+    assert act == 0 and not f.any()
+    act, f = force((10.0, 5.0, 5.1))                                           # above the top face
+    assert np.allclose(f, [0, 0, 2000.0 * 0.1])
+    act, f = force((10.4, 5.0, 1.0))                                           # inside: out through the nearest (+x) face
+    assert f[0] > 0 and f[1] == 0 and f[2] == 0 and abs(f[0] - 2000.0 * (0.2 + 0.1)) < 1e-9
+    k = 0.1 / np.sqrt(2)
+    act, f = force((10.5 + k, 5.5 + k, 1.0))                                   # off an edge: normal along the diagonal
+    assert act == 1 and abs(f[0] - f[1]) < 1e-9 and f[2] == 0 and abs(np.linalg.norm(f) - 2000.0 * 0.1) < 1e-6

@@ -25,7 +25,10 @@ def make(n, seed=0, auto_reset=False, max_steps=0, layout="env_major", gravity=0
                        teleport=bool(ek.pop("teleport", 0)), randomize=bool(ek.pop("randomize", 0)),
                        joint_damping=ek.pop("joint_damping", 0.0), joint_friction=ek.pop("joint_friction", 0.0),
                        ground_z=ek.pop("ground_z", float("nan")),
-                       contact_kp=ek.pop("contact_kp", 2000.0), contact_kd=ek.pop("contact_kd", 50.0))
+                       contact_kp=ek.pop("contact_kp", 2000.0), contact_kd=ek.pop("contact_kd", 50.0),
+                       obstacle_position=ek.pop("obstacle_position", (10.0, 5.0, 0.0)),
+                       obstacle_half_extents=ek.pop("obstacle_half_extents", (0.0, 0.0, 0.0)),
+                       pointer_radius=ek.pop("pointer_radius", 0.2))
     assert not ek
     env = PioneerVectorEnv(n, device="cuda:0", seed=seed, simulation_config=SimulationConfig(gravity=gravity),
                            engine_config=eng)
@@ -58,7 +61,7 @@ def test_teleport_zero_gravity_equals_kinematic_kernel():
     kin.close(); dyn.close()
 
 
-@pytest.mark.parametrize("scenario", ["pd", "gravity_friction", "randomized", "ground", "torque_limited"])
+@pytest.mark.parametrize("scenario", ["pd", "gravity_friction", "randomized", "ground", "torque_limited", "box", "box_and_ground"])
 def test_single_step_parity_resynced(scenario):
     cfg = {
         "pd": dict(),
@@ -66,6 +69,10 @@ def test_single_step_parity_resynced(scenario):
         "randomized": dict(gravity=9.81, randomize=1),
         "ground": dict(gravity=9.81, ground_z=8.0),
         "torque_limited": dict(gravity=3.0, torque_limit=500.0),
+        # a large block under the target zone so that many randomly posed pointers touch or penetrate it
+        "box": dict(gravity=9.81, obstacle_position=(18.0, 0.0, 0.0), obstacle_half_extents=(6.0, 8.0, 5.0)),
+        "box_and_ground": dict(gravity=9.81, ground_z=2.0, obstacle_position=(10.0, 5.0, 0.0),
+                               obstacle_half_extents=(0.5, 0.5, 5.0), pointer_radius=1.5),
     }[scenario]
     n = 2048
     env, orc = make(n, seed=5, **cfg)
@@ -79,12 +86,20 @@ def test_single_step_parity_resynced(scenario):
         obs, rew, done, trunc = env.vector_step(torch.from_numpy(act).cuda())
         oobs, orew, odone, otrunc = orc.step(act)
         w = env.get_dyn_state().cpu().numpy().astype(np.float64)
-        assert np.abs(w[0:6].T - orc.dstate["q"]).max() <= Q_TOL
-        assert np.abs(w[6:12].T - orc.dstate["qd"]).max() <= QD_TOL
+        eq = np.abs(w[0:6].T - orc.dstate["q"]).max(1); eqd = np.abs(w[6:12].T - orc.dstate["qd"]).max(1)
         o = obs.double().cpu().numpy()
-        assert np.abs(o[:, 0:6] - oobs[:, 0:6]).max() <= Q_TOL
-        assert np.abs(o[:, 126:129] - oobs[:, 126:129]).max() <= 1e-3      # pointer: 30-unit arm x 2e-5 rad
-        assert np.abs(o[:, 90:96] - oobs[:, 90:96]).max() <= QD_TOL
+        if scenario.startswith("box"):
+            # the nearest-face normal of a box is discontinuous on its medial axis and the penalty force
+            # switches on at depth 0: an env sitting within float32 noise of either may legitimately take
+            # the other branch for one sub-step.  Require all but 0.5 % of the envs within tolerance and
+            # bound the outliers.
+            ok = (eq <= Q_TOL) & (eqd <= QD_TOL)
+            assert ok.mean() >= 0.995 and eq.max() < 5e-3 and eqd.max() < 0.5
+        else:
+            assert eq.max() <= Q_TOL and eqd.max() <= QD_TOL
+            assert np.abs(o[:, 0:6] - oobs[:, 0:6]).max() <= Q_TOL
+            assert np.abs(o[:, 126:129] - oobs[:, 126:129]).max() <= 1e-3      # pointer: 30-unit arm x 2e-5 rad
+            assert np.abs(o[:, 90:96] - oobs[:, 90:96]).max() <= QD_TOL
         # the kinematic command state stays bit-exact
         assert np.array_equal(env.get_state().cpu().numpy().view(np.uint32)[:21], orc.state_words()[:21])
     st = env.get_dyn_state().cpu().numpy()
