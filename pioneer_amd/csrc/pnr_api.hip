@@ -653,8 +653,12 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
             Pt.reward = reward + (long long)t * h->n;
             Pt.done = done + (long long)t * h->n;
             Pt.trunc = truncated ? truncated + (long long)t * h->n : nullptr;
-            if (aem) hipLaunchKernelGGL((dyn_substeps_kernel<true>), gridA, blockA, 0, st, Pt, D, 0);
-            else hipLaunchKernelGGL((dyn_substeps_kernel<false>), gridA, blockA, 0, st, Pt, D, 0);
+            // link scales differ from 1 only under randomisation (or after pnr_set_dyn_state, which marks it)
+            const bool rnd = h->cfg.randomize || h->dyn_set;
+            if (aem && rnd) hipLaunchKernelGGL((dyn_substeps_kernel<true, true>), gridA, blockA, 0, st, Pt, D, 0);
+            else if (aem) hipLaunchKernelGGL((dyn_substeps_kernel<true, false>), gridA, blockA, 0, st, Pt, D, 0);
+            else if (rnd) hipLaunchKernelGGL((dyn_substeps_kernel<false, true>), gridA, blockA, 0, st, Pt, D, 0);
+            else hipLaunchKernelGGL((dyn_substeps_kernel<false, false>), gridA, blockA, 0, st, Pt, D, 0);
             if (oem) hipLaunchKernelGGL((step_kernel<true, true, true>), grid, block, 0, st, Pt, D);
             else hipLaunchKernelGGL((step_kernel<false, true, true>), grid, block, 0, st, Pt, D);
         }

@@ -344,7 +344,9 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
 // sub-steps of ABA + PD.  One env per lane.  Leaves step_index / reward / obs to
 // step_kernel<..., DYN = true>.
 // ---------------------------------------------------------------------------------
-template <bool ACT_EM>
+// RAND = per-env link scales (domain randomisation): loaded from the dyn words; otherwise every scale
+// is 1 and the model folds into literals.
+template <bool ACT_EM, bool RAND>
 __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, const DynParams D, int t)
 {
     const long long n = P.n;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
         fric[i] = D.dyn[(long long)(23 + i) * n + e]; damp[i] = D.dyn[(long long)(29 + i) * n + e];
     }
 #pragma unroll
-    for (int l = 0; l < kNumLinks; ++l) sc[l] = D.dyn[(long long)(12 + l) * n + e];
+    for (int l = 0; l < kNumLinks; ++l) sc[l] = RAND ? D.dyn[(long long)(12 + l) * n + e] : 1.0f;
     DynModel M;
     build_model(sc, M);
 
