@@ -252,34 +252,37 @@ def compute_gae(rewards, values, last_value, terminals, gamma, lam):
 
 
 class EpisodeStats:
-    """episode_reward_{max,min,mean}, episode_len_mean, episodes_total (cli.py:32-38), on device."""
+    """episode_reward_{max,min,mean}, episode_len_mean, episodes_total (cli.py:32-38), on device.
+
+    Every tensor is updated strictly IN PLACE: the sampling loop may be replayed from a captured
+    hipGraph, which keeps reading and writing the buffers that existed at capture time."""
 
     def __init__(self, n, device):
         self.ret = torch.zeros(n, device=device)
         self.len = torch.zeros(n, device=device)
         self.total = 0
-        self._reset_window(device)
-
-    def _reset_window(self, device=None):
-        device = device or self.ret.device
         self.w_sum = torch.zeros((), dtype=torch.float64, device=device)
         self.w_len = torch.zeros((), dtype=torch.float64, device=device)
         self.w_cnt = torch.zeros((), dtype=torch.float64, device=device)
         self.w_max = torch.full((), -float("inf"), device=device)
         self.w_min = torch.full((), float("inf"), device=device)
 
+    def _reset_window(self):
+        self.w_sum.zero_(); self.w_len.zero_(); self.w_cnt.zero_()
+        self.w_max.fill_(-float("inf")); self.w_min.fill_(float("inf"))
+
     def step(self, reward, terminal):
-        self.ret += reward
-        self.len += 1
+        self.ret.add_(reward)
+        self.len.add_(1.0)
         m = terminal > 0
-        cnt = m.sum()
-        self.w_cnt += cnt
-        self.w_sum += torch.where(m, self.ret, torch.zeros_like(self.ret)).sum().double()
-        self.w_len += torch.where(m, self.len, torch.zeros_like(self.len)).sum().double()
-        self.w_max = torch.maximum(self.w_max, torch.where(m, self.ret, torch.full_like(self.ret, -float("inf"))).max())
-        self.w_min = torch.minimum(self.w_min, torch.where(m, self.ret, torch.full_like(self.ret, float("inf"))).min())
-        self.ret = torch.where(m, torch.zeros_like(self.ret), self.ret)
-        self.len = torch.where(m, torch.zeros_like(self.len), self.len)
+        self.w_cnt.add_(m.sum())
+        self.w_sum.add_(torch.where(m, self.ret, torch.zeros_like(self.ret)).sum().double())
+        self.w_len.add_(torch.where(m, self.len, torch.zeros_like(self.len)).sum().double())
+        self.w_max.copy_(torch.maximum(self.w_max, torch.where(m, self.ret, torch.full_like(self.ret, -float("inf"))).max()))
+        self.w_min.copy_(torch.minimum(self.w_min, torch.where(m, self.ret, torch.full_like(self.ret, float("inf"))).min()))
+        keep = (~m).to(self.ret.dtype)
+        self.ret.mul_(keep)
+        self.len.mul_(keep)
 
     def summarize(self) -> Dict[str, float]:
         packed = torch.stack([self.w_sum, self.w_len, self.w_cnt])

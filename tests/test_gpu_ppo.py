@@ -102,3 +102,27 @@ def test_graph_captured_learner_matches_eager():
     (w0, i0), (w1, i1) = outs
     assert torch.allclose(w0, w1, atol=2e-5, rtol=1e-4)
     assert abs(i0["total_loss"] - i1["total_loss"]) < 1e-3 and abs(i0["kl"] - i1["kl"]) < 1e-4
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_episode_statistics_exact_under_graph_replay(use_graph):
+    """With TimeLimit(10) and T = 20 every env finishes exactly two 10-step episodes per iteration;
+    the device-side statistics must say so in eager mode AND when the sampling loop is replayed from a
+    captured hipGraph (state carried across replays has to be updated in place)."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    from pioneer_amd.ppo import PPOConfig, PPOTrainer
+    n = 1024
+    env = PioneerVectorEnv(n, device="cuda:0", seed=3, engine_config=EngineConfig(max_episode_steps=10))
+    tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=20, num_sgd_iter=1, sgd_minibatch_size=4096, lr=1e-5),
+                    use_graph=use_graph)
+    for it in range(1, 6):
+        r = tr.train()
+        early = int((tr.buf["done"] > 0).sum())                       # terminal successes end an episode early
+        assert r["episodes_this_iter"] >= 2 * n and r["episodes_total"] >= 2 * n * it
+        if early == 0:
+            assert r["episodes_this_iter"] == 2 * n and r["episode_len_mean"] == 10.0
+        assert math.isfinite(r["episode_reward_mean"]) and r["episode_reward_min"] <= r["episode_reward_mean"] <= r["episode_reward_max"]
+        # the mean return of a 10-step episode is bounded by the potential scale
+        assert -5.0 < r["episode_reward_mean"] < 100.0
+    assert (tr._graph is not None) == use_graph
+    env.close()

@@ -1,0 +1,20 @@
+"""Short PPO run printing the learning curve (evidence that the stack trains the reach task)."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pioneer_amd import PioneerVectorEnv, EngineConfig
+from pioneer_amd.ppo import PPOConfig, PPOTrainer
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500))
+cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=131072, lr=3e-4, amp_bf16=True,
+                entropy_coeff_start=3e-3, entropy_decay_steps=100_000_000, seed=0)
+tr = PPOTrainer(env, cfg, use_graph=True)
+t0 = time.time(); rows = []
+for it in range(1, iters + 1):
+    r = tr.train()
+    if it % 25 == 0 or it == 1:
+        row = {"iter": it, "timesteps_M": round(r["timesteps_total"] / 1e6, 1), "reward_mean": round(r["episode_reward_mean"], 2),
+               "len_mean": round(r["episode_len_mean"], 1), "episodes": r["episodes_total"], "wall_s": round(time.time() - t0, 1)}
+        rows.append(row); print(json.dumps(row), flush=True)
+env.close()
