@@ -7,9 +7,14 @@
 // instruction.  Observations are staged through a 17.5 KB LDS tile and leave as
 // 16-byte stores: env-major rows of a wave are one contiguous 17.5 KB span;
 // feature-major columns leave as 128-B segments, eight features per
-// instruction.  Envs never interact, so there is no cross-workgroup traffic and
-// block -> XCD placement only matters for L2 residency of the state planes
-// (block b touches the same lines every launch).
+// instruction, as non-temporal stores (write-once streaming data must not churn
+// the L2s that hold the state planes).  The grid is persistent (<= 2 048
+// one-wave workgroups striding over 32-env tiles, next tile prefetched ahead of
+// the current tile's stores: a wave's VMEM operations retire in order), and the
+// LDS hand-off inside the single-wave workgroup is a compiler-only barrier.
+// Envs never interact, so there is no cross-workgroup traffic and block -> XCD
+// placement only matters for L2 residency of the state planes (block b touches
+// the same lines every launch).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
