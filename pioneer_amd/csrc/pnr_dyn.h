@@ -104,6 +104,35 @@ __device__ __forceinline__ M3 rot_block(const M3& m, float c, float s)
     return {rot<AXn>(rm.r0, c, s), rot<AXn>(rm.r1, c, s), rot<AXn>(rm.r2, c, s)};                   // (R M) R^T: rows times R^T
 }
 
+// R S R^T for a SYMMETRIC S: six unique entries.  With (a, b) the two coordinates the rotation mixes
+// (v_a' = c v_a - s v_b, v_b' = s v_a + c v_b) and k the axis:
+//   S'aa = c^2 Saa - 2cs Sab + s^2 Sbb     S'bb = s^2 Saa + 2cs Sab + c^2 Sbb
+//   S'ab = cs (Saa - Sbb) + (c^2 - s^2) Sab  S'ak = c Sak - s Sbk   S'bk = s Sak + c Sbk   S'kk = Skk
+template <int AXn>
+__device__ __forceinline__ M3 rot_sym(const M3& m, float c, float s)
+{
+    constexpr int a = (AXn + 1) % 3, b = (AXn + 2) % 3, k = AXn;
+    const float Saa = comp(row(m, a), a), Sbb = comp(row(m, b), b), Sab = comp(row(m, a), b);
+    const float Sak = comp(row(m, a), k), Sbk = comp(row(m, b), k), Skk = comp(row(m, k), k);
+    const float cc = c * c, ss = s * s, cs = c * s;
+    const float naa = cc * Saa - 2.f * cs * Sab + ss * Sbb;
+    const float nbb = ss * Saa + 2.f * cs * Sab + cc * Sbb;
+    const float nab = cs * (Saa - Sbb) + (cc - ss) * Sab;
+    const float nak = c * Sak - s * Sbk, nbk = s * Sak + c * Sbk;
+    float e[3][3];
+    e[a][a] = naa; e[b][b] = nbb; e[k][k] = Skk;
+    e[a][b] = e[b][a] = nab; e[a][k] = e[k][a] = nak; e[b][k] = e[k][b] = nbk;
+    return {{e[0][0], e[0][1], e[0][2]}, {e[1][0], e[1][1], e[1][2]}, {e[2][0], e[2][1], e[2][2]}};
+}
+
+// a a^T scaled: symmetric, six products
+__device__ __forceinline__ M3 outer_sym(float k, V3 a)
+{
+    const float xx = k * a.x * a.x, yy = k * a.y * a.y, zz = k * a.z * a.z;
+    const float xy = k * a.x * a.y, xz = k * a.x * a.z, yz = k * a.y * a.z;
+    return {{xx, xy, xz}, {xy, yy, yz}, {xz, yz, zz}};
+}
+
 // spatial (articulated) inertia [[A, B], [B^T, C]] acting on [w; v]: n = A w + B v, f = B^T w + C v
 struct SI { M3 A, B, C; };
 struct SV { V3 a, l; };   // spatial vector: angular part, linear part
@@ -163,9 +192,9 @@ __device__ __forceinline__ void aba_inward(const SI& IA, const SV& pA, const SV&
     const float invD = 1.0f / out.D;
     // Ia = IA - U U^T / D
     SI Ia;
-    Ia.A = IA.A - outer(invD * out.Ua, out.Ua);
+    Ia.A = IA.A - outer_sym(invD, out.Ua);
     Ia.B = IA.B - outer(invD * out.Ua, out.Ul);
-    Ia.C = IA.C - outer(invD * out.Ul, out.Ul);
+    Ia.C = IA.C - outer_sym(invD, out.Ul);
     // c = v x (S qd)
     V3 ek = {k == 0 ? qdJ : 0.f, k == 1 ? qdJ : 0.f, k == 2 ? qdJ : 0.f};
     const V3 ca = cross(vJ.a, ek), cl = cross(vJ.l, ek);
@@ -177,7 +206,7 @@ __device__ __forceinline__ void aba_inward(const SI& IA, const SV& pA, const SV&
     // rotate into the parent's orientation, then shift to the parent's origin:
     //   C_p = C', B_p = B' + rx C', A_p = A' - P - P^T - (rx C') rx  with P = B' rx
     constexpr Axis AXJ = kJoints[J].axis;
-    const M3 A1 = rot_block<(int)AXJ>(Ia.A, cJ, sJ), B1 = rot_block<(int)AXJ>(Ia.B, cJ, sJ), C1 = rot_block<(int)AXJ>(Ia.C, cJ, sJ);
+    const M3 A1 = rot_sym<(int)AXJ>(Ia.A, cJ, sJ), B1 = rot_block<(int)AXJ>(Ia.B, cJ, sJ), C1 = rot_sym<(int)AXJ>(Ia.C, cJ, sJ);
     const M3 T = rx_mul<J>(C1);
     const M3 P = mul_rx<J>(B1);
     const M3 Q = mul_rx<J>(T);
