@@ -46,6 +46,13 @@ struct DynParams {
 
 constexpr float kFrictionEps = 0.05f;   // smooth sign(qd) = qd / sqrt(qd^2 + eps^2)
 
+// 1/x: hardware reciprocal (1 ulp) + one Newton step, instead of the ~10-instruction IEEE division
+__device__ __forceinline__ float fast_rcp(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return r * (2.0f - x * r);
+}
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -189,7 +196,7 @@ __device__ __forceinline__ void aba_inward(const SI& IA, const SV& pA, const SV&
     out.D = comp(out.Ua, k);
     out.u = tauJ - comp(pA.a, k);
     if (J == 0) return;
-    const float invD = 1.0f / out.D;
+    const float invD = fast_rcp(out.D);
     // Ia = IA - U U^T / D
     SI Ia;
     Ia.A = IA.A - outer_sym(invD, out.Ua);
@@ -259,7 +266,7 @@ __device__ __forceinline__ void acc_outward(const SV& ap, const SV& vJ, float c,
     V3 ek = {AXJ == 0 ? qd : 0.f, AXJ == 1 ? qd : 0.f, AXJ == 2 ? qd : 0.f};
     a.a = a.a + cross(vJ.a, ek);
     a.l = a.l + cross(vJ.l, ek);
-    qdd = (b.u - dot(b.Ua, a.a) - dot(b.Ul, a.l)) / b.D;
+    qdd = (b.u - dot(b.Ua, a.a) - dot(b.Ul, a.l)) * fast_rcp(b.D);
     add_comp(a.a, AXJ, qdd);
 }
 
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
                 if (D.tau_max > 0.f) tq = fminf(fmaxf(tq, -D.tau_max), D.tau_max);
             }
             tq -= damp[i] * qd[i];
-            tq -= fric[i] * qd[i] / sqrtf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
+            tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
             tau[i] = tq;
         }
         aba(D, M, q, qd, tau, qdd);
