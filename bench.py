@@ -7,7 +7,11 @@ the whole env batch of a rank, with synthetic actions already resident in HBM.
 N=1 workload = the configuration BASELINE.json's metric is quoted on: 65 536
 Pioneer-arm envs on one GPU.  For N>1 every rank steps its own 65 536-env shard
 (global env ids rank*65536..; no data-path collective — envs are independent),
-so scaling is "weak".  Launch for N>1:
+so scaling is "weak".  Extra legs in the same JSON line (never part of `value`): "fused_rollout"
+(pnr_rollout, T steps per launch), "large_batch" (262 144 envs per launch), at N>1 "strong_scaling"
+(65 536 envs IN TOTAL sharded over the ranks) and "ppo_loop" (BASELINE config[2] at N=1, config[3] at
+N>1: the full rollout+learn loop with the gradient all-reduce over RCCL), "cpu_baseline" at N=1.
+Launch for N>1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 Rank 0 prints ONE JSON line.
@@ -42,6 +46,8 @@ def parse_args():
     ap.add_argument("--ring", type=int, default=32, help="obs ring depth (rollout-buffer slices)")
     ap.add_argument("--large-envs", type=int, default=262144,
                     help="also time pnr_step on this many envs per GPU and report it as \"large_batch\" (0 = skip)")
+    ap.add_argument("--strong-total", type=int, default=65536,
+                    help="N>1: also time this many envs IN TOTAL sharded over the ranks, reported as \"strong_scaling\" (0 = skip)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the per-step launches from a hipGraph")
     ap.add_argument("--fused-leg", type=int, default=32,
                     help="also report the fused pnr_rollout rate with this many steps per launch (0 = skip)")
@@ -53,8 +59,10 @@ def parse_args():
     ap.add_argument("--gravity", type=float, default=0.0, help="dynamics mode: gravity (reference default 0)")
     ap.add_argument("--ppo-iters", type=int, default=-1,
                     help="also time N iterations of the full rollout+learn PPO loop (BASELINE config[2]/[3]) and report it as "
-                         "\"ppo_loop\"; default: 3 at --gpus 1, 0 otherwise (pass it explicitly for the multi-GPU all-reduce leg)")
-    ap.add_argument("--ppo-envs", type=int, default=16384)
+                         "\"ppo_loop\"; default 3 (0 in dynamics mode); at N>1 the gradients are all-reduced over RCCL")
+    ap.add_argument("--ppo-envs", type=int, default=0,
+                    help="TOTAL envs of the ppo_loop leg (0: 16 384 at N=1 = config[2]; 65 536 sharded over the ranks at N>1 = config[3])")
+    ap.add_argument("--ppo-timeout", type=float, default=240.0)
     return ap.parse_args()
 
 
@@ -135,6 +143,7 @@ def main():
     import torch
     import torch.distributed as dist
     from pioneer_amd import PioneerVectorEnv, EngineConfig, _lib
+    from pioneer_amd import dist as pdist
 
     # one process per GPU; PNR_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box) maps every rank to the
     # devices that exist and uses gloo, because RCCL refuses two ranks on one device
@@ -269,15 +278,14 @@ def main():
                  "frac": fb / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  "note": "pnr_rollout: same kernel, T steps per launch with open-loop actions; state stays in registers"}
 
-    # the same kernel on a larger batch per launch (amortises the ~3.5 us launch + first-load floor)
-    large = None
-    if T == 1 and args.large_envs > n and args.mode == "kinematic":
-        nl = args.large_envs
-        lenv = PioneerVectorEnv(nl, device=dev, seed=0, env_id_offset=world * n + rank * nl,
+    def side_leg(nl, id_off, k, warm, note):
+        """pnr_step on a separate env batch of nl envs per GPU (same kernel as `value`): wall time is the
+        max over ranks between barriers, avg_launch_ms is rank 0's HIP-event timing."""
+        lenv = PioneerVectorEnv(nl, device=dev, seed=0, env_id_offset=id_off,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
                                                            obs_layout=args.obs_layout, action_layout=args.action_layout))
         lenv.reset()
-        lring = 8
+        lring = 8 if nl >= 131072 else 32
         lacts = (torch.rand((4,) + tuple(lenv.action_shape), generator=g, device=dev) * 2 - 1) * \
             (amax if args.action_layout == "env_major" else amax[:, None])
         lobs = torch.empty((lring,) + tuple(lenv.obs_shape), dtype=torch.float32, device=dev)
@@ -285,32 +293,60 @@ def main():
         ldone = torch.empty((lring, nl), dtype=torch.uint8, device=dev)
         ltr = torch.empty((lring, nl), dtype=torch.uint8, device=dev)
         lh = lenv._h
+        lcalls = [(P(lacts, i % 4), P(lobs, i % lring), P(lrew, i % lring), P(ldone, i % lring), P(ltr, i % lring))
+                  for i in range(lring)]
 
-        def lrun(k):
-            for i in range(k):
-                rc = lib.pnr_step(lh, P(lacts, i % 4), P(lobs, i % lring), P(lrew, i % lring), P(ldone, i % lring),
-                                  P(ltr, i % lring), None, sp)
+        def lrun(kk):
+            for i in range(kk):
+                a, o, r, d, tr = lcalls[i % lring]
+                rc = lib.pnr_step(lh, a, o, r, d, tr, None, sp)
                 if rc:
                     _lib.check(rc, lh)
-        lrun(32)
+        lrun(warm)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         barrier()
-        e0.record(stream); lrun(256); e1.record(stream)
+        t0 = time.perf_counter()
+        e0.record(stream); lrun(k); e1.record(stream)
         barrier()
-        lms = e0.elapsed_time(e1) / 256
-        large = {"envs_per_gpu": nl, "steps": 256, "avg_launch_ms": lms, "env_steps_per_s_per_gpu": nl / (lms * 1e-3),
-                 "achieved_GBps": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9,
-                 "frac": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                 "note": "pnr_step, one launch per step, same kernel as `value`; rank 0's HIP-event timing"}
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        lms = e0.elapsed_time(e1) / k
         lenv.close()
-        del lobs, lacts
+        return {"envs_per_gpu": nl, "steps": k, "avg_launch_ms": lms, "ms_per_step": el / k * 1e3,
+                "value": float(nl) * world * k / el, "unit": "env-steps/s",
+                "env_steps_per_s_per_gpu": nl / (lms * 1e-3),
+                "achieved_GBps": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9,
+                "frac": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "note": note}
+
+    # the same kernel on a larger batch per launch (amortises the ~3.5 us launch + first-load floor)
+    large = None
+    if T == 1 and args.large_envs > n and args.mode == "kinematic":
+        large = side_leg(args.large_envs, world * n + rank * args.large_envs, 256, 32,
+                         "pnr_step, one launch per step, same kernel as `value`; avg_launch_ms/frac from rank 0's HIP events")
+
+    # BASELINE config[3] read literally: 65 536 envs IN TOTAL, sharded over the ranks (strong scaling;
+    # 8 192 envs per GPU at N=8, where one launch is shorter than the launch floor)
+    strong = None
+    if T == 1 and world > 1 and args.mode == "kinematic" and args.strong_total > 0:
+        start, cnt = pdist.shard_range(args.strong_total, world, rank)
+        strong = side_leg(cnt, start, max(256, args.steps), 64,
+                          f"{args.strong_total} envs in total sharded over {world} ranks (strong scaling of the named config)")
+        strong["total_envs"] = args.strong_total
+        strong["value"] = float(args.strong_total) / (strong["ms_per_step"] * 1e-3)
 
     def ppo_leg(iters):
-        """BASELINE config[2]/[3]: the full rollout + learn loop on a 16 384-env shard per GPU."""
+        """BASELINE config[2] at N=1 (16 384 envs, full rollout + learn loop) and config[3] at N>1
+        (65 536 envs in total sharded over the ranks, gradients all-reduced over RCCL/xGMI)."""
         from pioneer_amd.ppo import PPOConfig, PPOTrainer
-        penv = PioneerVectorEnv(args.ppo_envs, device=dev, seed=0, env_id_offset=rank * args.ppo_envs,
+        total = args.ppo_envs if args.ppo_envs > 0 else (16384 if world == 1 else 65536)
+        start, cnt = pdist.shard_range(total, world, rank)
+        penv = PioneerVectorEnv(cnt, device=dev, seed=0, env_id_offset=start,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=args.mode))
-        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=131072, amp_bf16=True)
+        mbs = min(131072, 32 * cnt)
+        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, amp_bf16=True)
         tr = PPOTrainer(penv, pcfg, use_graph=True)
         tr.train(); tr.train()                       # warm-up: eager iteration, then the graph-captured one
         barrier()
@@ -318,24 +354,20 @@ def main():
         rs = [tr.train() for _ in range(iters)]
         barrier()
         tp = time.perf_counter() - tp
+        graphed = {"sampling": tr._graph is not None, "learner": tr.learner._graph is not None,
+                   "learner_split_around_allreduce": bool(tr.learner._split)}
         penv.close()
-        steps = iters * 32 * args.ppo_envs * world
-        return {"value": steps / tp, "unit": "env-steps/s", "envs_per_gpu": args.ppo_envs, "rollout_T": 32,
-                "num_sgd_iter": 4, "sgd_minibatch_size": 131072, "mlp_dtype": "bf16 autocast",
-                "hip_graph_sampling": True, "iters": iters,
+        steps = iters * 32 * total
+        return {"value": steps / tp, "unit": "env-steps/s", "total_envs": total, "envs_per_gpu": cnt, "rollout_T": 32,
+                "num_sgd_iter": 4, "sgd_minibatch_size_per_rank": mbs, "mlp_dtype": "bf16 autocast",
+                "hip_graph": graphed, "iters": iters,
+                "grad_allreduce": (f"{dist.get_backend()} flat 0.82 MB bucket per minibatch" if world > 1 else None),
                 "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                 "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
 
-    ppo_loop = None
-    if args.ppo_iters < 0:
-        args.ppo_iters = 3 if (world == 1 and args.mode == "kinematic") else 0
-    if args.ppo_iters > 0:
-        try:
-            ppo_loop = ppo_leg(args.ppo_iters)
-        except Exception as exc:      # the extra leg must never take the main result down
-            ppo_loop = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-
-    if rank == 0:
+    def emit(ppo_loop):
+        if rank != 0:
+            return
         launches = K // T
         launch_ms = ev_ms / launches
         # per launch: T steps of action/obs/reward/flags traffic + ONE state read and write
@@ -371,11 +403,43 @@ def main():
             out["fused_rollout"] = fused
         if large:
             out["large_batch"] = large
+        if strong:
+            out["strong_scaling"] = strong
         if ppo_loop:
             out["ppo_loop"] = ppo_loop
         if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+
+    ppo_loop = None
+    if args.ppo_iters < 0:
+        args.ppo_iters = 3 if args.mode == "kinematic" else 0
+    if args.ppo_iters > 0:
+        # the extra leg must never take the main result down: exceptions are reported in place, and a
+        # leg that does not come back (e.g. ranks out of step in a collective) is cut off by a watchdog
+        # that prints the result line without it and ends the process
+        import threading
+        lock, state = threading.Lock(), {"done": False}
+
+        def on_timeout():
+            with lock:
+                if state["done"]:
+                    return
+                state["done"] = True
+                emit({"error": f"ppo leg did not finish within {args.ppo_timeout:.0f} s"})
+                sys.stdout.flush()
+                os._exit(0)
+        wd = threading.Timer(args.ppo_timeout, on_timeout)
+        wd.daemon = True
+        wd.start()
+        try:
+            ppo_loop = ppo_leg(args.ppo_iters)
+        except Exception as exc:
+            ppo_loop = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        with lock:
+            state["done"] = True
+        wd.cancel()
+    emit(ppo_loop)
 
     env.close()
     if world > 1:

@@ -68,6 +68,14 @@ def allreduce_mean_grads(params: Iterable[torch.nn.Parameter]) -> None:
         off += n
 
 
+def allreduce_mean_(t: torch.Tensor) -> torch.Tensor:
+    """In-place mean over ranks of an already-flat bucket."""
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(dist.get_world_size())
+    return t
+
+
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     if is_dist():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -36,7 +36,8 @@ def train(results_dir: str,
           envs_per_worker: int = 4096,
           ppo_config: Optional[PPOConfig] = None,
           mode: str = "kinematic",
-          log_every: int = 10):
+          log_every: int = 10,
+          use_graph: bool = True):
     """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list."""
     rank, local_rank, world = pdist.world_info()
     if os.environ.get("PNR_DIST_BACKEND") == "gloo":        # rehearsal: ranks may share the visible GPUs
@@ -66,7 +67,7 @@ def train(results_dir: str,
         env = PioneerVectorEnv(count, device=device, seed=cfg.seed, env_id_offset=start,
                                pioneer_config=pioneer_config,
                                engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=mode))
-        trainer = PPOTrainer(env, cfg)
+        trainer = PPOTrainer(env, cfg, use_graph=use_graph)   # hipGraph-captured sampling and updates
         last = {}
         log = open(os.path.join(tdir, "result.json"), "a") if rank == 0 else None
         t0 = time.time()

@@ -299,6 +299,10 @@ class EpisodeStats:
         return out
 
 
+# other threads (the RCCL watchdog of torch.distributed) may touch the HIP runtime while this thread captures
+_CAPTURE_MODE = "thread_local"
+
+
 class PPOLearner:
     """The learn phase alone (usable on CPU with any rollout tensors): minibatch SGD on the clipped
     surrogate + adaptive KL + clipped value loss - entropy bonus, gradients averaged over ranks."""
@@ -309,8 +313,13 @@ class PPOLearner:
         torch.manual_seed(cfg.seed)
         self.model = ActorCritic(cfg).to(self.device)
         pdist.broadcast_module_(self.model)
-        # hipGraph capture of one minibatch update (loss -> backward -> Adam): single rank, GPU, no grad clip
-        self.use_graph = bool(use_graph) and self.device.type == "cuda" and not pdist.is_dist() and not cfg.grad_clip
+        # hipGraph capture of one minibatch update, GPU, no grad clip.  One rank: loss -> backward -> Adam
+        # in ONE graph.  Several ranks: graph A (loss -> backward into a flat gradient bucket), the
+        # bucket's all-reduce issued eagerly (collectives stay out of the graphs), graph B (Adam).
+        self.use_graph = bool(use_graph) and self.device.type == "cuda" and not cfg.grad_clip
+        self._split = self.use_graph and pdist.is_dist()
+        self._flat_grad = None
+        self._graph_b = None
         self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr, capturable=self.use_graph)
         self.kl_coeff = cfg.kl_coeff
         self.timesteps_total = 0
@@ -381,6 +390,9 @@ class PPOLearner:
                     for k, v in batch.items():
                         torch.index_select(v, 0, idx, out=self._static[k])
                     self._graph.replay()
+                    if self._split:
+                        pdist.allreduce_mean_(self._flat_grad)      # the one 0.82 MB bucket, eager
+                        self._graph_b.replay()
                     info = self._static_info
                 else:
                     info = eager_step({k: v[idx] for k, v in batch.items()})
@@ -404,19 +416,37 @@ class PPOLearner:
 
 
 def _learner_capture(self, batch, idx):
-    """Capture loss -> backward -> Adam on static minibatch buffers into one hipGraph."""
+    """Capture one minibatch update on static buffers: one hipGraph (single rank) or two with the
+    gradient all-reduce between them (several ranks).  The capture pass only records work."""
     try:
         self._static = {k: v[idx].clone() for k, v in batch.items()}
         torch.cuda.synchronize(self.device)
-        self.opt.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        if not self._split:
+            self.opt.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
+                loss, info = self.loss(self._static)
+                loss.backward()
+                self.opt.step()
+            self._graph, self._static_info = g, info
+            return
+        # every parameter's .grad becomes a view of one flat bucket; backward accumulates in place
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=self.device)
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, capture_error_mode=_CAPTURE_MODE):
+            flat.zero_()
             loss, info = self.loss(self._static)
             loss.backward()
+        with torch.cuda.graph(gb, capture_error_mode=_CAPTURE_MODE):
             self.opt.step()
-        self._graph, self._static_info = g, info
+        self._graph, self._graph_b, self._flat_grad, self._static_info = ga, gb, flat, info
     except Exception:            # capture not possible here: stay eager
-        self._graph, self._static, self.use_graph = None, None, False
+        self._graph, self._graph_b, self._static, self.use_graph, self._split = None, None, None, False, False
         torch.cuda.synchronize(self.device)
 
 
@@ -502,7 +532,7 @@ class PPOTrainer:
             self._capturing = True              # in-graph noise comes from the default (graph-safe) generator
             torch.cuda.manual_seed(self.cfg.seed * 7919 + self.rank + 1)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
                 self._collect_impl()
             self._graph = g
             # the capture pass itself only recorded work: run it for real below

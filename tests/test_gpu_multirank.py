@@ -45,3 +45,56 @@ def test_two_ranks_train_in_lock_step(tmp_path):
     assert r0["timesteps_total"] == r1["timesteps_total"] == 2 * 256 * 8 * 3
     assert r0["kl"] == r1["kl"] and r0["episodes_total"] == r1["episodes_total"]   # all-reduced metrics
     assert r0["wsum"] == r1["wsum"] and r0["wabs"] == r1["wabs"]                   # one checkpoint, ranks in lock-step
+
+
+LEARNER_WORKER = r'''
+import json, os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["PNR_ROOT"])
+from pioneer_amd.ppo import PPOConfig, PPOLearner
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+dev = torch.device("cuda", 0)
+B = 4096
+g = torch.Generator(device=dev).manual_seed(100 + rank)           # every rank its own share of the batch
+R = lambda *s: torch.randn(*s, generator=g, device=dev)
+batch = {"obs": R(B, 137), "actions": R(B, 6), "mean": 0.1 * R(B, 6), "log_std": 0.1 * R(B, 6),
+         "logp": -8.0 + R(B), "values": R(B), "adv": R(B), "vtarg": R(B)}
+res = {}
+for use_graph in (False, True):
+    cfg = PPOConfig(num_sgd_iter=3, sgd_minibatch_size=B // 2, lr=1e-3, seed=11, amp_bf16=False)
+    lr = PPOLearner(cfg, dev, use_graph=use_graph)
+    pg = torch.Generator(device=dev).manual_seed(5)                # same minibatch permutations in both runs
+    infos = [lr.update(dict(batch), pg) for _ in range(3)]        # 18 updates: 3 eager, capture, 14 replays
+    w = torch.cat([p.detach().reshape(-1).double().cpu() for p in lr.model.parameters()])
+    res[str(use_graph)] = {"w": w, "kl": infos[-1]["kl"], "graphed": lr._graph is not None and lr._graph_b is not None,
+                           "split": bool(lr._split)}
+diff = float((res["True"]["w"] - res["False"]["w"]).abs().max())
+move = float((res["False"]["w"] - torch.cat([p.detach().reshape(-1).double().cpu() for p in PPOLearner(cfg, dev).model.parameters()])).abs().max())
+json.dump({"rank": rank, "diff": diff, "move": move, "graphed": res["True"]["graphed"], "split": res["True"]["split"],
+           "wsum_graph": float(res["True"]["w"].sum()), "wsum_eager": float(res["False"]["w"].sum()),
+           "kl_graph": res["True"]["kl"], "kl_eager": res["False"]["kl"]},
+          open(os.path.join(os.environ["PNR_OUT"], f"learner{rank}.json"), "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_split_graph_learner_equals_eager_across_two_ranks(tmp_path):
+    """Several ranks: graph A (loss -> backward into the flat bucket), eager all-reduce, graph B (Adam)
+    must give the weights of the eager data-parallel update, identically on both ranks."""
+    script = tmp_path / "learner.py"
+    script.write_text(LEARNER_WORKER)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, PNR_ROOT=ROOT, PNR_OUT=str(tmp_path), OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r0 = json.load(open(tmp_path / "learner0.json")); r1 = json.load(open(tmp_path / "learner1.json"))
+    for r in (r0, r1):
+        assert r["graphed"] and r["split"], r                     # the two-graph path really ran
+        assert r["move"] > 1e-3                                    # the weights did move
+        assert r["diff"] < 2e-5, r                                 # fp32, capturable vs plain Adam arithmetic
+        assert abs(r["kl_graph"] - r["kl_eager"]) < 1e-5
+    assert r0["wsum_graph"] == r1["wsum_graph"] and r0["wsum_eager"] == r1["wsum_eager"]   # ranks in lock-step
