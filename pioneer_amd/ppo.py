@@ -579,7 +579,7 @@ class PPOTrainer:
         return path
 
     def restore(self, path: str, restore_env: bool = False) -> None:
-        ck = torch.load(path, map_location=self.device, weights_only=False)   # our own file
+        ck = torch.load(path, map_location=self.device, weights_only=True)    # tensors and plain values only
         self.learner.model.load_state_dict(ck["model"]); self.learner.opt.load_state_dict(ck["opt"])
         self.filter.load_state_dict(ck["filter"]); self.learner.kl_coeff = ck["kl_coeff"]
         self.learner.timesteps_total = ck["timesteps_total"]; self.iteration = ck["iteration"]

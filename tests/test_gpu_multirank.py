@@ -23,7 +23,7 @@ df = train(results_dir=out, checkpoint_freq=0, num_samples=1, num_workers=1, mon
            ppo_config=PPOConfig(rollout_fragment_length=8, num_sgd_iter=2, sgd_minibatch_size=1024, seed=5))
 rank = int(os.environ["RANK"])
 row = df.iloc[0].to_dict() if hasattr(df, "iloc") else df[0]
-ck = torch.load(os.path.join(out, "PPO_Pioneer-v1_00000", "checkpoint_final.pt"), weights_only=False)
+ck = torch.load(os.path.join(out, "PPO_Pioneer-v1_00000", "checkpoint_final.pt"), weights_only=True)
 w = torch.cat([v.reshape(-1).double().cpu() for v in ck["model"].values()])
 json.dump({"rank": rank, "timesteps_total": int(row["timesteps_total"]), "episodes_total": int(row["episodes_total"]),
            "kl": float(row["kl"]), "wsum": float(w.sum()), "wabs": float(w.abs().sum())},

@@ -128,7 +128,7 @@ def _worker(rank, world, port, out_dir):
 def test_two_rank_gloo_matches_single_process(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(tmp_path / "r0.pt", weights_only=False); r1 = torch.load(tmp_path / "r1.pt", weights_only=False)
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=True); r1 = torch.load(tmp_path / "r1.pt", weights_only=True)
     # ranks agree with each other
     assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["w"], r1["w"]) and torch.equal(r0["mean"], r1["mean"])
     # and with one process on the concatenated batch
