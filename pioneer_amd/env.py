@@ -34,6 +34,8 @@ class PioneerKinematicEnv:
                  render_config: Optional[RenderConfig] = None,
                  device=None,
                  mode: str = "kinematic"):
+        self._ctor = dict(headless=headless, pioneer_config=pioneer_config, simulation_config=simulation_config,
+                          render_config=render_config, device=device, mode=mode)
         self.headless = headless
         self.config = pioneer_config or PioneerKinematicConfig()
         self.simulation_config = simulation_config or SimulationConfig()
@@ -61,6 +63,10 @@ class PioneerKinematicEnv:
         self.action_space = Box(-self.a_max, self.a_max, dtype=np.float32)  # :72
         self.observation_space = self.observation_to_space(self.observe())  # :73
         self.reward_range = (-float("inf"), float("inf"))                  # :74
+
+    # -- pickling: by constructor arguments, like gym.utils.EzPickle (pioneer_knm_env.py:38, :51) --
+    def __reduce__(self):
+        return (_rebuild_env, (self._ctor,))
 
     # -- randomness ------------------------------------------------------------------
     @staticmethod
@@ -156,6 +162,10 @@ class PioneerKinematicEnv:
 
     def close(self):
         self._vec.close()
+
+
+def _rebuild_env(ctor):
+    return PioneerKinematicEnv(**ctor)
 
 
 class TimeLimit:

@@ -21,6 +21,10 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _rebuild_vector_env(ctor):
+    return PioneerVectorEnv(**ctor)
+
+
 class PioneerVectorEnv:
     """N independent Pioneer arms stepped by one HIP kernel launch.
 
@@ -34,6 +38,9 @@ class PioneerVectorEnv:
                  simulation_config: Optional[SimulationConfig] = None,
                  engine_config: Optional[EngineConfig] = None):
         self._h = None
+        self._ctor = dict(num_envs=num_envs, device=device, seed=seed, env_id_offset=env_id_offset,
+                          pioneer_config=pioneer_config, simulation_config=simulation_config,
+                          engine_config=engine_config)
         self.lib = _lib.load_library()
         if not torch.cuda.is_available():
             raise RuntimeError("pioneer_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -221,6 +228,11 @@ class PioneerVectorEnv:
         f = w.view(np.float32)
         return dict(a=f[0:6].T.copy(), v=f[6:12].T.copy(), r=f[12:18].T.copy(), target=f[18:21].T.copy(),
                     potential=f[21].copy(), step_index=w[22].copy(), episode=w[23].copy())
+
+    def __reduce__(self):
+        """Pickled by constructor arguments (a fresh batch, like the reference's EzPickle envs);
+        use get_state()/set_state() to carry the simulation state."""
+        return (_rebuild_vector_env, (self._ctor,))
 
     def get_unwrapped(self):
         return []

@@ -6,6 +6,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -98,3 +99,46 @@ def test_split_graph_learner_equals_eager_across_two_ranks(tmp_path):
         assert r["diff"] < 2e-5, r                                 # fp32, capturable vs plain Adam arithmetic
         assert abs(r["kl_graph"] - r["kl_eager"]) < 1e-5
     assert r0["wsum_graph"] == r1["wsum_graph"] and r0["wsum_eager"] == r1["wsum_eager"]   # ranks in lock-step
+
+
+RCCL_WORKER = r'''
+import json, os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["PNR_ROOT"])
+os.environ.update(MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # "nccl" is RCCL on ROCm
+from pioneer_amd import dist as pdist
+pdist.is_dist = lambda: dist.is_initialized()       # take the multi-rank code paths with the one rank this box has
+from pioneer_amd import PioneerVectorEnv, EngineConfig
+from pioneer_amd.ppo import PPOConfig, PPOTrainer
+env = PioneerVectorEnv(2048, device=dev, seed=3, engine_config=EngineConfig(max_episode_steps=40))
+tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=16, num_sgd_iter=3, sgd_minibatch_size=8192, lr=3e-4, seed=3,
+                               amp_bf16=True), use_graph=True)
+rows = [tr.train() for _ in range(5)]
+json.dump({"backend": dist.get_backend(), "sampling_graph": tr._graph is not None,
+           "split": bool(tr.learner._split), "graph_a": tr.learner._graph is not None, "graph_b": tr.learner._graph_b is not None,
+           "kl": [r["kl"] for r in rows], "total_loss": [r["total_loss"] for r in rows],
+           "timesteps_total": rows[-1]["timesteps_total"], "episodes_total": rows[-1]["episodes_total"]},
+          open(os.path.join(os.environ["PNR_OUT"], "rccl.json"), "w"))
+env.close()
+dist.destroy_process_group()
+'''
+
+
+def test_graph_captured_loop_with_an_rccl_process_group(tmp_path):
+    """The N>1 code paths (sampling hipGraph, learner graphs split around the flat-bucket all-reduce,
+    filter/metric all-reduces) against a real RCCL process group — one rank, all this box has — so that
+    capture next to RCCL's watchdog thread and eager collectives between graph replays are exercised."""
+    script = tmp_path / "rccl.py"
+    script.write_text(RCCL_WORKER)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, PNR_ROOT=ROOT, PNR_OUT=str(tmp_path), MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = json.load(open(tmp_path / "rccl.json"))
+    assert r["backend"] == "nccl"
+    assert r["sampling_graph"] and r["split"] and r["graph_a"] and r["graph_b"], r
+    assert r["timesteps_total"] == 5 * 16 * 2048 and r["episodes_total"] > 0
+    assert all(np.isfinite(x) for x in r["kl"] + r["total_loss"]), r

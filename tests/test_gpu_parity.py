@@ -255,6 +255,25 @@ def test_single_env_facade_matches_oracle():
     env.close()
 
 
+def test_envs_pickle_by_constructor_arguments():
+    """EzPickle semantics (pioneer_knm_env.py:38, :51): unpickling builds a fresh env from the ctor args."""
+    import pickle
+    from pioneer_amd import PioneerKinematicEnv, PioneerKinematicConfig, PioneerVectorEnv, EngineConfig
+    env = PioneerKinematicEnv(device="cuda:0", pioneer_config=PioneerKinematicConfig(award_done=7.0))
+    twin = pickle.loads(pickle.dumps(env))
+    assert twin.config.award_done == 7.0 and twin.dof == 6
+    jp = np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6]); tp = (20.0, 1.0, 3.0)
+    assert np.array_equal(env.reset_world(jp, tp), twin.reset_world(jp, tp))
+    a = np.full(6, 0.5, dtype=np.float32)
+    assert np.array_equal(env.step(a)[0], twin.step(a)[0])
+    env.close(); twin.close()
+    vec = PioneerVectorEnv(64, device="cuda:0", seed=9, env_id_offset=128, engine_config=EngineConfig(max_episode_steps=50))
+    vtwin = pickle.loads(pickle.dumps(vec))
+    assert vtwin.num_envs == 64 and vtwin.env_id_offset == 128 and vtwin.engine_config.max_episode_steps == 50
+    assert torch.equal(vec.reset(), vtwin.reset())           # same seed and global env ids: same draws
+    vec.close(); vtwin.close()
+
+
 def test_errors_are_loud():
     from pioneer_amd import PioneerVectorEnv, PnrError
     env = PioneerVectorEnv(8, device="cuda:0")
