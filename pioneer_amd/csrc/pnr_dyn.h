@@ -18,6 +18,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/pioneer_amd.h"
 #include "pnr_device.h"
 
@@ -140,9 +143,144 @@ __device__ __forceinline__ M3 outer_sym(float k, V3 a)
     return {{xx, xy, xz}, {xy, yy, yz}, {xz, yz, zz}};
 }
 
-// spatial (articulated) inertia [[A, B], [B^T, C]] acting on [w; v]: n = A w + B v, f = B^T w + C v
-struct SI { M3 A, B, C; };
-struct SV { V3 a, l; };   // spatial vector: angular part, linear part
+// ---- packed spatial algebra ---------------------------------------------------------
+// CDNA4's fp32 vector peak needs v_pk_{fma,mul,add}_f32 (two results per instruction), and the
+// compiler's SLP pass cannot find the pairs in this code without burying them in shuffles.  So the
+// pairing is done by hand, by layout: every spatial quantity keeps its ANGULAR and LINEAR halves in
+// one 64-bit register pair, because the recursion treats the two halves alike almost everywhere
+// (same rotation, same axis products).  hipcc turns `f2` arithmetic straight into v_pk_* ops: a
+// scalar operand becomes an op_sel_hi splat and `.yx` an op_sel swap, neither costs an instruction.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// compile-time loops: every index below is a constant in the AST already (no local array or struct is
+// ever indexed by a loop variable, so nothing can be left behind in scratch)
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int K> __device__ __forceinline__ float vc(const V3& a) { if constexpr (K == 0) return a.x; else if constexpr (K == 1) return a.y; else return a.z; }
+template <int I, int J> __device__ __forceinline__ float mc(const M3& m)
+{
+    if constexpr (I == 0) return vc<J>(m.r0); else if constexpr (I == 1) return vc<J>(m.r1); else return vc<J>(m.r2);
+}
+
+// spatial vector: component i = (angular_i, linear_i)
+struct P3 { f2 x, y, z; };
+template <int K> __device__ __forceinline__ f2& pr(P3& a) { if constexpr (K == 0) return a.x; else if constexpr (K == 1) return a.y; else return a.z; }
+template <int K> __device__ __forceinline__ const f2& pc(const P3& a) { if constexpr (K == 0) return a.x; else if constexpr (K == 1) return a.y; else return a.z; }
+__device__ __forceinline__ P3 operator+(P3 a, P3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ P3 operator-(P3 a, P3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 ang(const P3& a) { return {a.x.x, a.y.x, a.z.x}; }
+__device__ __forceinline__ V3 lin(const P3& a) { return {a.x.y, a.y.y, a.z.y}; }
+__device__ __forceinline__ P3 pack(V3 a, V3 l) { return {{a.x, l.x}, {a.y, l.y}, {a.z, l.z}}; }
+
+// both halves rotated by R(axis, angle): child -> parent; R^T = rotp<AX>(v, c, -s)
+template <int AXn>
+__device__ __forceinline__ P3 rotp(const P3& v, float c, float s)
+{
+    if (AXn == (int)AX) return {v.x, c * v.y - s * v.z, s * v.y + c * v.z};
+    if (AXn == (int)AY) return {c * v.x + s * v.z, v.y, c * v.z - s * v.x};
+    return {c * v.x - s * v.y, s * v.x + c * v.y, v.z};
+}
+
+// (v.a, v.l) x (e_k qd) for both halves: two packed products, component k is zero
+template <int K>
+__device__ __forceinline__ P3 cross_axis(const P3& v, float qd)
+{
+    constexpr int a = (K + 1) % 3, b = (K + 2) % 3;
+    P3 c = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    pr<a>(c) = pc<b>(v) * qd;
+    pr<b>(c) = pc<a>(v) * (-qd);
+    return c;
+}
+
+// E (v - [0; r_J x v.a]): the motion transform parent -> child of joint J
+template <int J>
+__device__ __forceinline__ P3 to_child(const P3& vp, float c, float s)
+{
+    constexpr int AXJ = (int)kJoints[J].axis;
+    const V3 rxw = cross_r<J>(ang(vp));
+    P3 t = vp;
+    t.x.y -= rxw.x; t.y.y -= rxw.y; t.z.y -= rxw.z;
+    return rotp<AXJ>(t, c, -s);
+}
+
+// spatial (articulated) inertia [[A, B], [B^T, C]] acting on [w; v]: n = A w + B v, f = B^T w + C v.
+// A and C are symmetric and always transform alike: stored as six pairs (A_ij, C_ij).  B is general;
+// its transpose transforms like B itself, so the off-diagonal entries are the pairs (B_ij, B_ji).
+struct SIp {
+    f2 ac[6];     // (A_ij, C_ij) for ij = 00 01 02 11 12 22
+    float bd[3];  // B_00 B_11 B_22
+    f2 bo[3];     // (B_01, B_10) (B_02, B_20) (B_12, B_21)
+};
+// compile-time index maps (variable templates, so they are constants wherever they are used)
+constexpr int sidx_fn(int i, int j) { const int a = i < j ? i : j, b = i < j ? j : i; return a == 0 ? b : (a == 1 ? 2 + b : 5); }
+template <int I, int J> constexpr int SIDX = sidx_fn(I, J);
+template <int I, int J> constexpr int OIDX = I + J - 1;
+// (B_ij, B_ji)
+template <int I_, int J_>
+__device__ __forceinline__ f2 bpair(const SIp& I)
+{
+    if constexpr (I_ == J_) return (f2)(I.bd[I_]);
+    else if constexpr (I_ < J_) return I.bo[OIDX<I_, J_>];
+    else return I.bo[OIDX<I_, J_>].yx;
+}
+template <int I_, int J_>
+__device__ __forceinline__ float bget(const SIp& I)
+{
+    if constexpr (I_ == J_) return I.bd[I_];
+    else if constexpr (I_ < J_) return I.bo[OIDX<I_, J_>].x;
+    else return I.bo[OIDX<I_, J_>].y;
+}
+template <int I_, int J_>
+__device__ __forceinline__ void bset(SIp& I, f2 v)     // v = (B_ij, B_ji), I_ != J_
+{
+    if constexpr (I_ < J_) I.bo[OIDX<I_, J_>] = v; else I.bo[OIDX<I_, J_>] = v.yx;
+}
+__device__ __forceinline__ M3 unpackB(const SIp& I)
+{
+    return {{I.bd[0], I.bo[0].x, I.bo[1].x}, {I.bo[0].y, I.bd[1], I.bo[2].x}, {I.bo[1].y, I.bo[2].y, I.bd[2]}};
+}
+__device__ __forceinline__ M3 unpackC(const SIp& I)
+{
+    return {{I.ac[0].y, I.ac[1].y, I.ac[2].y}, {I.ac[1].y, I.ac[3].y, I.ac[4].y}, {I.ac[2].y, I.ac[4].y, I.ac[5].y}};
+}
+
+// R I R^T of all four blocks.  (a, b) are the coordinates the rotation mixes (v_a' = c v_a - s v_b,
+// v_b' = s v_a + c v_b), k the axis.  Symmetric pairs as rot_sym; for B
+//   B'aa = cc Baa - cs (Bab + Bba) + ss Bbb          B'bb = ss Baa + cs (Bab + Bba) + cc Bbb
+//   (B'ab, B'ba) = cs (Baa - Bbb) + cc (Bab, Bba) - ss (Bba, Bab)
+//   (B'ak, B'ka) = c (Bak, Bka) - s (Bbk, Bkb)       (B'bk, B'kb) = s (Bak, Bka) + c (Bbk, Bkb)
+template <int AXn>
+__device__ __forceinline__ SIp rot_inertia(const SIp& I, float c, float s)
+{
+    constexpr int a = (AXn + 1) % 3, b = (AXn + 2) % 3, k = AXn;
+    const float cc = c * c, ss = s * s, cs = c * s;
+    SIp o;
+    const f2 Saa = I.ac[SIDX<a, a>], Sbb = I.ac[SIDX<b, b>], Sab = I.ac[SIDX<a, b>];
+    const f2 Sak = I.ac[SIDX<a, k>], Sbk = I.ac[SIDX<b, k>];
+    const f2 x2 = (2.f * cs) * Sab;
+    o.ac[SIDX<a, a>] = cc * Saa - x2 + ss * Sbb;
+    o.ac[SIDX<b, b>] = ss * Saa + x2 + cc * Sbb;
+    o.ac[SIDX<a, b>] = cs * (Saa - Sbb) + (cc - ss) * Sab;
+    o.ac[SIDX<a, k>] = c * Sak - s * Sbk;
+    o.ac[SIDX<b, k>] = s * Sak + c * Sbk;
+    o.ac[SIDX<k, k>] = I.ac[SIDX<k, k>];
+    const float Baa = I.bd[a], Bbb = I.bd[b];
+    const f2 pab = bpair<a, b>(I), pak = bpair<a, k>(I), pbk = bpair<b, k>(I);
+    const float m = cs * (pab.x + pab.y);
+    o.bd[a] = cc * Baa - m + ss * Bbb;
+    o.bd[b] = ss * Baa + m + cc * Bbb;
+    o.bd[k] = I.bd[k];
+    const f2 nab = cs * (Baa - Bbb) + cc * pab - ss * pab.yx;
+    const f2 nak = c * pak - s * pbk;
+    const f2 nbk = s * pak + c * pbk;
+    bset<a, b>(o, nab);
+    bset<a, k>(o, nak);
+    bset<b, k>(o, nbk);
+    return o;
+}
 
 // skew(r_J) * M (each column crossed with r) and M * skew(r_J)
 template <int J>
@@ -161,7 +299,7 @@ __device__ __forceinline__ M3 mul_rx(const M3& m)
 }
 
 struct DynBody {   // what pass 3 needs from pass 2
-    V3 Ua, Ul;
+    P3 U;          // (Ua_i, Ul_i)
     float D, u;
 };
 
@@ -185,89 +323,128 @@ __device__ __forceinline__ void build_model(const float (&sc)[kNumLinks], DynMod
 }
 
 // one joint of pass 2 (tip -> base).  IA/pA: articulated inertia / bias force of body J in its own
-// frame (children already folded in).  Emits U, D, u and folds body J into its parent (PA, pP).
+// frame (children already folded in).  Emits U, D, u and folds body J into its parent (IP, pP).
 template <int J>
-__device__ __forceinline__ void aba_inward(const SI& IA, const SV& pA, const SV& vJ, float qdJ, float tauJ,
-                                           float cJ, float sJ, DynBody& out, SI& IP, SV& pP)
+__device__ __forceinline__ void aba_inward(const SIp& IA, const P3& pA, const P3& vJ, float qdJ, float tauJ,
+                                           float cJ, float sJ, DynBody& out, SIp& IP, P3& pP)
 {
     constexpr int k = (int)kJoints[J].axis;
-    out.Ua = col(IA.A, k);
-    out.Ul = row(IA.B, k);
-    out.D = comp(out.Ua, k);
-    out.u = tauJ - comp(pA.a, k);
+    // U = I S: (Ua_j, Ul_j) = (A_jk, B_kj)
+    P3 u;
+    static_for<3>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        pr<j>(u) = (f2){IA.ac[SIDX<j, k>].x, bget<k, j>(IA)};
+    });
+    out.U = u;
+    out.D = pc<k>(u).x;
+    out.u = tauJ - pc<k>(pA).x;
     if (J == 0) return;
     const float invD = fast_rcp(out.D);
     // Ia = IA - U U^T / D
-    SI Ia;
-    Ia.A = IA.A - outer_sym(invD, out.Ua);
-    Ia.B = IA.B - outer(invD * out.Ua, out.Ul);
-    Ia.C = IA.C - outer_sym(invD, out.Ul);
-    // c = v x (S qd)
-    V3 ek = {k == 0 ? qdJ : 0.f, k == 1 ? qdJ : 0.f, k == 2 ? qdJ : 0.f};
-    const V3 ca = cross(vJ.a, ek), cl = cross(vJ.l, ek);
-    // pa = pA + Ia c + U u / D
+    const P3 w = {invD * u.x, invD * u.y, invD * u.z};
+    SIp Ia;
+    static_for<3>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        Ia.bd[i] = IA.bd[i] - pc<i>(w).x * pc<i>(u).y;                // B_ij -= Ua_i Ul_j / D
+        static_for<3>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j >= i) Ia.ac[SIDX<i, j>] = IA.ac[SIDX<i, j>] - pc<i>(w) * pc<j>(u);
+            if constexpr (j > i) {
+                Ia.bo[OIDX<i, j>].x = IA.bo[OIDX<i, j>].x - pc<i>(w).x * pc<j>(u).y;
+                Ia.bo[OIDX<i, j>].y = IA.bo[OIDX<i, j>].y - pc<j>(w).x * pc<i>(u).y;
+            }
+        });
+    });
+    // c = v x (S qd); pa = pA + Ia c + U u / D:
+    //   (pa.a_i, pa.l_i) += (A_ij, C_ij) (ca_j, cl_j) + (B_ij, B_ji) (cl_j, ca_j)
+    const P3 cv = cross_axis<k>(vJ, qdJ);
     const float ud = out.u * invD;
-    SV pa;
-    pa.a = pA.a + mul(Ia.A, ca) + mul(Ia.B, cl) + ud * out.Ua;
-    pa.l = pA.l + mulT(Ia.B, ca) + mul(Ia.C, cl) + ud * out.Ul;
+    P3 pa;
+    static_for<3>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        f2 acc = pc<i>(pA) + ud * pc<i>(u);
+        static_for<3>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j != k) {                                   // c_k = 0
+                acc += Ia.ac[SIDX<i, j>] * pc<j>(cv);
+                acc += bpair<i, j>(Ia) * pc<j>(cv).yx;
+            }
+        });
+        pr<i>(pa) = acc;
+    });
     // rotate into the parent's orientation, then shift to the parent's origin:
     //   C_p = C', B_p = B' + rx C', A_p = A' - P - P^T - (rx C') rx  with P = B' rx
-    constexpr Axis AXJ = kJoints[J].axis;
-    const M3 A1 = rot_sym<(int)AXJ>(Ia.A, cJ, sJ), B1 = rot_block<(int)AXJ>(Ia.B, cJ, sJ), C1 = rot_sym<(int)AXJ>(Ia.C, cJ, sJ);
+    constexpr int AXJ = (int)kJoints[J].axis;
+    const SIp I1 = rot_inertia<AXJ>(Ia, cJ, sJ);
+    const M3 C1 = unpackC(I1), B1 = unpackB(I1);
     const M3 T = rx_mul<J>(C1);
-    const M3 P = mul_rx<J>(B1);
+    const M3 Pm = mul_rx<J>(B1);
     const M3 Q = mul_rx<J>(T);
-    IP.C = IP.C + C1;
-    IP.B = IP.B + B1 + T;
-    IP.A = IP.A + A1 - P - transpose(P) - Q;
-    const V3 n1 = rot<(int)AXJ>(pa.a, cJ, sJ), f1 = rot<(int)AXJ>(pa.l, cJ, sJ);
-    pP.a = pP.a + n1 + cross_r<J>(f1);
-    pP.l = pP.l + f1;
+    static_for<3>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        IP.bd[i] += I1.bd[i] + mc<i, i>(T);
+        static_for<3>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (j >= i) {
+                IP.ac[SIDX<i, j>] += I1.ac[SIDX<i, j>];
+                IP.ac[SIDX<i, j>].x -= mc<i, j>(Pm) + mc<j, i>(Pm) + mc<i, j>(Q);
+            }
+            if constexpr (j > i) {
+                IP.bo[OIDX<i, j>] += I1.bo[OIDX<i, j>];
+                IP.bo[OIDX<i, j>].x += mc<i, j>(T);
+                IP.bo[OIDX<i, j>].y += mc<j, i>(T);
+            }
+        });
+    });
+    const P3 p1 = rotp<AXJ>(pa, cJ, sJ);
+    const V3 rxf = cross_r<J>(lin(p1));
+    pP = pP + p1;
+    pP.x.x += rxf.x; pP.y.x += rxf.y; pP.z.x += rxf.z;
 }
 
 // rigid-body inertia and velocity-product bias of body J
 template <int J>
-__device__ __forceinline__ void rigid_body(const DynModel& M, const SV& v, SI& I, SV& p)
+__device__ __forceinline__ void rigid_body(const DynModel& M, const P3& vp, SIp& I, P3& p)
 {
-    if (J < kDof - 1) {
-        const float m = M.m[J];
-        I.A = diag3(m); I.B = diag3(0.f); I.C = diag3(m);
-        p.a = {0.f, 0.f, 0.f};
-        p.l = m * cross(v.a, v.l);
-    } else {
-        const float m = M.m[J];
+    const V3 va = ang(vp), vl = lin(vp);
+    const float m = M.m[J];
+    const f2 mm = {m, m}, zz = {0.f, 0.f};
+    if (J < kDof - 1) {                    // A = C = m 1, B = 0
+        I.ac[0] = mm; I.ac[1] = zz; I.ac[2] = zz; I.ac[3] = mm; I.ac[4] = zz; I.ac[5] = mm;
+        I.bd[0] = I.bd[1] = I.bd[2] = 0.f;
+        I.bo[0] = zz; I.bo[1] = zz; I.bo[2] = zz;
+        p = pack(V3{0.f, 0.f, 0.f}, m * cross(va, vl));
+    } else {                               // A = I6, B = skew(h), C = m 1
         const V3 h = M.h6;
-        I.A = M.I6;
-        I.B = {{0.f, -h.z, h.y}, {h.z, 0.f, -h.x}, {-h.y, h.x, 0.f}};
-        I.C = diag3(m);
-        const V3 n = mul(M.I6, v.a) + cross(h, v.l);
-        const V3 f = m * v.l - cross(h, v.a);
-        p.a = cross(v.a, n) + cross(v.l, f);
-        p.l = cross(v.a, f);
+        const float a00 = M.I6.r0.x, a01 = M.I6.r0.y, a02 = M.I6.r0.z, a11 = M.I6.r1.y, a12 = M.I6.r1.z, a22 = M.I6.r2.z;
+        I.ac[0] = (f2){a00, m};   I.ac[1] = (f2){a01, 0.f}; I.ac[2] = (f2){a02, 0.f};
+        I.ac[3] = (f2){a11, m};   I.ac[4] = (f2){a12, 0.f}; I.ac[5] = (f2){a22, m};
+        I.bd[0] = I.bd[1] = I.bd[2] = 0.f;
+        I.bo[0] = (f2){-h.z, h.z}; I.bo[1] = (f2){h.y, -h.y}; I.bo[2] = (f2){-h.x, h.x};
+        const V3 n = V3{a00 * va.x + a01 * va.y + a02 * va.z, a01 * va.x + a11 * va.y + a12 * va.z,
+                        a02 * va.x + a12 * va.y + a22 * va.z} + cross(h, vl);
+        const V3 f = m * vl - cross(h, va);
+        p = pack(cross(va, n) + cross(vl, f), cross(va, f));
     }
 }
 
 template <int J>
-__device__ __forceinline__ void vel_outward(const SV& vp, float c, float s, float qd, SV& v)
+__device__ __forceinline__ void vel_outward(const P3& vp, float c, float s, float qd, P3& v)
 {
     constexpr int AXJ = (int)kJoints[J].axis;
-    v.a = rot<AXJ>(vp.a, c, -s);
-    v.l = rot<AXJ>(vp.l - cross_r<J>(vp.a), c, -s);     // E (v_p - r x w_p)
-    add_comp(v.a, AXJ, qd);
+    v = to_child<J>(vp, c, s);
+    pr<AXJ>(v).x += qd;
 }
 
 template <int J>
-__device__ __forceinline__ void acc_outward(const SV& ap, const SV& vJ, float c, float s, float qd, const DynBody& b,
-                                            float& qdd, SV& a)
+__device__ __forceinline__ void acc_outward(const P3& ap, const P3& vJ, float c, float s, float qd, const DynBody& b,
+                                            float& qdd, P3& a)
 {
     constexpr int AXJ = (int)kJoints[J].axis;
-    a.a = rot<AXJ>(ap.a, c, -s);
-    a.l = rot<AXJ>(ap.l - cross_r<J>(ap.a), c, -s);
-    V3 ek = {AXJ == 0 ? qd : 0.f, AXJ == 1 ? qd : 0.f, AXJ == 2 ? qd : 0.f};
-    a.a = a.a + cross(vJ.a, ek);
-    a.l = a.l + cross(vJ.l, ek);
-    qdd = (b.u - dot(b.Ua, a.a) - dot(b.Ul, a.l)) * fast_rcp(b.D);
-    add_comp(a.a, AXJ, qdd);
+    a = to_child<J>(ap, c, s) + cross_axis<AXJ>(vJ, qd);
+    const f2 d = b.U.x * a.x + b.U.y * a.y + b.U.z * a.z;             // (Ua . a.a, Ul . a.l)
+    qdd = (b.u - (d.x + d.y)) * fast_rcp(b.D);
+    pr<AXJ>(a).x += qdd;
 }
 
 // world pose of body J from its parent's (for the pointer/ground contact)
@@ -281,7 +458,54 @@ __device__ __forceinline__ void pose_outward(const M3& Rp, V3 pp, float c, float
     R = {rot<AXJ>(Rp.r0, c, -s), rot<AXJ>(Rp.r1, c, -s), rot<AXJ>(Rp.r2, c, -s)};
 }
 
-// qdd = ABA(q, qd, tau); optional ground contact on the pointer
+// penalty contacts of the pointer sphere with the ground plane and the static box (the reference demo's
+// scene extras, pioneer_knm_env.py:249-261): the external spatial force on body 6, in body coordinates
+__device__ __forceinline__ P3 contact_force(const DynParams& D, const float (&c)[kDof], const float (&s)[kDof], const P3& v5)
+{
+    M3 R = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, Rn;
+    V3 p = {0.f, 0.f, 0.f}, pn;
+    pose_outward<0>(R, p, c[0], s[0], Rn, pn); R = Rn; p = pn;
+    pose_outward<1>(R, p, c[1], s[1], Rn, pn); R = Rn; p = pn;
+    pose_outward<2>(R, p, c[2], s[2], Rn, pn); R = Rn; p = pn;
+    pose_outward<3>(R, p, c[3], s[3], Rn, pn); R = Rn; p = pn;
+    pose_outward<4>(R, p, c[4], s[4], Rn, pn); R = Rn; p = pn;
+    pose_outward<5>(R, p, c[5], s[5], Rn, pn); R = Rn; p = pn;
+    const V3 t = {(float)kTipX, (float)kTipY, (float)kTipZ};
+    const V3 tip = p + mul(R, t);                         // world position of the pointer
+    const V3 vb = lin(v5) + cross(ang(v5), t);
+    const V3 vw = mul(R, vb);                             // world velocity of the pointer
+    V3 F = {0.f, 0.f, 0.f};
+    if (D.has_ground) {
+        const float depth = D.ground_z - tip.z;
+        const float fz = D.ckp * depth - D.ckd * vw.z;
+        if (depth > 0.f && fz > 0.f) F.z += fz;
+    }
+    if (D.has_box) {
+        // signed distance of the pointer centre to the axis-aligned box and its outward normal
+        const V3 dd = {tip.x - D.box_c[0], tip.y - D.box_c[1], tip.z - D.box_c[2]};
+        const V3 q = {fabsf(dd.x) - D.box_h[0], fabsf(dd.y) - D.box_h[1], fabsf(dd.z) - D.box_h[2]};
+        const V3 o = {fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f)};
+        const float out2 = dot(o, o);
+        V3 nrm; float sdf;
+        if (out2 > 0.f) {
+            const float len = sqrtf(out2);
+            sdf = len;
+            nrm = {(dd.x < 0.f ? -o.x : o.x) / len, (dd.y < 0.f ? -o.y : o.y) / len, (dd.z < 0.f ? -o.z : o.z) / len};
+        } else {                                          // inside: out through the nearest face
+            const int km = (q.x >= q.y && q.x >= q.z) ? 0 : (q.y >= q.z ? 1 : 2);
+            sdf = comp(q, km);
+            nrm = {km == 0 ? (dd.x < 0.f ? -1.f : 1.f) : 0.f, km == 1 ? (dd.y < 0.f ? -1.f : 1.f) : 0.f,
+                   km == 2 ? (dd.z < 0.f ? -1.f : 1.f) : 0.f};
+        }
+        const float depth = D.ptr_radius - sdf;
+        const float fn = D.ckp * depth - D.ckd * dot(vw, nrm);
+        if (depth > 0.f && fn > 0.f) F = F + fn * nrm;
+    }
+    const V3 fb = mulT(R, F);                             // R^T F
+    return pack(cross(t, fb), fb);
+}
+
+// qdd = ABA(q, qd, tau); optional contacts on the pointer
 __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const float (&q)[kDof], const float (&qd)[kDof],
                                     const float (&tau)[kDof], float (&qdd)[kDof])
 {
@@ -290,8 +514,8 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
     for (int i = 0; i < kDof; ++i) sincos_bounded(q[i], s[i], c[i]);
 
     // pass 1: body velocities
-    SV v[kDof];
-    const SV v0 = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    P3 v[kDof];
+    const P3 v0 = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     vel_outward<0>(v0, c[0], s[0], qd[0], v[0]);
     vel_outward<1>(v[0], c[1], s[1], qd[1], v[1]);
     vel_outward<2>(v[1], c[2], s[2], qd[2], v[2]);
@@ -299,59 +523,11 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
     vel_outward<4>(v[3], c[4], s[4], qd[4], v[4]);
     vel_outward<5>(v[4], c[5], s[5], qd[5], v[5]);
 
-    // external force on the pointer (body 6 coordinates): penalty contacts with the ground plane
-    // and the static box (the reference demo's scene extras, pioneer_knm_env.py:249-261)
-    SV fext = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    if (D.has_ground || D.has_box) {
-        M3 R = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, Rn;
-        V3 p = {0.f, 0.f, 0.f}, pn;
-        pose_outward<0>(R, p, c[0], s[0], Rn, pn); R = Rn; p = pn;
-        pose_outward<1>(R, p, c[1], s[1], Rn, pn); R = Rn; p = pn;
-        pose_outward<2>(R, p, c[2], s[2], Rn, pn); R = Rn; p = pn;
-        pose_outward<3>(R, p, c[3], s[3], Rn, pn); R = Rn; p = pn;
-        pose_outward<4>(R, p, c[4], s[4], Rn, pn); R = Rn; p = pn;
-        pose_outward<5>(R, p, c[5], s[5], Rn, pn); R = Rn; p = pn;
-        const V3 t = {(float)kTipX, (float)kTipY, (float)kTipZ};
-        const V3 tip = p + mul(R, t);                         // world position of the pointer
-        const V3 vb = v[5].l + cross(v[5].a, t);
-        const V3 vw = mul(R, vb);                             // world velocity of the pointer
-        V3 F = {0.f, 0.f, 0.f};
-        if (D.has_ground) {
-            const float depth = D.ground_z - tip.z;
-            const float fz = D.ckp * depth - D.ckd * vw.z;
-            if (depth > 0.f && fz > 0.f) F.z += fz;
-        }
-        if (D.has_box) {
-            // signed distance of the pointer centre to the axis-aligned box and its outward normal
-            const V3 dd = {tip.x - D.box_c[0], tip.y - D.box_c[1], tip.z - D.box_c[2]};
-            const V3 q = {fabsf(dd.x) - D.box_h[0], fabsf(dd.y) - D.box_h[1], fabsf(dd.z) - D.box_h[2]};
-            const V3 o = {fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f)};
-            const float out2 = dot(o, o);
-            V3 nrm; float sdf;
-            if (out2 > 0.f) {
-                const float len = sqrtf(out2);
-                sdf = len;
-                nrm = {(dd.x < 0.f ? -o.x : o.x) / len, (dd.y < 0.f ? -o.y : o.y) / len, (dd.z < 0.f ? -o.z : o.z) / len};
-            } else {                                          // inside: out through the nearest face
-                const int km = (q.x >= q.y && q.x >= q.z) ? 0 : (q.y >= q.z ? 1 : 2);
-                sdf = comp(q, km);
-                nrm = {km == 0 ? (dd.x < 0.f ? -1.f : 1.f) : 0.f, km == 1 ? (dd.y < 0.f ? -1.f : 1.f) : 0.f,
-                       km == 2 ? (dd.z < 0.f ? -1.f : 1.f) : 0.f};
-            }
-            const float depth = D.ptr_radius - sdf;
-            const float fn = D.ckp * depth - D.ckd * dot(vw, nrm);
-            if (depth > 0.f && fn > 0.f) F = F + fn * nrm;
-        }
-        const V3 fb = mulT(R, F);                             // R^T F
-        fext.a = cross(t, fb);
-        fext.l = fb;
-    }
-
     // pass 2: tip -> base
     DynBody B[kDof];
-    SI IA, IP; SV pA, pP;
+    SIp IA, IP; P3 pA, pP;
     rigid_body<5>(M, v[5], IA, pA);
-    pA.a = pA.a - fext.a; pA.l = pA.l - fext.l;
+    if (D.has_ground || D.has_box) pA = pA - contact_force(D, c, s, v[5]);
     rigid_body<4>(M, v[4], IP, pP);
     aba_inward<5>(IA, pA, v[5], qd[5], tau[5], c[5], s[5], B[5], IP, pP);
     IA = IP; pA = pP; rigid_body<3>(M, v[3], IP, pP);
@@ -366,7 +542,7 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
     aba_inward<0>(IA, pA, v[0], qd[0], tau[0], c[0], s[0], B[0], IP, pP);
 
     // pass 3: base -> tip; gravity as a base acceleration +g along z
-    SV a0 = {{0.f, 0.f, 0.f}, {0.f, 0.f, D.gravity}}, a1;
+    P3 a0 = {{0.f, 0.f}, {0.f, 0.f}, {0.f, D.gravity}}, a1;
     acc_outward<0>(a0, v[0], c[0], s[0], qd[0], B[0], qdd[0], a1); a0 = a1;
     acc_outward<1>(a0, v[1], c[1], s[1], qd[1], B[1], qdd[1], a1); a0 = a1;
     acc_outward<2>(a0, v[2], c[2], s[2], qd[2], B[2], qdd[2], a1); a0 = a1;
