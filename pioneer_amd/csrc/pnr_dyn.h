@@ -572,6 +572,16 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
     for (int p = 0; p < 2; ++p) {
         k0[p] = P.state[2 * e + p]; k1[p] = P.state[n2 + 2 * e + p]; k2[p] = P.state[2 * n2 + 2 * e + p];
     }
+    // dynamics state: every load of the kernel is issued here, before the first wait — with one wave
+    // per SIMD (65 536 envs) nothing else hides a memory round trip
+    float q[kDof], qd[kDof], sc[kNumLinks], fric[kDof], damp[kDof];
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) {
+        q[i] = D.dyn[(long long)i * n + e]; qd[i] = D.dyn[(long long)(6 + i) * n + e];
+        fric[i] = D.dyn[(long long)(23 + i) * n + e]; damp[i] = D.dyn[(long long)(29 + i) * n + e];
+    }
+#pragma unroll
+    for (int l = 0; l < kNumLinks; ++l) sc[l] = RAND ? D.dyn[(long long)(12 + l) * n + e] : 1.0f;
     float a[kDof], v[kDof], r[kDof];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -601,15 +611,6 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
         P.state[2 * n2 + 2 * e + p] = make_float4(r[3 * p + 2], k2[p].y, k2[p].z, k2[p].w);
     }
 
-    // dynamics state
-    float q[kDof], qd[kDof], sc[kNumLinks], fric[kDof], damp[kDof];
-#pragma unroll
-    for (int i = 0; i < kDof; ++i) {
-        q[i] = D.dyn[(long long)i * n + e]; qd[i] = D.dyn[(long long)(6 + i) * n + e];
-        fric[i] = D.dyn[(long long)(23 + i) * n + e]; damp[i] = D.dyn[(long long)(29 + i) * n + e];
-    }
-#pragma unroll
-    for (int l = 0; l < kNumLinks; ++l) sc[l] = RAND ? D.dyn[(long long)(12 + l) * n + e] : 1.0f;
     DynModel M;
     build_model(sc, M);
 
@@ -617,27 +618,29 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
 #pragma unroll
         for (int i = 0; i < kDof; ++i) { q[i] = r[i]; qd[i] = 0.f; }
     }
+    // wave-uniform options folded into the arithmetic once, so the sub-step loop carries no branches:
+    // teleport = no motor torque (gains 0), no torque cap = cap at +inf
+    const float kp = D.teleport ? 0.f : D.kp, kd = D.teleport ? 0.f : D.kd;
+    const float tcap = D.tau_max > 0.f ? D.tau_max : __builtin_inff();
     for (int k = 0; k < D.nsub; ++k) {
         float tau[kDof], qdd[kDof];
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {
-            float tq = 0.f;
-            if (!D.teleport) {
-                tq = D.kp * (r[i] - q[i]) + D.kd * (v[i] - qd[i]);
-                if (D.tau_max > 0.f) tq = fminf(fmaxf(tq, -D.tau_max), D.tau_max);
-            }
+            float tq = kp * (r[i] - q[i]) + kd * (v[i] - qd[i]);
+            tq = fminf(fmaxf(tq, -tcap), tcap);
             tq -= damp[i] * qd[i];
             tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
             tau[i] = tq;
         }
         aba(D, M, q, qd, tau, qdd);
 #pragma unroll
-        for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits
-            qd[i] += qdd[i] * D.dt_sub;
-            q[i] += qd[i] * D.dt_sub;
+        for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits (selects, no branches)
             const float hi = limit_hi(i), lo = limit_lo(i);
-            if (q[i] > hi) { q[i] = hi; if (qd[i] > 0.f) qd[i] = 0.f; }
-            if (q[i] < lo) { q[i] = lo; if (qd[i] < 0.f) qd[i] = 0.f; }
+            const float qdn = qd[i] + qdd[i] * D.dt_sub;
+            const float qn = q[i] + qdn * D.dt_sub;
+            const bool over = qn > hi, under = qn < lo;
+            q[i] = over ? hi : (under ? lo : qn);
+            qd[i] = ((over && qdn > 0.f) || (under && qdn < 0.f)) ? 0.f : qdn;
         }
     }
 #pragma unroll
