@@ -9,7 +9,7 @@ Pioneer-arm envs on one GPU.  For N>1 every rank steps its own 65 536-env shard
 (global env ids rank*65536..; no data-path collective — envs are independent),
 so scaling is "weak".  Extra legs in the same JSON line (never part of `value`): "fused_rollout"
 (pnr_rollout, T steps per launch), "large_batch" (262 144 envs per launch), at N>1 "strong_scaling"
-(65 536 envs IN TOTAL sharded over the ranks) and "ppo_loop" (BASELINE config[2] at N=1, config[3] at
+(65 536 envs IN TOTAL sharded over the ranks), "dynamics_randomized" (BASELINE config[4]) and "ppo_loop" (BASELINE config[2] at N=1, config[3] at
 N>1: the full rollout+learn loop with the gradient all-reduce over RCCL), "cpu_baseline" at N=1.
 Launch for N>1:
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -48,6 +48,8 @@ def parse_args():
                     help="also time pnr_step on this many envs per GPU and report it as \"large_batch\" (0 = skip)")
     ap.add_argument("--strong-total", type=int, default=65536,
                     help="N>1: also time this many envs IN TOTAL sharded over the ranks, reported as \"strong_scaling\" (0 = skip)")
+    ap.add_argument("--dynamic-leg", type=int, default=1,
+                    help="also time dynamics mode with per-env randomisation (BASELINE config[4]) as \"dynamics_randomized\"")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the per-step launches from a hipGraph")
     ap.add_argument("--fused-leg", type=int, default=32,
                     help="also report the fused pnr_rollout rate with this many steps per launch (0 = skip)")
@@ -278,12 +280,13 @@ def main():
                  "frac": fb / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  "note": "pnr_rollout: same kernel, T steps per launch with open-loop actions; state stays in registers"}
 
-    def side_leg(nl, id_off, k, warm, note):
-        """pnr_step on a separate env batch of nl envs per GPU (same kernel as `value`): wall time is the
-        max over ranks between barriers, avg_launch_ms is rank 0's HIP-event timing."""
-        lenv = PioneerVectorEnv(nl, device=dev, seed=0, env_id_offset=id_off,
+    def side_leg(nl, id_off, k, warm, note, bytes_per_env_step=BYTES_PER_ENV_STEP, sim=None, **engine_kw):
+        """pnr_step on a separate env batch of nl envs per GPU: wall time is the max over ranks between
+        barriers, avg_launch_ms is rank 0's HIP-event timing."""
+        lenv = PioneerVectorEnv(nl, device=dev, seed=0, env_id_offset=id_off, simulation_config=sim,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
-                                                           obs_layout=args.obs_layout, action_layout=args.action_layout))
+                                                           obs_layout=args.obs_layout, action_layout=args.action_layout,
+                                                           **engine_kw))
         lenv.reset()
         lring = 8 if nl >= 131072 else 32
         lacts = (torch.rand((4,) + tuple(lenv.action_shape), generator=g, device=dev) * 2 - 1) * \
@@ -318,14 +321,24 @@ def main():
         return {"envs_per_gpu": nl, "steps": k, "avg_launch_ms": lms, "ms_per_step": el / k * 1e3,
                 "value": float(nl) * world * k / el, "unit": "env-steps/s",
                 "env_steps_per_s_per_gpu": nl / (lms * 1e-3),
-                "achieved_GBps": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9,
-                "frac": BYTES_PER_ENV_STEP * nl / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "note": note}
+                "achieved_GBps": bytes_per_env_step * nl / (lms * 1e-3) / 1e9,
+                "frac": bytes_per_env_step * nl / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "note": note}
 
     # the same kernel on a larger batch per launch (amortises the ~3.5 us launch + first-load floor)
     large = None
     if T == 1 and args.large_envs > n and args.mode == "kinematic":
         large = side_leg(args.large_envs, world * n + rank * args.large_envs, 256, 32,
                          "pnr_step, one launch per step, same kernel as `value`; avg_launch_ms/frac from rank 0's HIP events")
+
+    # BASELINE config[4]: dynamics mode (ABA + PD + limits, 10 sub-steps) with per-env randomised link
+    # masses / friction / damping; parity unpinned (the reference never exercises dynamics).  VALU-bound:
+    # `frac` is still quoted against HBM with SURVEY 8(d)'s 842 B per env-step.
+    dynamic = None
+    if T == 1 and args.mode == "kinematic" and args.dynamic_leg:
+        dynamic = side_leg(n, (2 * world + rank) * n + world * args.large_envs, 512, 64,
+                           "mode=dynamic, randomize=True, gravity 9.81: dyn_substeps_kernel (one env per lane, packed fp32 "
+                           "ABA, VALU-bound) + step_kernel<DYN>; algorithmic bytes 842 B per env-step",
+                           bytes_per_env_step=842, sim=SimulationConfig(gravity=9.81), mode="dynamic", randomize=True)
 
     # BASELINE config[3] read literally: 65 536 envs IN TOTAL, sharded over the ranks (strong scaling;
     # 8 192 envs per GPU at N=8, where one launch is shorter than the launch floor)
@@ -403,6 +416,8 @@ def main():
             out["fused_rollout"] = fused
         if large:
             out["large_batch"] = large
+        if dynamic:
+            out["dynamics_randomized"] = dynamic
         if strong:
             out["strong_scaling"] = strong
         if ppo_loop:
