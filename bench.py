@@ -336,8 +336,8 @@ def main():
     dynamic = None
     if T == 1 and args.mode == "kinematic" and args.dynamic_leg:
         dynamic = side_leg(n, (2 * world + rank) * n + world * args.large_envs, 512, 64,
-                           "mode=dynamic, randomize=True, gravity 9.81: dyn_substeps_kernel (one env per lane, packed fp32 "
-                           "ABA, VALU-bound) + step_kernel<DYN>; algorithmic bytes 842 B per env-step",
+                           "mode=dynamic, randomize=True, gravity 9.81: dyn_step_kernel (sub-steps one env per lane with packed "
+                           "fp32 ABA, VALU-bound; then lane pairs finish reward/obs); algorithmic bytes 842 B per env-step",
                            bytes_per_env_step=842, sim=SimulationConfig(gravity=9.81), mode="dynamic", randomize=True)
 
     # BASELINE config[3] read literally: 65 536 envs IN TOTAL, sharded over the ranks (strong scaling;

@@ -34,8 +34,8 @@ namespace pnr {
 // step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps.
 // One wave = 32 envs (lane pair per env), one wave per workgroup.
 // ---------------------------------------------------------------------------------
-template <bool OBS_EM, bool ACT_EM, bool DYN>
-__global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynParams D)
+template <bool OBS_EM, bool ACT_EM>
+__global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
 {
     __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
 
@@ -59,7 +59,6 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
     // tiles.  The NEXT tile's state and first action are requested before the current tile is
     // processed, so they never queue behind this CU's own obs stores.
     const auto load_act0 = [&](long long e_, float (&a_)[kJpl]) {
-        if (DYN) { a_[0] = a_[1] = a_[2] = 0.f; return; }
         if (ACT_EM) {
             const float* a3 = P.actions + e_ * kDof + kJpl * p;         // 12 B per lane, lanes contiguous
             a_[0] = a3[0]; a_[1] = a3[1]; a_[2] = a3[2];
@@ -107,8 +106,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
     if (P.diag & 16) { if (valid) P.reward[e] = s.pot; continue; }   // launch + state-load floor
 
     for (int t = 0; t < P.T; ++t) {
-        LaneState o;     // what reward / obs see: the kinematic state, or the simulated q, qd in dynamics mode
-        if (!DYN) {
+        {
             // -- action of this step (this lane's three joints) ----------------------
             // this step's action was requested one step (or one tile) ago; request the next one now,
             // ahead of this step's obs stores (VMEM ops of a wave retire in order)
@@ -131,24 +129,11 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
             }
 #pragma unroll
             for (int i = 0; i < kJpl; ++i) s.a[i] = act[i];           // :144 (quirk Q1)
-            o = s;
-        } else {
-            // dyn_substeps_kernel already integrated the command and ran the sub-steps
-            o = s;
-#pragma unroll
-            for (int i = 0; i < kJpl; ++i) {
-                const float qi = valid ? D.dyn[(long long)(kJpl * p + i) * n + e] : 0.f;
-                const float qdi = valid ? D.dyn[(long long)(6 + kJpl * p + i) * n + e] : 0.f;
-                o.r[i] = qi;
-                // teleport = reference semantics: obs shows the env's own v (pioneer_knm_env.py:202)
-                o.v[i] = D.teleport ? s.v[i] : qdi;
-            }
         }
         s.step += 1;                                                  // bullet_env.py:193
-        o.step = s.step;
 
         Pose q;
-        compute_pose(o, p, q);
+        compute_pose(s, p, q);
 
         // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
         const float old_pot = s.pot;
@@ -160,11 +145,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
         const float rw = (r_pot + r_step) + r_done;                   // :165
         s.pot = pot;
         // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
-        bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
-        // dynamics mode: a lane whose simulation diverged (non-finite pose) is cut like a time-out, so
-        // auto-reset recovers it instead of carrying NaNs forever (kinematic mode keeps the reference's
-        // NaN-propagating behaviour)
-        if (DYN && !(q.dist == q.dist && __builtin_fabsf(q.dist) <= 3.0e38f)) trunc = !done;
+        const bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
 
         if (valid && p == 0) {
             const long long o = (long long)t * n + e;
@@ -176,12 +157,9 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
 
         // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
         // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
-        o.pot = pot;
         if (P.auto_reset && (done || trunc)) {
             reset_env(P, K, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
-            if (DYN && valid) dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);
-            o = s;
-            compute_pose(o, p, q);
+            compute_pose(s, p, q);
         }
 
         // state goes out before the obs is packed: its stores drain under the LDS emit
@@ -192,18 +170,174 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P, const DynP
         if (t > 0 || !first_tile) wave_lds_sync();   // previous flush done before the tile is rewritten
         if (OBS_EM) {
             SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-            if (!diag_noemit) emit_obs<false>(K, o, q, p, sink);
+            if (!diag_noemit) emit_obs<false>(K, s, q, p, sink);
             wave_lds_sync();
             if (!diag_noflush) flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
         } else {
             SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-            emit_obs<false>(K, o, q, p, sink);
+            emit_obs<false>(K, s, q, p, sink);
             wave_lds_sync();
             flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
         }
     }
     first_tile = false;
     }   // tile loop
+}
+
+// ---------------------------------------------------------------------------------
+// dynamics-mode step: ONE launch per env-step.  A workgroup is one wave and owns 64 envs.
+//   phase A  one env per lane: command integration + the ABA sub-steps (pnr_dyn.h), results handed
+//            over through LDS in the HBM record layout;
+//   phase B  the lanes regroup as pairs (as in step_kernel) and finish two 32-env tiles: reward,
+//            TimeLimit, auto-reset, state and q/qd write-back, observation through the LDS tile.
+// The hand-off area is the head of the obs tile: both tiles' records are read into registers before
+// the first observation is packed.
+// ---------------------------------------------------------------------------------
+constexpr int kDynEnvsPerWg = kWave;                       // phase A: one env per lane
+constexpr int kHandRecFloats = 3 * 2 * kDynEnvsPerWg * 4;  // three float4 planes of 2 records per env
+constexpr int kHandFloats = kHandRecFloats + 2 * kDof * kDynEnvsPerWg;
+static_assert(kHandFloats <= kTileFloats, "the hand-off area must fit into the obs tile it aliases");
+
+template <bool OBS_EM>
+__device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParams& D, const LaneConsts& K, const RawState& raw,
+                                                const float (&dq)[kJpl], const float (&dqd)[kJpl], float* tile,
+                                                long long tile0, int lane, bool tile_in_use)
+{
+    const int p = lane & 1, el = lane >> 1;
+    const long long n = P.n;
+    const long long e = tile0 + el;
+    const bool valid = e < n;               // the pair shares `valid`, so DPP partners are live
+    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
+
+    LaneState s;
+    unpack_state(raw, p, s);                // all-zero records for lanes past the end
+    LaneState o = s;                        // what reward / obs see: the simulated q, qd
+#pragma unroll
+    for (int i = 0; i < kJpl; ++i) {
+        o.r[i] = dq[i];
+        // teleport = reference semantics: obs shows the env's own v (pioneer_knm_env.py:202)
+        o.v[i] = D.teleport ? s.v[i] : dqd[i];
+    }
+    s.step += 1;                                                  // bullet_env.py:193
+    o.step = s.step;
+
+    Pose q;
+    compute_pose(o, p, q);
+
+    // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
+    const float old_pot = s.pot;
+    const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
+    const bool done = q.dist < P.done_dist;                       // :160
+    const float r_pot = pot - old_pot;
+    const float r_step = -P.penalty;
+    const float r_done = done ? P.award_done : 0.0f;
+    const float rw = (r_pot + r_step) + r_done;                   // :165
+    s.pot = pot;
+    // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
+    bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
+    // a lane whose simulation diverged (non-finite pose) is cut like a time-out, so auto-reset recovers
+    // it instead of carrying NaNs forever (kinematic mode keeps the reference's NaN-propagating behaviour)
+    if (!(q.dist == q.dist && __builtin_fabsf(q.dist) <= 3.0e38f)) trunc = !done;
+
+    if (valid && p == 0) {
+        stream_store(P.reward + e, rw);
+        stream_store(P.done + e, (uint8_t)done);
+        if (P.trunc) stream_store(P.trunc + e, (uint8_t)trunc);
+        if (P.info) stream_store(reinterpret_cast<float4*>(P.info) + e, make_float4(r_pot, r_step, r_done, q.dist));
+    }
+
+    // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
+    // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
+    o.pot = pot;
+    const bool redraw = P.auto_reset && (done || trunc);
+    if (redraw) {
+        reset_env(P, K, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
+        if (valid) dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);   // q = r, qd = 0, new draws
+        o = s;
+        compute_pose(o, p, q);
+    }
+    if (valid) {
+        store_state(P.state, n, 2 * tile0 + lane, p, s);
+        if (!redraw) {
+#pragma unroll
+            for (int i = 0; i < kJpl; ++i) {
+                D.dyn[(long long)(kJpl * p + i) * n + e] = dq[i];
+                D.dyn[(long long)(6 + kJpl * p + i) * n + e] = dqd[i];
+            }
+        }
+    }
+
+    // -- observe() ----------------------------------------------------------------
+    if (tile_in_use) wave_lds_sync();       // previous flush done before the tile is rewritten
+    if (OBS_EM) {
+        SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
+        emit_obs<false>(K, o, q, p, sink);
+        wave_lds_sync();
+        flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
+    } else {
+        SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
+        emit_obs<false>(K, o, q, p, sink);
+        wave_lds_sync();
+        flush_feature_tile(tile, P.obs + tile0, n, nvalid, lane);
+    }
+}
+
+template <bool OBS_EM, bool ACT_EM, bool RAND>
+__global__ __launch_bounds__(kWave) void dyn_step_kernel(const KParams P, const DynParams D)
+{
+    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+    const int lane = threadIdx.x;
+    const long long n = P.n;
+    const long long base = (long long)blockIdx.x * kDynEnvsPerWg;
+    float4* hrec = reinterpret_cast<float4*>(tile);               // [3][2 * 64] records, index 2 * env + p
+    float* hq = tile + kHandRecFloats;                            // [12][64]: q then qd
+
+    // ---- phase A: one env per lane
+    {
+        const long long e = base + lane;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 k0[2] = {z4, z4}, k1[2] = {z4, z4}, k2[2] = {z4, z4};
+        float q[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qd[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (e < n) dyn_substeps_lane<ACT_EM, RAND>(P, D, e, k0, k1, k2, q, qd);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            hrec[2 * lane + p] = k0[p];
+            hrec[2 * kDynEnvsPerWg + 2 * lane + p] = k1[p];
+            hrec[4 * kDynEnvsPerWg + 2 * lane + p] = k2[p];
+        }
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) {
+            hq[i * kDynEnvsPerWg + lane] = q[i];
+            hq[(kDof + i) * kDynEnvsPerWg + lane] = qd[i];
+        }
+    }
+    wave_lds_sync();
+
+    // ---- phase B: lane pairs; both tiles' hand-off records leave LDS before the tile is reused
+    const int p = lane & 1, el = lane >> 1;
+    RawState raw0, raw1;
+    float dq0[kJpl], dqd0[kJpl], dq1[kJpl], dqd1[kJpl];
+    {
+        const int r0 = lane, r1 = 2 * kEnvsPerWave + lane;        // record 2 * env + p of env el / env 32 + el
+        raw0 = {hrec[r0], hrec[2 * kDynEnvsPerWg + r0], hrec[4 * kDynEnvsPerWg + r0]};
+        raw1 = {hrec[r1], hrec[2 * kDynEnvsPerWg + r1], hrec[4 * kDynEnvsPerWg + r1]};
+#pragma unroll
+        for (int i = 0; i < kJpl; ++i) {
+            dq0[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + el];
+            dqd0[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + el];
+            dq1[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave + el];
+            dqd1[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave + el];
+        }
+    }
+    wave_lds_sync();
+    const LaneConsts K = lane_consts(p);
+    // the 36 constant obs entries of this lane's tile slots: once per kernel
+    if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K, sink); }
+    else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K, sink); }
+
+    dyn_finish_tile<OBS_EM>(P, D, K, raw0, dq0, dqd0, tile, base, lane, false);
+    if (base + kEnvsPerWave < n)
+        dyn_finish_tile<OBS_EM>(P, D, K, raw1, dq1, dqd1, tile, base + kEnvsPerWave, lane, true);
 }
 
 // ---------------------------------------------------------------------------------
@@ -645,11 +779,11 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     const DynParams& D = h->dbase;
     const bool oem = h->cfg.obs_layout == PNR_ENV_MAJOR, aem = h->cfg.action_layout == PNR_ENV_MAJOR;
     if (h->cfg.mode == PNR_MODE_DYNAMIC) {
-        // two launches per step: the one-env-per-lane ABA sub-steps, then the pair kernel for
-        // reward / TimeLimit / auto-reset / obs on the simulated joints
-        static int dyn_block = -1;
-        if (dyn_block < 0) { const char* e_ = getenv("PNR_DYN_BLOCK"); dyn_block = e_ ? atoi(e_) : kWave; if (dyn_block < 1 || dyn_block > 1024) dyn_block = kWave; }
-        const dim3 gridA((unsigned)((h->n + dyn_block - 1) / dyn_block)), blockA(dyn_block);
+        // one launch per step: dyn_step_kernel runs the sub-steps one env per lane, then finishes the
+        // step (reward / TimeLimit / auto-reset / obs) as lane pairs
+        const dim3 gridD((unsigned)((h->n + kDynEnvsPerWg - 1) / kDynEnvsPerWg));
+        // link scales differ from 1 only under randomisation (or after pnr_set_dyn_state, which marks it)
+        const bool rnd = h->cfg.randomize || h->dyn_set;
         for (int t = 0; t < T; ++t) {
             KParams Pt = P;
             Pt.T = 1;
@@ -658,22 +792,23 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
             Pt.reward = reward + (long long)t * h->n;
             Pt.done = done + (long long)t * h->n;
             Pt.trunc = truncated ? truncated + (long long)t * h->n : nullptr;
-            // link scales differ from 1 only under randomisation (or after pnr_set_dyn_state, which marks it)
-            const bool rnd = h->cfg.randomize || h->dyn_set;
-            if (aem && rnd) hipLaunchKernelGGL((dyn_substeps_kernel<true, true>), gridA, blockA, 0, st, Pt, D, 0);
-            else if (aem) hipLaunchKernelGGL((dyn_substeps_kernel<true, false>), gridA, blockA, 0, st, Pt, D, 0);
-            else if (rnd) hipLaunchKernelGGL((dyn_substeps_kernel<false, true>), gridA, blockA, 0, st, Pt, D, 0);
-            else hipLaunchKernelGGL((dyn_substeps_kernel<false, false>), gridA, blockA, 0, st, Pt, D, 0);
-            if (oem) hipLaunchKernelGGL((step_kernel<true, true, true>), grid, block, 0, st, Pt, D);
-            else hipLaunchKernelGGL((step_kernel<false, true, true>), grid, block, 0, st, Pt, D);
+#define PNR_DYN_LAUNCH(O, A, R) hipLaunchKernelGGL((dyn_step_kernel<O, A, R>), gridD, block, 0, st, Pt, D)
+            if (oem) {
+                if (aem) { if (rnd) PNR_DYN_LAUNCH(true, true, true); else PNR_DYN_LAUNCH(true, true, false); }
+                else { if (rnd) PNR_DYN_LAUNCH(true, false, true); else PNR_DYN_LAUNCH(true, false, false); }
+            } else {
+                if (aem) { if (rnd) PNR_DYN_LAUNCH(false, true, true); else PNR_DYN_LAUNCH(false, true, false); }
+                else { if (rnd) PNR_DYN_LAUNCH(false, false, true); else PNR_DYN_LAUNCH(false, false, false); }
+            }
+#undef PNR_DYN_LAUNCH
         }
         HIP_TRY(h, hipGetLastError());
         return PNR_OK;
     }
-    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true, false>), grid, block, 0, st, P, D);
-    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false, false>), grid, block, 0, st, P, D);
-    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true, false>), grid, block, 0, st, P, D);
-    else hipLaunchKernelGGL((step_kernel<false, false, false>), grid, block, 0, st, P, D);
+    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, st, P);
+    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P);
+    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
 }

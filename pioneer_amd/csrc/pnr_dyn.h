@@ -552,29 +552,28 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
 }
 
 // ---------------------------------------------------------------------------------
-// kernel A: kinematic command integration (the parity-mode integrator) + nsub
-// sub-steps of ABA + PD.  One env per lane.  Leaves step_index / reward / obs to
-// step_kernel<..., DYN = true>.
+// Phase A of a dynamics step for ONE env in this lane: kinematic command integration (the
+// parity-mode integrator) + nsub sub-steps of ABA + PD.  In: the env's two state records as they
+// lie in HBM (k0/k1/k2[p], see load_state_raw).  Out: the records with a, v, r updated, and the
+// simulated q, qd.  Nothing is stored here: pnr::dyn_step_kernel hands the results to its pair
+// lanes through LDS.
 // ---------------------------------------------------------------------------------
 // RAND = per-env link scales (domain randomisation): loaded from the dyn words; otherwise every scale
 // is 1 and the model folds into literals.
 template <bool ACT_EM, bool RAND>
-__global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, const DynParams D, int t)
+__device__ __forceinline__ void dyn_substeps_lane(const KParams& P, const DynParams& D, long long e,
+                                                  float4 (&k0)[2], float4 (&k1)[2], float4 (&k2)[2],
+                                                  float (&q)[kDof], float (&qd)[kDof])
 {
     const long long n = P.n;
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-
-    // kinematic state: both half-records of this env
     const long long n2 = 2 * n;
-    float4 k0[2], k1[2], k2[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         k0[p] = P.state[2 * e + p]; k1[p] = P.state[n2 + 2 * e + p]; k2[p] = P.state[2 * n2 + 2 * e + p];
     }
-    // dynamics state: every load of the kernel is issued here, before the first wait — with one wave
-    // per SIMD (65 536 envs) nothing else hides a memory round trip
-    float q[kDof], qd[kDof], sc[kNumLinks], fric[kDof], damp[kDof];
+    // dynamics state: every load is issued here, before the first wait — with one wave per SIMD
+    // (65 536 envs) nothing else hides a memory round trip
+    float sc[kNumLinks], fric[kDof], damp[kDof];
 #pragma unroll
     for (int i = 0; i < kDof; ++i) {
         q[i] = D.dyn[(long long)i * n + e]; qd[i] = D.dyn[(long long)(6 + i) * n + e];
@@ -590,14 +589,13 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
         r[3 * p + 2] = k2[p].x;
     }
     float act[kDof];
-    const float* A = P.actions + (long long)t * n * kDof;
     if (ACT_EM) {
-        const float2* a2 = reinterpret_cast<const float2*>(A + e * kDof);
+        const float2* a2 = reinterpret_cast<const float2*>(P.actions + e * kDof);
         const float2 x0 = a2[0], x1 = a2[1], x2 = a2[2];
         act[0] = x0.x; act[1] = x0.y; act[2] = x1.x; act[3] = x1.y; act[4] = x2.x; act[5] = x2.y;
     } else {
 #pragma unroll
-        for (int i = 0; i < kDof; ++i) act[i] = A[(long long)i * n + e];
+        for (int i = 0; i < kDof; ++i) act[i] = P.actions[(long long)i * n + e];
     }
 #pragma unroll
     for (int i = 0; i < kDof; ++i) {
@@ -606,9 +604,9 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        P.state[2 * e + p] = make_float4(a[3 * p], a[3 * p + 1], a[3 * p + 2], v[3 * p]);
-        P.state[n2 + 2 * e + p] = make_float4(v[3 * p + 1], v[3 * p + 2], r[3 * p], r[3 * p + 1]);
-        P.state[2 * n2 + 2 * e + p] = make_float4(r[3 * p + 2], k2[p].y, k2[p].z, k2[p].w);
+        k0[p] = make_float4(a[3 * p], a[3 * p + 1], a[3 * p + 2], v[3 * p]);
+        k1[p] = make_float4(v[3 * p + 1], v[3 * p + 2], r[3 * p], r[3 * p + 1]);
+        k2[p].x = r[3 * p + 2];
     }
 
     DynModel M;
@@ -643,11 +641,6 @@ __global__ __launch_bounds__(256) void dyn_substeps_kernel(const KParams P, cons
             qd[i] = ((over && qdn > 0.f) || (under && qdn < 0.f)) ? 0.f : qdn;
         }
     }
-#pragma unroll
-    for (int i = 0; i < kDof; ++i) {
-        D.dyn[(long long)i * n + e] = q[i];
-        D.dyn[(long long)(6 + i) * n + e] = qd[i];
-    }
 }
 
 // reset of the dynamics words for this lane's joints (called by the pair kernels after reset_env):
@@ -661,7 +654,7 @@ __device__ __forceinline__ void dyn_reset_lane(const KParams& P, const DynParams
         D.dyn[(long long)(kJpl * p + i) * n + e] = s.r[i];
         D.dyn[(long long)(6 + kJpl * p + i) * n + e] = 0.f;
     }
-    float u[24];
+    float u[24] = {};
     if (D.randomize) {
 #pragma unroll
         for (uint32_t b = 0; b < 6; ++b) {
@@ -680,7 +673,11 @@ __device__ __forceinline__ void dyn_reset_lane(const KParams& P, const DynParams
 #pragma unroll
     for (int i = 0; i < kJpl; ++i) {
         const int j = kJpl * p + i;
-        const float uf = p ? u[11 + kJpl + i] : u[11 + i], ud = p ? u[17 + kJpl + i] : u[17 + i];
+        // both candidates become plain register values first: left as `p ? u[a] : u[b]`, LLVM folds the
+        // select into the address and the whole array is demoted to scratch (cf. lane_consts)
+        float uf0 = u[11 + i], uf1 = u[11 + kJpl + i], ud0 = u[17 + i], ud1 = u[17 + kJpl + i];
+        asm volatile("" : "+v"(uf0), "+v"(uf1), "+v"(ud0), "+v"(ud1));
+        const float uf = p ? uf1 : uf0, ud = p ? ud1 : ud0;
         D.dyn[(long long)(23 + j) * n + e] = D.randomize ? (float)(D.fric_lo + D.fric_span * (double)uf) : D.joint_friction;
         D.dyn[(long long)(29 + j) * n + e] = D.randomize ? (float)(D.damp_lo + D.damp_span * (double)ud) : D.joint_damping;
     }
