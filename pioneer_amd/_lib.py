@@ -101,7 +101,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libpioneer_amd.so")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+           "-ffp-contract=off", "-fno-slp-vectorize",
+           "-mllvm", "-amdgpu-kernarg-preload-count=16",     # leading scalar kernel args arrive preloaded in SGPRs
+           "-Wall", "-Wno-unused-function",
            "-o", LIB_PATH, os.path.join(CSRC, "pnr_api.hip")]
     if verbose:
         print(" ".join(cmd), flush=True)

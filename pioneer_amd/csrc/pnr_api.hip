@@ -34,16 +34,19 @@ namespace pnr {
 // step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps.
 // One wave = 32 envs (lane pair per env), one wave per workgroup.
 // ---------------------------------------------------------------------------------
+// The three leading scalar parameters repeat P.state / P.actions / P.n: plain leading arguments are
+// preloaded into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count), so the first
+// state and action loads do not wait for a kernarg fetch; the by-value struct is fetched behind them.
 template <bool OBS_EM, bool ACT_EM>
-__global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
+__global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_, const float* __restrict__ actions_,
+                                                     const long long n_, const KParams P)
 {
     __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
 
-    if (P.diag & 64) return;                // empty-launch floor
     const int lane = threadIdx.x;
     const int p = lane & 1;                 // which half of the env's joints
     const int el = lane >> 1;               // env within the wave's tile
-    const long long n = P.n;
+    const long long n = n_;
     const long long ntiles = (n + kEnvsPerWave - 1) / kEnvsPerWave;
 
     // PNR_DIAG timing-only ablations (outputs are wrong when set; see DESIGN.md "Where the time goes")
@@ -60,11 +63,11 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
     // processed, so they never queue behind this CU's own obs stores.
     const auto load_act0 = [&](long long e_, float (&a_)[kJpl]) {
         if (ACT_EM) {
-            const float* a3 = P.actions + e_ * kDof + kJpl * p;         // 12 B per lane, lanes contiguous
+            const float* a3 = actions_ + e_ * kDof + kJpl * p;         // 12 B per lane, lanes contiguous
             a_[0] = a3[0]; a_[1] = a3[1]; a_[2] = a3[2];
         } else {
 #pragma unroll
-            for (int i = 0; i < kJpl; ++i) a_[i] = P.actions[(long long)(kJpl * p + i) * n + e_];
+            for (int i = 0; i < kJpl; ++i) a_[i] = actions_[(long long)(kJpl * p + i) * n + e_];
         }
     };
 
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
     RawState raw = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float act0[kJpl] = {0.f, 0.f, 0.f};
     if (tix < ntiles && tix * kEnvsPerWave + el < n) {
-        raw = load_state_raw(P.state, n, 2 * tix * kEnvsPerWave + lane);
+        raw = load_state_raw(state_, n, 2 * tix * kEnvsPerWave + lane);
         load_act0(tix * kEnvsPerWave + el, act0);
     }
     bool first_tile = true;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
     {
         const long long nt = tix + gridDim.x;
         if (nt < ntiles && nt * kEnvsPerWave + el < n) {
-            raw = load_state_raw(P.state, n, 2 * nt * kEnvsPerWave + lane);
+            raw = load_state_raw(state_, n, 2 * nt * kEnvsPerWave + lane);
             load_act0(nt * kEnvsPerWave + el, act0);
         } else {
             raw = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
             // ahead of this step's obs stores (VMEM ops of a wave retire in order)
             float act[kJpl] = {act_first[0], act_first[1], act_first[2]};
             if (t + 1 < P.T && valid) {
-                const float* A = P.actions + (long long)(t + 1) * n * kDof;
+                const float* A = actions_ + (long long)(t + 1) * n * kDof;
                 if (ACT_EM) {
                     const float* a3 = A + e * kDof + kJpl * p;
                     act_first[0] = a3[0]; act_first[1] = a3[1]; act_first[2] = a3[2];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const KParams P)
         }
 
         // state goes out before the obs is packed: its stores drain under the LDS emit
-        if (t == P.T - 1 && valid && !diag_nostate) store_state(P.state, n, rec, p, s);
+        if (t == P.T - 1 && valid && !diag_nostate) store_state(state_, n, rec, p, s);
 
         // -- observe() ----------------------------------------------------------------
         float* obs_t = P.obs + (long long)t * n * kObsDim;
@@ -805,10 +808,10 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
         HIP_TRY(h, hipGetLastError());
         return PNR_OK;
     }
-    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, st, P);
-    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P);
-    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P);
+    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, st, P.state, P.actions, P.n, P);
+    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P.state, P.actions, P.n, P);
+    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P.state, P.actions, P.n, P);
+    else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P.state, P.actions, P.n, P);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
 }
