@@ -112,6 +112,26 @@ class MeanStdFilter:
             y = torch.clamp(y, -self.clip, self.clip)
         return torch.where(self.n < 2, x, y)      # identity until two samples exist (no host sync)
 
+    # The statistics only change at sync(): the rollout prepares shift / scale / clip vectors once
+    # (in place, float32) and applies them with three kernels per step instead of a dozen.
+    def prepare(self) -> None:
+        if not hasattr(self, "_loc"):
+            d, dev = self.mean.numel(), self.mean.device
+            self._loc = torch.zeros(d, device=dev); self._inv = torch.ones(d, device=dev)
+            self._lo = torch.empty(d, device=dev); self._hi = torch.empty(d, device=dev)
+        ident = self.n < 2                                   # identity until two samples exist (no host sync)
+        clip = self.clip if self.clip else float("inf")
+        self._loc.copy_(torch.where(ident, torch.zeros_like(self.mean), self.mean))
+        self._inv.copy_(torch.where(ident, torch.ones_like(self.mean), 1.0 / (self.std + 1e-8)))
+        self._hi.copy_(torch.where(ident, torch.full_like(self.mean, float("inf")), torch.full_like(self.mean, clip)))
+        self._lo.copy_(-self._hi)
+
+    def apply_(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """out = clip((x - mean) / (std + 1e-8)) with the vectors of the last prepare()."""
+        torch.sub(x, self._loc, out=out)
+        out.mul_(self._inv)
+        return torch.clamp(out, min=self._lo, max=self._hi, out=out)
+
     def state_dict(self):
         return {"n": self.n, "mean": self.mean, "m2": self.m2}
 
@@ -122,6 +142,8 @@ class MeanStdFilter:
 class NoFilter:
     def observe(self, x): pass
     def sync(self): pass
+    def prepare(self): pass
+    def apply_(self, x, out): return out.copy_(x)
     def __call__(self, x): return x
     def state_dict(self): return {}
     def load_state_dict(self, sd): pass
@@ -204,9 +226,55 @@ class ActorCritic(nn.Module):
         appended to input and weight on the fly, so the parameters are the reference's."""
         first = net[0]
         h = _LinearSplitK.apply(x_pad, nn.functional.pad(first.weight, (0, pad)), first.bias)
-        for layer in list(net)[1:]:
+        layers = list(net)[1:]
+        for layer in layers[:-1]:
             h = _LinearSplitK.apply(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
-        return h
+        # the heads (12 and 1 output rows) run as 16-row GEMMs: on this BLAS library a bf16 GEMM + bias with
+        # a 1- or 12-wide output corrupted memory when replayed from a hipGraph (NaNs in unrelated tensors)
+        head = layers[-1]
+        rp = (-head.out_features) % 16
+        out = _LinearSplitK.apply(h, nn.functional.pad(head.weight, (0, 0, 0, rp)), nn.functional.pad(head.bias, (0, rp)))
+        return out[:, :head.out_features]
+
+    # -- no-grad inference on cached weights (the sampling loop) ----------------------------------
+    # The rollout runs the nets T times on unchanged parameters: the K-padded, compute-dtype copies of the
+    # weights are made once per rollout (in place, so a captured hipGraph keeps using them) instead of
+    # ~14 pad / cast kernels per net and step.  Same GEMMs on the same values as forward().
+    def refresh_inference_cache(self, amp_bf16: bool) -> None:
+        dt = torch.bfloat16 if (amp_bf16 and next(self.parameters()).is_cuda) else torch.float32
+        cache = getattr(self, "_icache", None)
+        if cache is None or cache["dtype"] != dt:
+            cache = {"dtype": dt, "nets": []}
+            for net in (self.policy, self.value):
+                lins = [l for l in net if isinstance(l, nn.Linear)]
+                pad = (-lins[0].in_features) % 16
+                dev = lins[0].weight.device
+                # every cached matrix is [rows padded to 16, K padded to 16]: the zero rows / columns cost nothing
+                # and keep the BLAS library on its aligned kernels (the 1-row value head is the odd one out)
+                p16 = lambda n: n + (-n) % 16                                  # noqa: E731
+                ws = [torch.zeros((p16(l.out_features), l.in_features + (pad if i == 0 else 0)), dtype=dt, device=dev)
+                      for i, l in enumerate(lins)]
+                bs = [torch.zeros(p16(l.out_features), dtype=dt, device=dev) for l in lins]
+                cache["nets"].append((lins, ws, bs))
+            self._icache = cache
+        with torch.no_grad():
+            for lins, ws, bs in cache["nets"]:
+                for l, w, b in zip(lins, ws, bs):
+                    w[:l.out_features, :l.in_features].copy_(l.weight)
+                    b[:l.out_features].copy_(l.bias)
+
+    @torch.no_grad()
+    def forward_cached(self, x_pad):
+        """x_pad: [N, 144] in the cache's dtype (zero pad columns).  Returns (head [N, 12], v [N, 1]) in that dtype."""
+        outs = []
+        for lins, ws, bs in self._icache["nets"]:
+            h = x_pad
+            for i, (w, b) in enumerate(zip(ws, bs)):
+                h = nn.functional.linear(h, w, b)
+                if i + 1 < len(ws):
+                    h = torch.tanh(h)
+            outs.append(h[:, :lins[-1].out_features])
+        return outs[0], outs[1]
 
     def forward(self, obs, amp_bf16: bool = False):
         pad = (-obs.shape[-1]) % 16
@@ -283,6 +351,34 @@ class EpisodeStats:
         keep = (~m).to(self.ret.dtype)
         self.ret.mul_(keep)
         self.len.mul_(keep)
+
+    def rollout(self, rewards: torch.Tensor, terminals: torch.Tensor) -> None:
+        """The same bookkeeping as T calls of step(), from the rollout's [T, N] reward / terminal (0/1)
+        buffers in ~25 kernels instead of ~30 per step.  With k(t) the 1-based index of the most recent
+        terminal strictly before step t (0 = none in this rollout), the episode ending at a terminal t
+        has return csum[t] - csum[k(t)] (+ the carried-in return if k(t) = 0) and length t - k(t)
+        (+ the carried-in length)."""
+        T, N = rewards.shape
+        term = terminals.to(rewards.dtype)
+        idx = torch.arange(1, T + 1, device=rewards.device, dtype=rewards.dtype).unsqueeze(1)
+        last = torch.cummax(term * idx, dim=0).values                       # most recent terminal at or before t
+        zero = torch.zeros((1, N), device=rewards.device, dtype=rewards.dtype)
+        prev = torch.cat([zero, last[:-1]], dim=0)                          # ... strictly before t
+        csum0 = torch.cat([zero, torch.cumsum(rewards, dim=0)], dim=0)      # csum0[k] = sum of the first k rewards
+        fresh = prev == 0
+        ep_ret = csum0[1:] - torch.gather(csum0, 0, prev.long()) + torch.where(fresh, self.ret.unsqueeze(0), zero)
+        ep_len = idx - prev + torch.where(fresh, self.len.unsqueeze(0), zero)
+        m = term > 0
+        self.w_cnt.add_(m.sum())
+        self.w_sum.add_(torch.where(m, ep_ret, zero).sum().double())
+        self.w_len.add_(torch.where(m, ep_len, zero).sum().double())
+        self.w_max.copy_(torch.maximum(self.w_max, torch.where(m, ep_ret, torch.full_like(zero, -float("inf"))).max()))
+        self.w_min.copy_(torch.minimum(self.w_min, torch.where(m, ep_ret, torch.full_like(zero, float("inf"))).min()))
+        end = last[-1]                                                       # [N]
+        open_ = end == 0
+        tail = csum0[-1] - torch.gather(csum0, 0, end.long().unsqueeze(0)).squeeze(0)
+        self.ret.copy_(tail + torch.where(open_, self.ret, torch.zeros_like(self.ret)))
+        self.len.copy_(float(T) - end + torch.where(open_, self.len, torch.zeros_like(self.len)))
 
     def summarize(self) -> Dict[str, float]:
         packed = torch.stack([self.w_sum, self.w_len, self.w_cnt])
@@ -471,9 +567,13 @@ class PPOTrainer:
         self.stats = EpisodeStats(env.num_envs, self.device)
         self.gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed * 1000003 + self.rank)
         self.a_max = torch.from_numpy(env.a_max).to(self.device)
+        self._a_lo = -self.a_max
         self.iteration = 0
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._graph = None
+        self._xin = None
+        self._xlast = torch.empty((env.num_envs, self.cfg.obs_dim), dtype=torch.float32, device=self.device)
+        self._env_act = torch.empty((env.num_envs, self.cfg.act_dim), dtype=torch.float32, device=self.device)
         T, N = self.cfg.rollout_fragment_length, env.num_envs
         f32 = dict(dtype=torch.float32, device=self.device)
         self.raw_obs = torch.empty((N, self.cfg.obs_dim), **f32)       # static: the obs the next rollout starts from
@@ -482,8 +582,7 @@ class PPOTrainer:
             "raw_obs": torch.empty((T, N, self.cfg.obs_dim), **f32),   # written in place by pnr_step
             "obs": torch.empty((T, N, self.cfg.obs_dim), **f32),       # filtered, what the nets saw
             "actions": torch.empty((T, N, self.cfg.act_dim), **f32),
-            "mean": torch.empty((T, N, self.cfg.act_dim), **f32),
-            "log_std": torch.empty((T, N, self.cfg.act_dim), **f32),
+            "head": torch.empty((T, N, 2 * self.cfg.act_dim), **f32),  # policy head: means | clamped log-stds
             "logp": torch.empty((T, N), **f32), "values": torch.empty((T, N), **f32),
             "reward": torch.empty((T, N), **f32),
             "adv": torch.empty((T, N), **f32), "vtarg": torch.empty((T, N), **f32),
@@ -493,33 +592,46 @@ class PPOTrainer:
 
     @torch.no_grad()
     def _collect_impl(self) -> None:
-        """T steps into the static buffers; pure device work (capturable)."""
+        """T steps into the static buffers; pure device work (capturable).  Per step only what the next
+        step needs (filter, nets on cached weights, action draw, pnr_step: ~25 kernels); log-probs, episode
+        statistics, filter moments and GAE are computed once, after the loop, from the [T, N] buffers."""
         cfg, buf, model = self.cfg, self.buf, self.learner.model
-        T = cfg.rollout_fragment_length
+        T, A = cfg.rollout_fragment_length, cfg.act_dim
         raw = self.raw_obs
-        self.filter.observe(raw)                       # the start observation; the rest after the loop, in one pass
+        model.refresh_inference_cache(cfg.amp_bf16)
+        self.filter.prepare()
+        cdt = model._icache["dtype"]
+        if self._xin is None or self._xin.dtype != cdt:
+            self._xin = torch.zeros((raw.shape[0], cfg.obs_dim + (-cfg.obs_dim) % 16), dtype=cdt, device=self.device)
+        xin = self._xin
+        noise = (torch.randn((T,) + tuple(buf["actions"].shape[1:]), device=self.device) if self._capturing
+                 else torch.randn((T,) + tuple(buf["actions"].shape[1:]), generator=self.gen, device=self.device))
         for t in range(T):
-            x = self.filter(raw)
-            buf["obs"][t] = x
-            mean, log_std, v = model(x, cfg.amp_bf16)
-            noise = (torch.randn(mean.shape, device=self.device) if self._capturing
-                     else torch.randn(mean.shape, generator=self.gen, device=self.device))
-            act = mean + torch.exp(log_std) * noise
-            buf["actions"][t] = act; buf["mean"][t] = mean; buf["log_std"][t] = log_std
-            buf["logp"][t] = gaussian_logp(act, mean, log_std); buf["values"][t] = v
-            env_act = torch.maximum(torch.minimum(act, self.a_max), -self.a_max) if cfg.clip_actions else act
+            x = buf["obs"][t]
+            self.filter.apply_(raw, out=x)
+            xin[:, :cfg.obs_dim].copy_(x)
+            head, v = model.forward_cached(xin)
+            buf["head"][t].copy_(head)
+            buf["values"][t].copy_(v.squeeze(-1))
+            mean, log_std = buf["head"][t][:, :A], buf["head"][t][:, A:]
+            log_std.clamp_(-20.0, 2.0)
+            act = torch.addcmul(mean, torch.exp(log_std), noise[t], out=buf["actions"][t])
+            env_act = torch.clamp(act, self._a_lo, self.a_max, out=self._env_act) if cfg.clip_actions else act
             out = {"obs": buf["raw_obs"][t], "reward": buf["reward"][t], "done": buf["done"][t], "truncated": buf["trunc"][t]}
             self.env.vector_step(env_act, out=out)
             raw = buf["raw_obs"][t]
-            term = (buf["done"][t] | buf["trunc"][t]).float()
-            self.stats.step(buf["reward"][t], term)
-        # the filter only changes at sync(), so observing the T-1 later inputs here is identical to
+        mean, log_std = buf["head"][..., :A], buf["head"][..., A:]
+        buf["logp"].copy_(gaussian_logp(buf["actions"], mean, log_std))
+        terminals = (buf["done"] | buf["trunc"]).float()
+        self.stats.rollout(buf["reward"], terminals)
+        # the filter only changes at sync(), so observing all inputs here, in one pass, is identical to
         # observing them one by one inside the loop (32 small float64 column reductions per rollout)
+        self.filter.observe(self.raw_obs)
         if T > 1:
             self.filter.observe(buf["raw_obs"][:T - 1])
         self.raw_obs.copy_(raw)
-        last_v = model(self.filter(raw), cfg.amp_bf16)[2]
-        terminals = (buf["done"] | buf["trunc"]).float()
+        xin[:, :cfg.obs_dim].copy_(self.filter.apply_(raw, out=self._xlast))
+        last_v = model.forward_cached(xin)[1].squeeze(-1).float()      # bootstrap value of the state after the last step
         adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, terminals, cfg.gamma, cfg.lambda_)
         buf["adv"].copy_(adv); buf["vtarg"].copy_(vtarg)
 
@@ -542,8 +654,9 @@ class PPOTrainer:
             self._collect_impl()
         buf = self.buf
         flat = lambda x: x.reshape(-1, *x.shape[2:])  # noqa: E731
-        return {"obs": flat(buf["obs"]), "actions": flat(buf["actions"]), "mean": flat(buf["mean"]),
-                "log_std": flat(buf["log_std"]), "logp": flat(buf["logp"]), "values": flat(buf["values"]),
+        A = self.cfg.act_dim
+        return {"obs": flat(buf["obs"]), "actions": flat(buf["actions"]), "mean": flat(buf["head"][..., :A]),
+                "log_std": flat(buf["head"][..., A:]), "logp": flat(buf["logp"]), "values": flat(buf["values"]),
                 "adv": flat(buf["adv"]), "vtarg": flat(buf["vtarg"])}
 
     def train(self) -> Dict[str, float]:
