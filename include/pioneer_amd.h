@@ -210,6 +210,20 @@ int pnr_set_dyn_state(pnr_handle h, const float* words_in, void* stream);
 int pnr_diag_sincos(const float* x, float* sin_out, float* cos_out, int64_t n,
                     int bounded, void* stream);
 
+/* Host-driver helper (not part of the env surface): the element-wise part of the PPO loss with the
+ * hyper-parameters of pioneer/launch/pioneer_knm_train.py:45-67 (clip_param, vf_clip_param,
+ * vf_loss_coeff; kl_coeff and entropy_coeff as device scalars because they change between captured
+ * replays), forward and backward in one launch.  head_policy / head_value are the two nets' raw
+ * outputs as rows of 16 floats (means 0..5, log-stds 6..11 | value 0); the gradients of the batch-mean
+ * loss come back in the same layout; partial_sums [partial_rows][8] receives per-block sums of
+ * (policy_loss, vf_loss, kl, entropy, total) with partial_rows >= ceil(batch / 256).  Device pointers. */
+int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_value, const float* actions,
+                 const float* logp_old, const float* mean_old, const float* log_std_old, const float* adv,
+                 const float* value_target, const float* value_old, const float* kl_coeff,
+                 const float* entropy_coeff, float clip_param, float vf_clip_param, float vf_loss_coeff,
+                 float* grad_head_policy, float* grad_head_value, float* partial_sums, int64_t partial_rows,
+                 void* stream);
+
 int64_t pnr_num_envs(pnr_handle h);
 
 /* Last error message of `h`, or of the calling thread when h == NULL. */

@@ -27,6 +27,7 @@
 #include "../../include/pioneer_amd.h"
 #include "pnr_device.h"
 #include "pnr_dyn.h"
+#include "pnr_ppo.h"
 
 namespace pnr {
 
@@ -834,6 +835,29 @@ int pnr_diag_sincos(const float* x, float* sin_out, float* cos_out, int64_t n, i
     if (n == 0) return PNR_OK;
     hipLaunchKernelGGL(diag_sincos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, sin_out, cos_out, (long long)n, bounded);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_value, const float* actions,
+                 const float* logp_old, const float* mean_old, const float* log_std_old, const float* adv,
+                 const float* value_target, const float* value_old, const float* kl_coeff, const float* entropy_coeff,
+                 float clip_param, float vf_clip_param, float vf_loss_coeff, float* grad_head_policy,
+                 float* grad_head_value, float* partial_sums, int64_t partial_rows, void* stream)
+{
+    if (batch <= 0 || !head_policy || !head_value || !actions || !logp_old || !mean_old || !log_std_old || !adv ||
+        !value_target || !value_old || !kl_coeff || !entropy_coeff || !grad_head_policy || !grad_head_value || !partial_sums)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_loss: null argument or empty batch");
+    const long long blocks = (batch + kPpoBlock - 1) / kPpoBlock;
+    if (partial_rows < blocks)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_loss: partial_sums has %lld rows, the launch needs %lld",
+                    (long long)partial_rows, blocks);
+    PpoLossParams P;
+    P.head_p = head_policy; P.head_v = head_value; P.actions = actions; P.logp_old = logp_old; P.mean_old = mean_old;
+    P.ls_old = log_std_old; P.adv = adv; P.vtarg = value_target; P.v_old = value_old; P.kl_coeff = kl_coeff;
+    P.ent_coeff = entropy_coeff; P.g_head_p = grad_head_policy; P.g_head_v = grad_head_value; P.partials = partial_sums;
+    P.B = batch; P.clip = clip_param; P.vf_clip = vf_clip_param; P.vf_coeff = vf_loss_coeff;
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)blocks), dim3(kPpoBlock), 0, (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }

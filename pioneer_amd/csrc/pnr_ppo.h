@@ -1,0 +1,137 @@
+// pnr_ppo.h — the element-wise part of the PPO learner's loss, forward AND backward, as one kernel.
+//
+// The host driver (pioneer_amd/ppo.py) replaces RLlib's PPOTrainer loop with the hyper-parameters of
+// pioneer/launch/pioneer_knm_train.py:45-67 (clip_param, vf_clip_param, kl_coeff, vf_loss_coeff,
+// entropy_coeff).  Written with torch ops, the loss over a [B, 6] Gaussian head is ~40 small kernels
+// forward and ~80 backward per minibatch — a quarter of the learn phase at B = 131 072.  Here one
+// thread owns one sample: it reads the two heads' raw outputs and the rollout record, writes
+// d loss / d head and accumulates the five reported means.  Semantics (ties included) are those of
+// PPOLearner.loss() under torch autograd, which stays the CPU path and the checker
+// (tests/test_gpu_ppo.py::test_fused_loss_matches_autograd).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace pnr {
+
+constexpr int kPpoActDim = kDof;          // 6 means + 6 log-stds in a 16-float head row
+constexpr int kPpoHeadStride = 16;
+constexpr int kPpoBlock = 256;
+constexpr int kPpoSums = 8;               // policy_loss, vf_loss, kl, entropy, total, 3 spare
+
+struct PpoLossParams {
+    const float* head_p;    // [B][16]: mean[0:6], raw log_std[6:12]
+    const float* head_v;    // [B][16]: v at column 0
+    const float* actions;   // [B][6]
+    const float* logp_old;  // [B]
+    const float* mean_old;  // [B][6]
+    const float* ls_old;    // [B][6] (already clamped when it was recorded)
+    const float* adv;       // [B]
+    const float* vtarg;     // [B]
+    const float* v_old;     // [B]
+    const float* kl_coeff;  // device scalars: their values change between graph replays
+    const float* ent_coeff;
+    float* g_head_p;        // [B][16]  d loss / d head_p
+    float* g_head_v;        // [B][16]  d loss / d head_v
+    float* partials;        // [gridDim.x][8] per-block sums (summed by the caller: deterministic)
+    long long B;
+    float clip, vf_clip, vf_coeff;
+};
+
+__global__ __launch_bounds__(kPpoBlock) void ppo_loss_kernel(const PpoLossParams P)
+{
+    __shared__ float red[kPpoSums][kPpoBlock / 64];
+    const long long i = (long long)blockIdx.x * kPpoBlock + threadIdx.x;
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < P.B) {
+        const float klc = *P.kl_coeff, entc = *P.ent_coeff;
+        const float invB = 1.0f / (float)P.B;
+        const float4* hp = reinterpret_cast<const float4*>(P.head_p + i * kPpoHeadStride);
+        const float4 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+        const float m[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
+        const float raw[6] = {h1.z, h1.w, h2.x, h2.y, h2.z, h2.w};
+        const float v = P.head_v[i * kPpoHeadStride];
+        float a[6], m0[6], l0[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { a[j] = P.actions[i * 6 + j]; m0[j] = P.mean_old[i * 6 + j]; l0[j] = P.ls_old[i * 6 + j]; }
+        const float adv = P.adv[i], vt = P.vtarg[i], v0 = P.v_old[i], lp0 = P.logp_old[i];
+
+        float ls[6], z[6], s[6];
+        bool pass[6];
+        float logp = -0.5f * 6.0f * 1.8378770664093453f;           // -3 log(2 pi)
+        float kl = 0.f, ent = 6.0f * 1.4189385332046727f;          // 6 * 0.5 log(2 pi e)
+        float dkl_m[6], dkl_l[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            pass[j] = raw[j] >= -20.0f && raw[j] <= 2.0f;          // torch.clamp passes the gradient on [min, max]
+            ls[j] = fminf(fmaxf(raw[j], -20.0f), 2.0f);
+            s[j] = expf(-ls[j]);
+            z[j] = (a[j] - m[j]) * s[j];
+            logp += -0.5f * z[j] * z[j] - ls[j];
+            const float ivar = s[j] * s[j];
+            const float d = m0[j] - m[j];
+            const float q = (expf(2.0f * l0[j]) + d * d) * ivar;  // (var0 + (m0 - m)^2) / var
+            kl += ls[j] - l0[j] + 0.5f * q - 0.5f;
+            dkl_m[j] = -d * ivar;
+            dkl_l[j] = 1.0f - q;
+            ent += ls[j];
+        }
+        const float ratio = expf(logp - lp0);
+        const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+        const float s1 = adv * ratio, s2 = adv * rc;
+        const float surr = fminf(s1, s2);
+        const bool inrange = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
+        // torch.minimum: the smaller argument takes the gradient, a tie splits it; the clipped branch is
+        // constant outside the range
+        float dsurr = 0.f;                                          // d surr / d logp
+        if (s1 < s2) dsurr = s1;
+        else if (s1 == s2) dsurr = 0.5f * s1 + (inrange ? 0.5f * s1 : 0.f);
+        else dsurr = inrange ? s1 : 0.f;
+
+        const float e1 = v - vt;
+        const float dv = v - v0;
+        const bool vin = dv >= -P.vf_clip && dv <= P.vf_clip;
+        const float e2 = v0 + fminf(fmaxf(dv, -P.vf_clip), P.vf_clip) - vt;
+        const float f1 = e1 * e1, f2 = e2 * e2;
+        const float vf = fmaxf(f1, f2);
+        const float g1 = 2.0f * e1, g2 = vin ? 2.0f * e2 : 0.f;
+        const float dvf = f1 > f2 ? g1 : (f1 < f2 ? g2 : 0.5f * (g1 + g2));   // torch.maximum, ties split
+
+        float gm[6], gl[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            gm[j] = (-dsurr * z[j] * s[j] + klc * dkl_m[j]) * invB;
+            gl[j] = pass[j] ? (-dsurr * (z[j] * z[j] - 1.0f) + klc * dkl_l[j] - entc) * invB : 0.f;
+        }
+        float4* gp = reinterpret_cast<float4*>(P.g_head_p + i * kPpoHeadStride);
+        gp[0] = make_float4(gm[0], gm[1], gm[2], gm[3]);
+        gp[1] = make_float4(gm[4], gm[5], gl[0], gl[1]);
+        gp[2] = make_float4(gl[2], gl[3], gl[4], gl[5]);
+        gp[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* gv = reinterpret_cast<float4*>(P.g_head_v + i * kPpoHeadStride);
+        gv[0] = make_float4(P.vf_coeff * dvf * invB, 0.f, 0.f, 0.f);
+        gv[1] = gv[2] = gv[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        acc[0] = -surr; acc[1] = vf; acc[2] = kl; acc[3] = ent;
+        acc[4] = -surr + klc * kl + P.vf_coeff * vf - entc * ent;
+    }
+    // block sums: wave shuffle, then across the four waves through LDS
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float x = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kPpoSums) {
+        float x = 0.f;
+        if (threadIdx.x < 5) {
+#pragma unroll
+            for (int w = 0; w < kPpoBlock / 64; ++w) x += red[threadIdx.x][w];
+        }
+        P.partials[(long long)blockIdx.x * kPpoSums + threadIdx.x] = x;
+    }
+}
+
+}  // namespace pnr

@@ -220,7 +220,7 @@ class ActorCritic(nn.Module):
         return mean, torch.clamp(log_std, -20.0, 2.0)
 
     @staticmethod
-    def _run(net: nn.Sequential, x_pad, pad: int):
+    def _run(net: nn.Sequential, x_pad, pad: int, full: bool = False):
         """First layer on a K padded to a multiple of 16 (137 -> 144): the BLAS library's kernels for an
         unaligned K = 137 run at ~3 TFLOP/s (391 us for a 16384 x 137 x 256 GEMM); the zero columns are
         appended to input and weight on the fly, so the parameters are the reference's."""
@@ -234,7 +234,19 @@ class ActorCritic(nn.Module):
         head = layers[-1]
         rp = (-head.out_features) % 16
         out = _LinearSplitK.apply(h, nn.functional.pad(head.weight, (0, 0, 0, rp)), nn.functional.pad(head.bias, (0, rp)))
-        return out[:, :head.out_features]
+        return out if full else out[:, :head.out_features]
+
+    def forward_heads(self, obs, amp_bf16: bool = False):
+        """The two nets' raw head outputs as float32 rows of 16 (policy: means 0..5, unclamped log-stds
+        6..11; value: column 0) — the layout pnr_ppo_loss consumes."""
+        pad = (-obs.shape[-1]) % 16
+        x = nn.functional.pad(obs, (0, pad)) if pad else obs
+        if amp_bf16 and obs.is_cuda:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                hp, hv = self._run(self.policy, x, pad, True), self._run(self.value, x, pad, True)
+        else:
+            hp, hv = self._run(self.policy, x, pad, True), self._run(self.value, x, pad, True)
+        return hp.float(), hv.float()
 
     # -- no-grad inference on cached weights (the sampling loop) ----------------------------------
     # The rollout runs the nets T times on unchanged parameters: the K-padded, compute-dtype copies of the
@@ -302,6 +314,40 @@ def gaussian_kl(mean0, log_std0, mean1, log_std1):
     """KL(N0 || N1) for diagonal Gaussians."""
     var0, var1 = torch.exp(2 * log_std0), torch.exp(2 * log_std1)
     return (log_std1 - log_std0 + (var0 + (mean0 - mean1) ** 2) / (2 * var1) - 0.5).sum(-1)
+
+
+class FusedPPOLoss(torch.autograd.Function):
+    """PPOLearner.loss()'s element-wise part as ONE HIP kernel (pnr_ppo_loss, csrc/pnr_ppo.h): forward
+    values and d loss / d head in the same launch instead of ~120 small kernels per minibatch."""
+
+    @staticmethod
+    def forward(ctx, head_p, head_v, mb, kl_c, ent_c, clip, vf_clip, vf_coeff):
+        from . import _lib
+        import ctypes as C
+        lib = _lib.load_library()
+        B = head_p.shape[0]
+        head_p, head_v = head_p.contiguous(), head_v.contiguous()
+        assert head_p.shape == (B, 16) and head_v.shape == (B, 16) and head_p.dtype == head_v.dtype == torch.float32
+        t = {k: mb[k].contiguous() for k in ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values")}
+        assert all(v.dtype == torch.float32 and v.is_cuda and v.shape[0] == B for v in t.values())
+        assert t["actions"].shape == t["mean"].shape == t["log_std"].shape == (B, 6)
+        g_p, g_v = torch.empty_like(head_p), torch.empty_like(head_v)
+        rows = (B + 255) // 256
+        partials = torch.empty((rows, 8), dtype=torch.float32, device=head_p.device)
+        P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+        _lib.check(lib.pnr_ppo_loss(B, P(head_p), P(head_v), P(t["actions"]), P(t["logp"]), P(t["mean"]), P(t["log_std"]),
+                                    P(t["adv"]), P(t["vtarg"]), P(t["values"]), P(kl_c), P(ent_c),
+                                    C.c_float(clip), C.c_float(vf_clip), C.c_float(vf_coeff), P(g_p), P(g_v), P(partials),
+                                    rows, C.c_void_p(torch.cuda.current_stream(head_p.device).cuda_stream)))
+        means = partials.sum(0) / B          # policy_loss, vf_loss, kl, entropy, total
+        ctx.save_for_backward(g_p, g_v)
+        ctx.mark_non_differentiable(means)
+        return means[4].clone(), means
+
+    @staticmethod
+    def backward(ctx, g_total, _g_means):
+        g_p, g_v = ctx.saved_tensors
+        return g_p * g_total, g_v * g_total, None, None, None, None, None, None
 
 
 def compute_gae(rewards, values, last_value, terminals, gamma, lam):
@@ -426,6 +472,7 @@ class PPOLearner:
         self._static = None
         self._static_info = None
         self._eager_updates = 0
+        self.fused_loss = self.device.type == "cuda" and cfg.act_dim == 6   # pnr_ppo_loss; torch ops otherwise (CPU)
 
     def entropy_coeff(self) -> float:
         frac = min(1.0, self.timesteps_total / max(1, self.cfg.entropy_decay_steps))
@@ -433,6 +480,11 @@ class PPOLearner:
 
     def loss(self, mb: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         cfg = self.cfg
+        if self.fused_loss and mb["obs"].is_cuda:
+            hp, hv = self.model.forward_heads(mb["obs"], cfg.amp_bf16)
+            total, m = FusedPPOLoss.apply(hp, hv, mb, self._kl_c, self._ent_c, float(cfg.clip_param),
+                                          float(cfg.vf_clip_param), float(cfg.vf_loss_coeff))
+            return total, {"policy_loss": m[0], "vf_loss": m[1], "kl": m[2], "entropy": m[3], "total_loss": m[4]}
         mean, log_std, v = self.model(mb["obs"], cfg.amp_bf16)
         logp = gaussian_logp(mb["actions"], mean, log_std)
         ratio = torch.exp(logp - mb["logp"])

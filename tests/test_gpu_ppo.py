@@ -126,3 +126,93 @@ def test_episode_statistics_exact_under_graph_replay(use_graph):
         assert -5.0 < r["episode_reward_mean"] < 100.0
     assert (tr._graph is not None) == use_graph
     env.close()
+
+
+def _torch_loss_from_heads(hp, hv, mb, kl_c, ent_c, cfg):
+    """PPOLearner.loss()'s arithmetic (torch ops + autograd), starting from the raw head rows."""
+    from pioneer_amd.ppo import gaussian_entropy, gaussian_kl, gaussian_logp
+    mean, log_std, v = hp[:, :6], torch.clamp(hp[:, 6:12], -20.0, 2.0), hv[:, 0]
+    logp = gaussian_logp(mb["actions"], mean, log_std)
+    ratio = torch.exp(logp - mb["logp"])
+    adv = mb["adv"]
+    surr = torch.minimum(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_param, 1 + cfg.clip_param))
+    kl = gaussian_kl(mb["mean"], mb["log_std"], mean, log_std)
+    ent = gaussian_entropy(log_std)
+    vf1 = (v - mb["vtarg"]) ** 2
+    v_clipped = mb["values"] + torch.clamp(v - mb["values"], -cfg.vf_clip_param, cfg.vf_clip_param)
+    vf = torch.maximum(vf1, (v_clipped - mb["vtarg"]) ** 2)
+    total = (-surr + kl_c * kl + cfg.vf_loss_coeff * vf - ent_c * ent).mean()
+    return total, torch.stack([(-surr).mean(), vf.mean(), kl.mean(), ent.mean(), total])
+
+
+@pytest.mark.parametrize("B", [1, 255, 4099, 131072])
+def test_fused_loss_matches_autograd(B):
+    """pnr_ppo_loss (one HIP kernel, forward + backward) against the torch-ops loss under autograd: values and
+    d loss / d head, with ratios on both sides of the clip range, active value clipping, log-stds beyond the
+    clamp and exact ties (ratio == 1, v == v_old)."""
+    from pioneer_amd.ppo import FusedPPOLoss, PPOConfig
+    cfg = PPOConfig()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(B)
+    R = lambda *s: torch.randn(*s, generator=g, device=dev)   # noqa: E731
+    hp = torch.zeros(B, 16, device=dev); hv = torch.zeros(B, 16, device=dev)
+    hp[:, :6] = R(B, 6); hp[:, 6:12] = 0.7 * R(B, 6) - 0.5; hv[:, 0] = 3 * R(B)
+    hp[:, 12:] = R(B, 4); hv[:, 1:] = R(B, 15)                       # padding columns must not matter
+    if B > 8:
+        hp[0, 6:12] = torch.tensor([2.5, -21.0, 2.0, -20.0, 0.0, 1.0], device=dev)   # beyond / on the clamp
+    mb = {"actions": hp[:, :6].detach() + 1.5 * R(B, 6), "mean": hp[:, :6].detach() + 0.3 * R(B, 6),
+          "log_std": torch.clamp(hp[:, 6:12].detach() + 0.2 * R(B, 6), -20, 2), "adv": R(B), "vtarg": 3 * R(B),
+          "values": hv[:, 0].detach() + 4 * R(B)}
+    if B > 8:   # keep the row with the extreme log-stds well conditioned: z = 0 and the old policy equal to the new one
+        mb["actions"][0] = hp[0, :6]; mb["mean"][0] = hp[0, :6]; mb["log_std"][0] = torch.clamp(hp[0, 6:12], -20, 2)
+    with torch.no_grad():
+        from pioneer_amd.ppo import gaussian_logp
+        lp = gaussian_logp(mb["actions"], hp[:, :6], torch.clamp(hp[:, 6:12], -20, 2))
+    mb["logp"] = lp + 0.4 * R(B)                                     # ratios spread over ~[0.3, 3]
+    if B > 8:
+        mb["logp"][1] = lp[1]                                        # ratio exactly 1: the minimum's tie
+        mb["values"][2] = hv[2, 0]                                   # v == v_old: the maximum's tie
+    kl_c = torch.tensor(0.37, device=dev); ent_c = torch.tensor(0.013, device=dev)
+
+    a_p, a_v = hp.clone().requires_grad_(True), hv.clone().requires_grad_(True)
+    ref_total, ref_means = _torch_loss_from_heads(a_p, a_v, mb, kl_c, ent_c, cfg)
+    ref_total.backward()
+    b_p, b_v = hp.clone().requires_grad_(True), hv.clone().requires_grad_(True)
+    total, means = FusedPPOLoss.apply(b_p, b_v, mb, kl_c, ent_c, float(cfg.clip_param), float(cfg.vf_clip_param),
+                                      float(cfg.vf_loss_coeff))
+    (2.0 * total).backward()                                         # the upstream factor must reach the heads
+    assert torch.allclose(means[:5], ref_means, rtol=2e-5, atol=1e-5), (means, ref_means)
+    # fp32 against fp32 with different summation orders: compared per sample, relative to that sample's largest
+    # gradient entry (a few samples have ratios far outside the clip range and gradients 100x the typical one)
+    for fused, ref in ((b_p.grad / 2, a_p.grad), (b_v.grad / 2, a_v.grad)):
+        row = ref.abs().max(1, keepdim=True).values
+        err = (fused - ref).abs()
+        bad = int((err > 2e-4 * row + 1e-9).any(1).sum())
+        # a sample whose ratio (or value step) lands within rounding of a clip boundary may fall on different
+        # sides in the two implementations: the gradient is discontinuous there.  Allow a handful in 131 072.
+        assert bad <= B // 20000, (bad, float(err.max()), float(row.max()))
+    assert float(b_p.grad[:, 12:].abs().max()) == 0.0 and float(b_v.grad[:, 1:].abs().max()) == 0.0
+    if B > 8:
+        assert float(b_p.grad[0, 6].abs()) == 0.0 and float(b_p.grad[0, 7].abs()) == 0.0     # clamped: no gradient
+        assert float(b_p.grad[0, 8].abs()) > 0.0 and float(b_p.grad[0, 9].abs()) > 0.0       # on the bound: passes
+
+
+def test_learner_fused_and_torch_losses_train_alike():
+    """Two learners from the same seed, one on pnr_ppo_loss and one on torch ops, after a few fp32 updates."""
+    from pioneer_amd.ppo import PPOConfig, PPOLearner
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7)
+    B = 8192
+    R = lambda *s: torch.randn(*s, generator=g, device=dev)   # noqa: E731
+    batch = {"obs": R(B, 137), "actions": R(B, 6), "mean": 0.1 * R(B, 6), "log_std": 0.1 * R(B, 6),
+             "logp": -8.0 + R(B), "values": R(B), "adv": R(B), "vtarg": R(B)}
+    outs = []
+    for fused in (False, True):
+        L = PPOLearner(PPOConfig(num_sgd_iter=2, sgd_minibatch_size=B // 2, lr=1e-3, seed=11, amp_bf16=False), dev)
+        L.fused_loss = fused
+        pg = torch.Generator(device=dev).manual_seed(5)
+        infos = [L.update(dict(batch), pg) for _ in range(2)]
+        outs.append((torch.cat([p.detach().reshape(-1) for p in L.model.parameters()]), infos[-1]))
+    (w0, i0), (w1, i1) = outs
+    assert torch.allclose(w0, w1, atol=3e-5, rtol=1e-4)
+    assert abs(i0["total_loss"] - i1["total_loss"]) < 1e-4 * max(1.0, abs(i0["total_loss"])) and abs(i0["kl"] - i1["kl"]) < 1e-5

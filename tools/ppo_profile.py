@@ -1,11 +1,13 @@
-"""Run a few PPO iterations (for rocprofv3 --kernel-trace --stats)."""
+"""Run a few PPO iterations (for rocprofv3 --kernel-trace --stats).  PPO_PROFILE_GRAPH=1 replays the
+captured hipGraphs (kernel durations without host gaps), default eager."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pioneer_amd import PioneerVectorEnv, EngineConfig
 from pioneer_amd.ppo import PPOConfig, PPOTrainer
+g = os.environ.get("PPO_PROFILE_GRAPH") == "1"
 env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500))
-tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=131072, amp_bf16=True), use_graph=False)
-for _ in range(4):
+tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=131072, amp_bf16=True), use_graph=g)
+for _ in range(int(os.environ.get("PPO_PROFILE_ITERS", "4"))):
     r = tr.train()
 print(r["sample_time_s"], r["learn_time_s"])
