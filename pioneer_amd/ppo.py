@@ -195,10 +195,10 @@ class _LinearSplitK(torch.autograd.Function):
             # a bf16 batched GEMM with a single output row (the value head) takes ~11 ms of HOST time per
             # call in the BLAS library (tools/gemm_probe2.py): pad tiny heads to 8 rows and slice
             dyp = nn.functional.pad(dy, (0, 8 - out)) if out < 8 else dy
-            dw = torch.bmm(dyp.view(S, B // S, -1).transpose(1, 2), x2.view(S, B // S, -1)).float().sum(0)[:out]
+            dw = torch.bmm(dyp.view(S, B // S, -1).transpose(1, 2), x2.view(S, B // S, -1)).sum(0, dtype=torch.float32)[:out]
         else:
             dw = (dy.t() @ x2).float()
-        db = dy.float().sum(0)
+        db = dy.sum(0, dtype=torch.float32)          # one reduction with a float32 accumulator, no cast pass
         return dx, dw.to(weight.dtype), db.to(weight.dtype)
 
 
