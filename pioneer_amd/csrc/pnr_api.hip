@@ -35,12 +35,14 @@ namespace pnr {
 // step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps.
 // One wave = 32 envs (lane pair per env), one wave per workgroup.
 // ---------------------------------------------------------------------------------
-// The three leading scalar parameters repeat P.state / P.actions / P.n: plain leading arguments are
-// preloaded into SGPRs by the command processor (-mllvm -amdgpu-kernarg-preload-count), so the first
-// state and action loads do not wait for a kernarg fetch; the by-value struct is fetched behind them.
+// The leading scalar parameters repeat P.state / P.actions / P.n / P.dt / P.eps and carry max_v_to_r (v_max
+// is formed from it and the constexpr limits): plain leading arguments (up to 14 dwords) are preloaded into SGPRs by the command processor (-mllvm
+// -amdgpu-kernarg-preload-count), so neither the first state and action loads nor the integrator wait for
+// a kernarg fetch; the by-value struct, needed from the reward block on, is fetched behind them.
 template <bool OBS_EM, bool ACT_EM>
 __global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_, const float* __restrict__ actions_,
-                                                     const long long n_, const KParams P)
+                                                     const long long n_, const double dt_, const double eps_,
+                                                     const float max_v_to_r_, const KParams P)
 {
     __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
 
@@ -53,11 +55,10 @@ __global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_
     // PNR_DIAG timing-only ablations (outputs are wrong when set; see DESIGN.md "Where the time goes")
     const bool diag_noflush = P.diag & 2, diag_noemit = P.diag & 4, diag_nostate = P.diag & 8;
 
-    const float vmax0 = p ? P.v_max[kJpl + 0] : P.v_max[0];
-    const float vmax1 = p ? P.v_max[kJpl + 1] : P.v_max[1];
-    const float vmax2 = p ? P.v_max[kJpl + 2] : P.v_max[2];
-    const float vmax[kJpl] = {vmax0, vmax1, vmax2};
     const LaneConsts K = lane_consts(p);
+    // v_max = max_v_to_r * (r_hi - r_lo) (pioneer_knm_env.py:57), the same float32 product pnr_get_constants forms
+    const float vmax[kJpl] = {max_v_to_r_ * (K.lim[0] - (-K.lim[0])), max_v_to_r_ * (K.lim[1] - (-K.lim[1])),
+                              max_v_to_r_ * (K.lim[2] - (-K.lim[2]))};
 
     // Persistent tile loop: the grid is capped (host: <= 8 waves per CU) and every wave strides over
     // tiles.  The NEXT tile's state and first action are requested before the current tile is
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_
 #pragma unroll
             for (int i = 0; i < kJpl; ++i) {
                 const float lim = K.lim[i];
-                if (!(P.diag & 32)) integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, P.dt, P.eps, s.v[i], s.r[i]);
+                if (!(P.diag & 32)) integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, dt_, eps_, s.v[i], s.r[i]);
             }
 #pragma unroll
             for (int i = 0; i < kJpl; ++i) s.a[i] = act[i];           // :144 (quirk Q1)
@@ -809,10 +810,10 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
         HIP_TRY(h, hipGetLastError());
         return PNR_OK;
     }
-    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, st, P.state, P.actions, P.n, P);
-    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P.state, P.actions, P.n, P);
-    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P.state, P.actions, P.n, P);
-    else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P.state, P.actions, P.n, P);
+    if (oem && aem) hipLaunchKernelGGL((step_kernel<true, true>), grid, block, 0, st, P.state, P.actions, P.n, P.dt, P.eps, (float)h->cfg.max_v_to_r, P);
+    else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P.state, P.actions, P.n, P.dt, P.eps, (float)h->cfg.max_v_to_r, P);
+    else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P.state, P.actions, P.n, P.dt, P.eps, (float)h->cfg.max_v_to_r, P);
+    else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P.state, P.actions, P.n, P.dt, P.eps, (float)h->cfg.max_v_to_r, P);
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
 }
