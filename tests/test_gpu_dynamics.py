@@ -169,3 +169,29 @@ def test_diverged_lanes_are_cut_and_recovered():
     st = env.state_dict()
     assert (st["episode"][bad.cpu().numpy()] == 2).all() and (st["episode"][~bad.cpu().numpy()] == 1).all()
     env.close()
+
+
+@pytest.mark.parametrize("n", [1, 31, 37, 64, 97, 129])
+def test_ragged_batches_against_the_oracle(n):
+    """dyn_step_kernel's workgroups own 64 envs and finish them as two 32-env tiles: batch sizes that leave the
+    second tile partial (37), absent (31, 1), exactly full (64) or start a new workgroup with one env (129, 97),
+    with randomisation, gravity, TimeLimit and auto-reset on; every output row is compared."""
+    env, orc = make(n, seed=9, auto_reset=True, max_steps=6, gravity=9.81, randomize=1)
+    obs = env.reset(); oobs = orc.reset()
+    assert obs.shape == (n, 137) and np.abs(obs.double().cpu().numpy() - oobs).max() < 3e-5
+    rng = np.random.RandomState(n)
+    for t in range(14):                                   # two time-limit resets per env
+        act = (rng.uniform(-0.3, 0.3, (n, 6)) * env.a_max).astype(np.float32)
+        sync_oracle_from_gpu(env, orc)
+        obs, rew, done, trunc = env.vector_step(torch.from_numpy(act).cuda())
+        oobs, orew, odone, otrunc = orc.step(act)
+        assert np.array_equal(trunc.cpu().numpy(), otrunc) and np.array_equal(done.cpu().numpy(), odone)
+        w = env.get_dyn_state().cpu().numpy().astype(np.float64)
+        assert np.abs(w[0:6].T - orc.dstate["q"]).max() <= Q_TOL and np.abs(w[6:12].T - orc.dstate["qd"]).max() <= QD_TOL
+        o = obs.double().cpu().numpy()
+        assert np.abs(o[:, 0:6] - oobs[:, 0:6]).max() <= Q_TOL and np.abs(o[:, 126:129] - oobs[:, 126:129]).max() <= 1e-3
+        assert np.abs(rew.double().cpu().numpy() - orew).max() <= 2e-3
+        assert np.array_equal(env.get_state().cpu().numpy().view(np.uint32), orc.state_words()) or \
+            np.array_equal(env.get_state().cpu().numpy().view(np.uint32)[:21], orc.state_words()[:21])
+        assert np.array_equal(env.get_dyn_state().cpu().numpy()[12:35], orc.dyn_words()[12:35])   # per-env draws after resets
+    env.close()
