@@ -287,12 +287,17 @@ __device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParam
     }
 }
 
+// Leading scalar arguments as in step_kernel: preloaded into SGPRs, they repeat P.state / D.dyn / P.actions /
+// P.n / P.dt / P.eps and carry max_v_to_r.
 template <bool OBS_EM, bool ACT_EM, bool RAND>
-__global__ __launch_bounds__(kWave) void dyn_step_kernel(const KParams P, const DynParams D)
+__global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
+                                                         const float* __restrict__ actions_, const long long n_,
+                                                         const double dt_, const double eps_, const float max_v_to_r_,
+                                                         const KParams P, const DynParams D)
 {
     __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
     const int lane = threadIdx.x;
-    const long long n = P.n;
+    const long long n = n_;
     const long long base = (long long)blockIdx.x * kDynEnvsPerWg;
     float4* hrec = reinterpret_cast<float4*>(tile);               // [3][2 * 64] records, index 2 * env + p
     float* hq = tile + kHandRecFloats;                            // [12][64]: q then qd
@@ -303,7 +308,8 @@ __global__ __launch_bounds__(kWave) void dyn_step_kernel(const KParams P, const 
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 k0[2] = {z4, z4}, k1[2] = {z4, z4}, k2[2] = {z4, z4};
         float q[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qd[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (e < n) dyn_substeps_lane<ACT_EM, RAND>(P, D, e, k0, k1, k2, q, qd);
+        const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
+        if (e < n) dyn_substeps_lane<ACT_EM, RAND>(lead, D, e, k0, k1, k2, q, qd);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             hrec[2 * lane + p] = k0[p];
@@ -797,7 +803,8 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
             Pt.reward = reward + (long long)t * h->n;
             Pt.done = done + (long long)t * h->n;
             Pt.trunc = truncated ? truncated + (long long)t * h->n : nullptr;
-#define PNR_DYN_LAUNCH(O, A, R) hipLaunchKernelGGL((dyn_step_kernel<O, A, R>), gridD, block, 0, st, Pt, D)
+#define PNR_DYN_LAUNCH(O, A, R) hipLaunchKernelGGL((dyn_step_kernel<O, A, R>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, \
+                                              Pt.n, Pt.dt, Pt.eps, (float)h->cfg.max_v_to_r, Pt, D)
             if (oem) {
                 if (aem) { if (rnd) PNR_DYN_LAUNCH(true, true, true); else PNR_DYN_LAUNCH(true, true, false); }
                 else { if (rnd) PNR_DYN_LAUNCH(true, false, true); else PNR_DYN_LAUNCH(true, false, false); }

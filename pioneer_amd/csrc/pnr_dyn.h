@@ -560,27 +560,34 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
 // ---------------------------------------------------------------------------------
 // RAND = per-env link scales (domain randomisation): loaded from the dyn words; otherwise every scale
 // is 1 and the model folds into literals.
+// `in` carries the pointers and integrator constants the kernel received as preloaded leading arguments
+// (so that the first loads and the integrator do not wait for the kernarg structs).
+struct DynLead {
+    const float4* state; const float* dyn; const float* actions;
+    long long n; double dt, eps; float max_v_to_r;
+};
+
 template <bool ACT_EM, bool RAND>
-__device__ __forceinline__ void dyn_substeps_lane(const KParams& P, const DynParams& D, long long e,
+__device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynParams& D, long long e,
                                                   float4 (&k0)[2], float4 (&k1)[2], float4 (&k2)[2],
                                                   float (&q)[kDof], float (&qd)[kDof])
 {
-    const long long n = P.n;
+    const long long n = in.n;
     const long long n2 = 2 * n;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        k0[p] = P.state[2 * e + p]; k1[p] = P.state[n2 + 2 * e + p]; k2[p] = P.state[2 * n2 + 2 * e + p];
+        k0[p] = in.state[2 * e + p]; k1[p] = in.state[n2 + 2 * e + p]; k2[p] = in.state[2 * n2 + 2 * e + p];
     }
     // dynamics state: every load is issued here, before the first wait — with one wave per SIMD
     // (65 536 envs) nothing else hides a memory round trip
     float sc[kNumLinks], fric[kDof], damp[kDof];
 #pragma unroll
     for (int i = 0; i < kDof; ++i) {
-        q[i] = D.dyn[(long long)i * n + e]; qd[i] = D.dyn[(long long)(6 + i) * n + e];
-        fric[i] = D.dyn[(long long)(23 + i) * n + e]; damp[i] = D.dyn[(long long)(29 + i) * n + e];
+        q[i] = in.dyn[(long long)i * n + e]; qd[i] = in.dyn[(long long)(6 + i) * n + e];
+        fric[i] = in.dyn[(long long)(23 + i) * n + e]; damp[i] = in.dyn[(long long)(29 + i) * n + e];
     }
 #pragma unroll
-    for (int l = 0; l < kNumLinks; ++l) sc[l] = RAND ? D.dyn[(long long)(12 + l) * n + e] : 1.0f;
+    for (int l = 0; l < kNumLinks; ++l) sc[l] = RAND ? in.dyn[(long long)(12 + l) * n + e] : 1.0f;
     float a[kDof], v[kDof], r[kDof];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -590,16 +597,16 @@ __device__ __forceinline__ void dyn_substeps_lane(const KParams& P, const DynPar
     }
     float act[kDof];
     if (ACT_EM) {
-        const float2* a2 = reinterpret_cast<const float2*>(P.actions + e * kDof);
+        const float2* a2 = reinterpret_cast<const float2*>(in.actions + e * kDof);
         const float2 x0 = a2[0], x1 = a2[1], x2 = a2[2];
         act[0] = x0.x; act[1] = x0.y; act[2] = x1.x; act[3] = x1.y; act[4] = x2.x; act[5] = x2.y;
     } else {
 #pragma unroll
-        for (int i = 0; i < kDof; ++i) act[i] = P.actions[(long long)i * n + e];
+        for (int i = 0; i < kDof; ++i) act[i] = in.actions[(long long)i * n + e];
     }
 #pragma unroll
     for (int i = 0; i < kDof; ++i) {
-        integrate_joint(a[i], v[i], r[i], P.v_max[i], limit_lo(i), limit_hi(i), P.dt, P.eps, v[i], r[i]);
+        integrate_joint(a[i], v[i], r[i], in.max_v_to_r * (limit_hi(i) - limit_lo(i)), limit_lo(i), limit_hi(i), in.dt, in.eps, v[i], r[i]);
         a[i] = act[i];
     }
 #pragma unroll
