@@ -69,13 +69,25 @@ def train(results_dir: str,
                                engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=mode))
         trainer = PPOTrainer(env, cfg, use_graph=use_graph)   # hipGraph-captured sampling and updates
         last = {}
+        # the files Tune leaves in a trial directory: params.json, result.json (one line per iteration), progress.csv
         log = open(os.path.join(tdir, "result.json"), "a") if rank == 0 else None
+        csv_log, csv_cols = None, None
+        if rank == 0:
+            with open(os.path.join(tdir, "params.json"), "w") as f:
+                json.dump({"env": "Pioneer-v1", "env_config": ENV_CONFIG, "mode": mode, "num_envs": total_envs,
+                           **{k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()}}, f, indent=2)
         t0 = time.time()
         for it in range(1, training_iterations + 1):
             last = trainer.train()
             last.update({"experiment_id": experiment_id, "trial_id": trial_id, "time_total_s": time.time() - t0})
             if log:
                 log.write(json.dumps({k: v for k, v in last.items()}) + "\n"); log.flush()
+                if csv_log is None:
+                    csv_cols = list(last.keys())
+                    csv_log = open(os.path.join(tdir, "progress.csv"), "a")
+                    if csv_log.tell() == 0:
+                        csv_log.write(",".join(csv_cols) + "\n")
+                csv_log.write(",".join(str(last.get(c, "")) for c in csv_cols) + "\n"); csv_log.flush()
                 if monitor and it % log_every == 0:
                     print(f"[{trial_id}] iter {it} reward_mean {last['episode_reward_mean']:.2f} "
                           f"len {last['episode_len_mean']:.1f} steps/s {last['env_steps_per_s']:.3g}", flush=True)
@@ -84,6 +96,8 @@ def train(results_dir: str,
         trainer.save(os.path.join(tdir, "checkpoint_final.pt"))      # checkpoint_at_end=True, :73
         if log:
             log.close()
+        if csv_log:
+            csv_log.close()
         rows.append(last)
         env.close()
     try:

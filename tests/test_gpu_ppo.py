@@ -65,6 +65,12 @@ def test_launch_train_mirrors_reference_signature(tmp_path):
     for t in ("00000", "00001"):
         d = tmp_path / f"PPO_Pioneer-v1_{t}"
         assert (d / "checkpoint_2.pt").exists() and (d / "checkpoint_final.pt").exists() and (d / "result.json").exists()
+        # Tune's trial-directory files
+        import csv as _csv, json as _json
+        params = _json.load(open(d / "params.json"))
+        assert params["env"] == "Pioneer-v1" and params["env_config"]["award_done"] == 5.0 and "lr" in params
+        prog = list(_csv.DictReader(open(d / "progress.csv")))
+        assert len(prog) == len(open(d / "result.json").read().strip().splitlines()) and "episode_reward_mean" in prog[0]
     assert "episode_reward_mean" in dump(df)
 
 
