@@ -1,6 +1,8 @@
 """GPU smoke of the full rollout + learn loop (BASELINE config[2] shape, small)."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -222,3 +224,26 @@ def test_learner_fused_and_torch_losses_train_alike():
     (w0, i0), (w1, i1) = outs
     assert torch.allclose(w0, w1, atol=3e-5, rtol=1e-4)
     assert abs(i0["total_loss"] - i1["total_loss"]) < 1e-4 * max(1.0, abs(i0["total_loss"])) and abs(i0["kl"] - i1["kl"]) < 1e-5
+
+
+def test_evaluate_checkpoint_and_record_gif(tmp_path):
+    """The reference's eval script role (temp/pioneer_eval.py:53-78): restore a checkpoint, roll the policy out in
+    the single-env façade, record the frames."""
+    from PIL import Image
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    from pioneer_amd.evaluate import evaluate
+    from pioneer_amd.ppo import PPOConfig, PPOTrainer
+    env = PioneerVectorEnv(512, device="cuda:0", seed=1, engine_config=EngineConfig(max_episode_steps=20))
+    tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=8, num_sgd_iter=1, sgd_minibatch_size=2048))
+    tr.train(); tr.train()
+    ck = tr.save(str(tmp_path / "ck.pt"))
+    env.close()
+    gif = tmp_path / "eval.gif"
+    res = evaluate(ck, episodes=2, max_episode_steps=12, gif_path=str(gif), frame_stride=3)
+    assert len(res["episode_rewards"]) == 2 and all(1 <= n <= 12 for n in res["episode_lengths"])
+    assert all(np.isfinite(r) for r in res["episode_rewards"]) and res["frames"] >= 4
+    im = Image.open(gif)
+    assert im.is_animated and im.n_frames == res["frames"] and im.size == (1280, 800)     # RenderConfig defaults
+    # the stochastic policy runs too, and in dynamics mode
+    res2 = evaluate(ck, episodes=1, max_episode_steps=5, mode="dynamic", deterministic=False)
+    assert res2["episode_lengths"] == [5] or res2["successes"][0]
