@@ -20,6 +20,7 @@ import torch
 from . import dist as pdist
 from .config import EngineConfig, PioneerKinematicConfig
 from .ppo import PPOConfig, PPOTrainer, sample_entropy_start
+from .tb import ScalarWriter
 from .vector_env import PioneerVectorEnv
 
 ENV_CONFIG = {"award_potential_slope": 10.0, "award_done": 5.0, "penalty_step": 1 / 100}  # pioneer_knm_train.py:53-57
@@ -69,9 +70,11 @@ def train(results_dir: str,
                                engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=mode))
         trainer = PPOTrainer(env, cfg, use_graph=use_graph)   # hipGraph-captured sampling and updates
         last = {}
-        # the files Tune leaves in a trial directory: params.json, result.json (one line per iteration), progress.csv
+        # the files Tune leaves in a trial directory: params.json, result.json (one line per iteration), progress.csv,
+        # a TensorBoard event file
         log = open(os.path.join(tdir, "result.json"), "a") if rank == 0 else None
         csv_log, csv_cols = None, None
+        tb_log = ScalarWriter(tdir) if rank == 0 else None      # events.out.tfevents.*: `tensorboard --logdir results_dir`
         if rank == 0:
             with open(os.path.join(tdir, "params.json"), "w") as f:
                 json.dump({"env": "Pioneer-v1", "env_config": ENV_CONFIG, "mode": mode, "num_envs": total_envs,
@@ -88,6 +91,7 @@ def train(results_dir: str,
                     if csv_log.tell() == 0:
                         csv_log.write(",".join(csv_cols) + "\n")
                 csv_log.write(",".join(str(last.get(c, "")) for c in csv_cols) + "\n"); csv_log.flush()
+                tb_log.add_scalars(last, step=it)
                 if monitor and it % log_every == 0:
                     print(f"[{trial_id}] iter {it} reward_mean {last['episode_reward_mean']:.2f} "
                           f"len {last['episode_len_mean']:.1f} steps/s {last['env_steps_per_s']:.3g}", flush=True)
@@ -98,6 +102,8 @@ def train(results_dir: str,
             log.close()
         if csv_log:
             csv_log.close()
+        if tb_log:
+            tb_log.close()
         rows.append(last)
         env.close()
     try:

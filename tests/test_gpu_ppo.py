@@ -73,6 +73,10 @@ def test_launch_train_mirrors_reference_signature(tmp_path):
         assert params["env"] == "Pioneer-v1" and params["env_config"]["award_done"] == 5.0 and "lr" in params
         prog = list(_csv.DictReader(open(d / "progress.csv")))
         assert len(prog) == len(open(d / "result.json").read().strip().splitlines()) and "episode_reward_mean" in prog[0]
+        from pioneer_amd.tb import read_events
+        (evf,) = [f for f in os.listdir(d) if f.startswith("events.out.tfevents.")]
+        ev = read_events(str(d / evf))
+        assert [s_ for s_, _ in ev] == [0, 1, 2, 3] and "ray/tune/timesteps_total" in ev[-1][1]
     assert "episode_reward_mean" in dump(df)
 
 
