@@ -4,7 +4,8 @@
 Keeps the reference CLI's surface (cli.py:12-40 there: sub-command ``pioneer-train-kinem`` with
 ``-e/--experiment``, ``-c/--checkpoint-freq``, ``-n/--num-samples``, ``-w/--num-workers``,
 ``--no-monitor``; ``tracking.training_root`` and a ``logging`` dictConfig read from an optional
-``config.yaml`` next to this file) on top of ``pioneer_amd.launch.train``.  For several GPUs run it
+``config.yaml`` next to this file) on top of ``pioneer_amd.launch.train``, plus ``pioneer-eval`` (the role of the
+reference's temp/pioneer_eval.py: restore a checkpoint, roll out, record).  For several GPUs run it
 under ``python -m torch.distributed.run --nproc-per-node N cli.py pioneer-train-kinem ...``.
 """
 import argparse
@@ -46,12 +47,26 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("--iterations", type=int, default=1000)
     tr.add_argument("--envs-per-worker", type=int, default=4096)
     tr.add_argument("--mode", choices=["kinematic", "dynamic"], default="kinematic")
+    ev = sub.add_parser("pioneer-eval", help="roll a saved policy out in the single-env facade, optionally record a GIF")
+    ev.add_argument("-k", "--checkpoint", required=True, help="a checkpoint_*.pt written by pioneer-train-kinem")
+    ev.add_argument("--episodes", type=int, default=3)
+    ev.add_argument("--max-steps", type=int, default=500)
+    ev.add_argument("--gif", default=None)
+    ev.add_argument("--stochastic", action="store_true")
+    ev.add_argument("--mode", choices=["kinematic", "dynamic"], default="kinematic")
     return ap
 
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
     settings = load_settings()
+    if args.command == "pioneer-eval":
+        import json
+        from pioneer_amd.evaluate import evaluate
+        res = evaluate(args.checkpoint, args.episodes, args.max_steps, args.gif, mode=args.mode,
+                       deterministic=not args.stochastic, frame_stride=2)
+        print(json.dumps(res))
+        return 0
     from pioneer_amd.launch import RESULT_COLUMNS, dump, train
     out_dir = os.path.join(settings["tracking"]["training_root"], args.experiment)
     rows = train(results_dir=out_dir, checkpoint_freq=args.checkpoint_freq, num_samples=args.num_samples,
