@@ -6,7 +6,8 @@ experiment_id / trial_id as cli.py:32-38 selects them).  Ray Tune's trial fan-ou
 sequential loop of ``num_samples`` trials (each samples its entropy-coefficient start value
 log-uniformly in [1e-3, 1e-1], pioneer_knm_train.py:32-41,63); RLlib's rollout workers become
 one device-resident env batch per GPU (``num_workers`` scales the batch: workers x envs_per_worker).
-Launch with torch.distributed.run for several GPUs.
+``monitor`` is RLlib's episode recording switch there (:51): here it prints progress lines and writes one evaluation
+episode as ``monitor_<iteration>.gif`` next to every checkpoint.  Launch with torch.distributed.run for several GPUs.
 """
 import json
 import os
@@ -38,7 +39,8 @@ def train(results_dir: str,
           ppo_config: Optional[PPOConfig] = None,
           mode: str = "kinematic",
           log_every: int = 10,
-          use_graph: bool = True):
+          use_graph: bool = True,
+          monitor_steps: int = 500):
     """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list."""
     rank, local_rank, world = pdist.world_info()
     if os.environ.get("PNR_DIST_BACKEND") == "gloo":        # rehearsal: ranks may share the visible GPUs
@@ -96,8 +98,10 @@ def train(results_dir: str,
                     print(f"[{trial_id}] iter {it} reward_mean {last['episode_reward_mean']:.2f} "
                           f"len {last['episode_len_mean']:.1f} steps/s {last['env_steps_per_s']:.3g}", flush=True)
             if checkpoint_freq and it % checkpoint_freq == 0:
-                trainer.save(os.path.join(tdir, f"checkpoint_{it}.pt"))
-        trainer.save(os.path.join(tdir, "checkpoint_final.pt"))      # checkpoint_at_end=True, :73
+                ck = trainer.save(os.path.join(tdir, f"checkpoint_{it}.pt"))
+                _record(monitor and rank == 0, ck, os.path.join(tdir, f"monitor_{it}.gif"), device, mode, monitor_steps)
+        ck = trainer.save(os.path.join(tdir, "checkpoint_final.pt"))      # checkpoint_at_end=True, :73
+        _record(monitor and rank == 0, ck, os.path.join(tdir, "monitor_final.gif"), device, mode, monitor_steps)
         if log:
             log.close()
         if csv_log:
@@ -111,6 +115,19 @@ def train(results_dir: str,
         return pd.DataFrame(rows)
     except Exception:
         return rows
+
+
+def _record(enabled: bool, checkpoint: str, gif_path: str, device, mode: str, max_steps: int) -> None:
+    """RLlib's 'monitor': True (pioneer_knm_train.py:51) records episodes as videos into the results directory; here one
+    evaluation episode of the checkpointed policy is written as a GIF next to each checkpoint."""
+    if not enabled:
+        return
+    try:
+        from .evaluate import evaluate
+        evaluate(checkpoint, episodes=1, max_episode_steps=max_steps, gif_path=gif_path, device=device, mode=mode,
+                 frame_stride=4)
+    except Exception as exc:          # a recording problem must not end a training run
+        print(f"monitor: recording {gif_path} failed: {type(exc).__name__}: {exc}", flush=True)
 
 
 def dump(rows, cols=RESULT_COLUMNS) -> str:

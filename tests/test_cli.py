@@ -37,6 +37,7 @@ def test_train_then_eval_through_the_cli(tmp_path, monkeypatch, capsys):
     rc = cli.main(["pioneer-train-kinem", "-e", "smoke", "-c", "1", "-n", "1", "-w", "1", "--no-monitor",
                    "--iterations", "2", "--envs-per-worker", "256"])
     assert rc == 0
+    assert not list((tmp_path / "smoke" / "PPO_Pioneer-v1_00000").glob("monitor_*.gif"))
     out = capsys.readouterr().out
     assert "episode_reward_mean" in out and "00000" in out          # the github-style results table
     tdir = tmp_path / "smoke" / "PPO_Pioneer-v1_00000"
@@ -44,3 +45,18 @@ def test_train_then_eval_through_the_cli(tmp_path, monkeypatch, capsys):
     rc = cli.main(["pioneer-eval", "-k", str(tdir / "checkpoint_final.pt"), "--episodes", "1", "--max-steps", "6",
                    "--gif", str(tmp_path / "e.gif")])
     assert rc == 0 and (tmp_path / "e.gif").exists() and "episode_rewards" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_monitor_records_an_episode_per_checkpoint(tmp_path):
+    """monitor=True (RLlib's episode recording, pioneer_knm_train.py:51): a GIF next to every checkpoint."""
+    from PIL import Image
+    from pioneer_amd.launch import train
+    from pioneer_amd.ppo import PPOConfig
+    train(results_dir=str(tmp_path), checkpoint_freq=1, num_samples=1, num_workers=1, monitor=True, training_iterations=2,
+          envs_per_worker=256, ppo_config=PPOConfig(rollout_fragment_length=8, num_sgd_iter=1, sgd_minibatch_size=2048),
+          monitor_steps=9)
+    d = tmp_path / "PPO_Pioneer-v1_00000"
+    gifs = sorted(p.name for p in d.glob("monitor_*.gif"))
+    assert gifs == ["monitor_1.gif", "monitor_2.gif", "monitor_final.gif"]
+    assert Image.open(d / "monitor_final.gif").n_frames >= 1
