@@ -280,7 +280,7 @@ def main():
                  "frac": fb / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  "note": "pnr_rollout: same kernel, T steps per launch with open-loop actions; state stays in registers"}
 
-    def side_leg(nl, id_off, k, warm, note, bytes_per_env_step=BYTES_PER_ENV_STEP, sim=None, **engine_kw):
+    def side_leg(nl, id_off, k, warm, note, bytes_per_env_step=BYTES_PER_ENV_STEP, sim=None, rollout_T=0, **engine_kw):
         """pnr_step on a separate env batch of nl envs per GPU: wall time is the max over ranks between
         barriers, avg_launch_ms is rank 0's HIP-event timing."""
         lenv = PioneerVectorEnv(nl, device=dev, seed=0, env_id_offset=id_off, simulation_config=sim,
@@ -317,8 +317,31 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         lms = e0.elapsed_time(e1) / k
+        roll = None
+        if rollout_T > 1 and lring >= rollout_T:
+            # the same steps as ONE pnr_rollout launch per rollout_T steps (open-loop actions)
+            racts = (torch.rand((rollout_T,) + tuple(lenv.action_shape), generator=g, device=dev) * 2 - 1) * \
+                (amax if args.action_layout == "env_major" else amax[:, None])
+            rcall = lambda: _lib.check(lib.pnr_rollout(lh, rollout_T, P(racts, 0), P(lobs, 0), P(lrew, 0), P(ldone, 0), P(ltr, 0), sp), lh)  # noqa: E731
+            for _ in range(3):
+                rcall()
+            barrier()
+            r0 = time.perf_counter()
+            reps = max(4, k // rollout_T)
+            for _ in range(reps):
+                rcall()
+            barrier()
+            rel = time.perf_counter() - r0
+            if world > 1:
+                tmax = torch.tensor([rel], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                rel = float(tmax.item())
+            roll = {"steps_per_launch": rollout_T, "steps": reps * rollout_T, "ms_per_step": rel / (reps * rollout_T) * 1e3,
+                    "value": float(nl) * world * reps * rollout_T / rel, "unit": "env-steps/s"}
         lenv.close()
-        return {"envs_per_gpu": nl, "steps": k, "avg_launch_ms": lms, "ms_per_step": el / k * 1e3,
+        if roll:
+            note = note + "; `rollout`: pnr_rollout, the steps looped inside one launch"
+        return {**({"rollout": roll} if roll else {}), "envs_per_gpu": nl, "steps": k, "avg_launch_ms": lms, "ms_per_step": el / k * 1e3,
                 "value": float(nl) * world * k / el, "unit": "env-steps/s",
                 "env_steps_per_s_per_gpu": nl / (lms * 1e-3),
                 "achieved_GBps": bytes_per_env_step * nl / (lms * 1e-3) / 1e9,
@@ -338,7 +361,7 @@ def main():
         dynamic = side_leg(n, (2 * world + rank) * n + world * args.large_envs, 512, 64,
                            "mode=dynamic, randomize=True, gravity 9.81: dyn_step_kernel (sub-steps one env per lane with packed "
                            "fp32 ABA, VALU-bound; then lane pairs finish reward/obs); algorithmic bytes 842 B per env-step",
-                           bytes_per_env_step=842, sim=SimulationConfig(gravity=9.81), mode="dynamic", randomize=True)
+                           bytes_per_env_step=842, sim=SimulationConfig(gravity=9.81), rollout_T=32, mode="dynamic", randomize=True)
 
     # BASELINE config[3] read literally: 65 536 envs IN TOTAL, sharded over the ranks (strong scaling;
     # 8 192 envs per GPU at N=8, where one launch is shorter than the launch floor)

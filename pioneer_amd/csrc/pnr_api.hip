@@ -190,13 +190,17 @@ __global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_
 }
 
 // ---------------------------------------------------------------------------------
-// dynamics-mode step: ONE launch per env-step.  A workgroup is one wave and owns 64 envs.
-//   phase A  one env per lane: command integration + the ABA sub-steps (pnr_dyn.h), results handed
-//            over through LDS in the HBM record layout;
+// dynamics-mode step: ONE launch per pnr_step / pnr_rollout.  A workgroup is one wave and owns 64 envs.
+//   phase A  one env per lane: command integration + the ABA sub-steps (pnr_dyn.h); a, v, r, q, qd of the
+//            env stay in that lane's registers for all T steps of the launch and are handed to phase B
+//            through LDS every step;
 //   phase B  the lanes regroup as pairs (as in step_kernel) and finish two 32-env tiles: reward,
-//            TimeLimit, auto-reset, state and q/qd write-back, observation through the LDS tile.
-// The hand-off area is the head of the obs tile: both tiles' records are read into registers before
-// the first observation is packed.
+//            TimeLimit, auto-reset, observation through the LDS tile; the pair lanes keep target,
+//            potential, step and episode counters of their envs in registers.  A reset is reported back
+//            to the env's phase-A lane through a small LDS note (episode counter + the new r), which
+//            re-draws the per-env parameters itself.
+// The hand-off area is the head of the obs tile: both tiles' values are read into registers before the
+// first observation is packed.  With T > 1 the obs stores of step t drain under the sub-steps of t + 1.
 // ---------------------------------------------------------------------------------
 constexpr int kDynEnvsPerWg = kWave;                       // phase A: one env per lane
 constexpr int kHandRecFloats = 3 * 2 * kDynEnvsPerWg * 4;  // three float4 planes of 2 records per env
@@ -349,6 +353,233 @@ __global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restric
     dyn_finish_tile<OBS_EM>(P, D, K, raw0, dq0, dqd0, tile, base, lane, false);
     if (base + kEnvsPerWave < n)
         dyn_finish_tile<OBS_EM>(P, D, K, raw1, dq1, dqd1, tile, base + kEnvsPerWave, lane, true);
+}
+
+
+constexpr int kComFloats = 2 * kWave * 4;                  // common words of each lane's two envs between steps: float4 [2][64]
+constexpr int kRstFloats = (1 + kDof) * kDynEnvsPerWg;     // reset notes: episode flag + new r [7][64]
+
+struct DynTileRegs {      // what phase A handed over for this lane's record of one env
+    RawState raw;         // a, v, r of the lane's three joints (+ the common words on the first step)
+    float q[kJpl], qd[kJpl];
+};
+
+__device__ __forceinline__ void dyn_write_handoff(float* hand, int lane, const DynLane& L)
+{
+    float4* hrec = reinterpret_cast<float4*>(hand);               // [3][2 * 64] records, index 2 * env + p
+    float* hq = hand + kHandRecFloats;                            // [12][64]: q then qd
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        hrec[2 * lane + p] = make_float4(L.a[3 * p], L.a[3 * p + 1], L.a[3 * p + 2], L.v[3 * p]);
+        hrec[2 * kDynEnvsPerWg + 2 * lane + p] = make_float4(L.v[3 * p + 1], L.v[3 * p + 2], L.r[3 * p], L.r[3 * p + 1]);
+        hrec[4 * kDynEnvsPerWg + 2 * lane + p] = make_float4(L.r[3 * p + 2], L.cw[p][0], L.cw[p][1], L.cw[p][2]);
+    }
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) {
+        hq[i * kDynEnvsPerWg + lane] = L.q[i];
+        hq[(kDof + i) * kDynEnvsPerWg + lane] = L.qd[i];
+    }
+}
+
+__device__ __forceinline__ void dyn_read_handoff(const float* hand, int env, int p, DynTileRegs& g)
+{
+    const float4* hrec = reinterpret_cast<const float4*>(hand);
+    const float* hq = hand + kHandRecFloats;
+    const int r = 2 * env + p;
+    g.raw = {hrec[r], hrec[2 * kDynEnvsPerWg + r], hrec[4 * kDynEnvsPerWg + r]};
+#pragma unroll
+    for (int i = 0; i < kJpl; ++i) {
+        g.q[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + env];
+        g.qd[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + env];
+    }
+}
+
+// One 32-env tile of phase B.  The env's common words (target | potential, step, episode) arrive with the first
+// hand-off; between the steps of a looped launch they wait in `com` (LDS), so that nothing of phase B stays in
+// registers during the sub-steps.
+template <bool OBS_EM>
+__device__ __forceinline__ void dyn_rollout_tile(const KParams& P, const DynParams& D, const LaneConsts& K, const DynTileRegs& in,
+                                                float4* com, float* tile, float* rst, long long tile0, int t, int lane,
+                                                bool tile_in_use)
+{
+    const int p = lane & 1, el = lane >> 1;
+    const long long n = P.n;
+    const long long e = tile0 + el;
+    const bool valid = e < n;               // the pair shares `valid`, so DPP partners are live
+    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
+    const bool last = t == P.T - 1;
+
+    LaneState s;
+    {
+        RawState raw = in.raw;
+        if (t > 0) { const float4 c = *com; raw.p2.y = c.y; raw.p2.z = c.z; raw.p2.w = c.w; }
+        unpack_state(raw, p, s);            // a, v, r of this lane's joints + the env's common words
+    }
+    LaneState o = s;                        // what reward / obs see: the simulated q, qd
+#pragma unroll
+    for (int i = 0; i < kJpl; ++i) {
+        o.r[i] = in.q[i];
+        // teleport = reference semantics: obs shows the env's own v (pioneer_knm_env.py:202)
+        o.v[i] = D.teleport ? s.v[i] : in.qd[i];
+    }
+    s.step += 1;                                                  // bullet_env.py:193
+    o.step = s.step;
+
+    Pose q;
+    compute_pose(o, p, q);
+
+    // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
+    const float old_pot = s.pot;
+    const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
+    const bool done = q.dist < P.done_dist;                       // :160
+    const float r_pot = pot - old_pot;
+    const float r_step = -P.penalty;
+    const float r_done = done ? P.award_done : 0.0f;
+    const float rw = (r_pot + r_step) + r_done;                   // :165
+    s.pot = pot;
+    // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
+    bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
+    // a lane whose simulation diverged (non-finite pose) is cut like a time-out, so auto-reset recovers
+    // it instead of carrying NaNs forever (kinematic mode keeps the reference's NaN-propagating behaviour)
+    if (!(q.dist == q.dist && __builtin_fabsf(q.dist) <= 3.0e38f)) trunc = !done;
+
+    if (valid && p == 0) {
+        const long long oi = (long long)t * n + e;
+        stream_store(P.reward + oi, rw);
+        stream_store(P.done + oi, (uint8_t)done);
+        if (P.trunc) stream_store(P.trunc + oi, (uint8_t)trunc);
+        if (P.info) stream_store(reinterpret_cast<float4*>(P.info) + oi, make_float4(r_pot, r_step, r_done, q.dist));
+    }
+
+    // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
+    // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
+    o.pot = pot;
+    const bool redraw = P.auto_reset && (done || trunc);
+    if (redraw) {
+        reset_env(P, K, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
+        if (valid) {
+            dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);   // q = r, qd = 0, new draws
+            // note for the env's phase-A lane: the counter after the reset (>= 1) and the new joints
+            const int env = el + (int)(tile0 & (kDynEnvsPerWg - 1));
+            if (p == 0) rst[env] = __uint_as_float(s.episode);
+#pragma unroll
+            for (int i = 0; i < kJpl; ++i) rst[(1 + kJpl * p + i) * kDynEnvsPerWg + env] = s.r[i];
+        }
+        o = s;
+        compute_pose(o, p, q);
+    }
+    if (valid && last) {
+        store_state(P.state, n, 2 * tile0 + lane, p, s);
+        if (!redraw) {
+#pragma unroll
+            for (int i = 0; i < kJpl; ++i) {
+                D.dyn[(long long)(kJpl * p + i) * n + e] = in.q[i];
+                D.dyn[(long long)(6 + kJpl * p + i) * n + e] = in.qd[i];
+            }
+        }
+    }
+    *com = make_float4(0.f, p ? s.pot : s.tgt[0], p ? __uint_as_float(s.step) : s.tgt[1],
+                        p ? __uint_as_float(s.episode) : s.tgt[2]);
+
+    // -- observe() ----------------------------------------------------------------
+    float* obs_t = P.obs + (long long)t * n * kObsDim;
+    if (tile_in_use) wave_lds_sync();       // previous flush done before the tile is rewritten
+    if (OBS_EM) {
+        SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
+        emit_obs<false>(K, o, q, p, sink);
+        wave_lds_sync();
+        flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
+    } else {
+        SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
+        emit_obs<false>(K, o, q, p, sink);
+        wave_lds_sync();
+        flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
+    }
+}
+
+// pnr_rollout in dynamics mode: P.T steps in ONE launch.  Same two phases as dyn_step_kernel, but the env's
+// a, v, r, q, qd and parameters stay in its phase-A lane's registers from step to step, the pair lanes keep the
+// common words (target | potential, step, episode) in LDS between steps, and a reset travels back to the phase-A
+// lane as a small LDS note (episode counter + the new r) from which that lane re-draws the parameters itself.
+// The obs stores of step t drain under the sub-steps of step t + 1.  The hand-off has its own 9 KB here (the
+// kernel runs one wave per SIMD anyway), so a tile's values are read right before that tile is finished and
+// nothing of phase B is live during the sub-steps.
+template <bool OBS_EM, bool ACT_EM, bool RAND>
+__global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
+                                                         const float* __restrict__ actions_, const long long n_,
+                                                         const double dt_, const double eps_, const float max_v_to_r_,
+                                                         const KParams P, const DynParams D)
+{
+    __shared__ __attribute__((aligned(16))) float lds[kTileFloats + kComFloats + kRstFloats + kHandFloats];
+    float* tile = lds;
+    float4* com = reinterpret_cast<float4*>(lds + kTileFloats);   // [2][64] common words between steps, index tile * 64 + lane
+    float* rst = lds + kTileFloats + kComFloats;                  // [7][64] reset notes, phase B -> phase A
+    float* hand = lds + kTileFloats + kComFloats + kRstFloats;    // records + q, qd planes (kHandFloats)
+    const int lane = threadIdx.x;
+    const int p = lane & 1, el = lane >> 1;
+    const long long n = n_;
+    const long long base = (long long)blockIdx.x * kDynEnvsPerWg;
+    const long long eA = base + lane;                             // phase A: this lane's env
+    const bool liveA = eA < n;
+    const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
+
+    DynLane L;
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { L.a[i] = L.v[i] = L.r[i] = L.q[i] = L.qd[i] = 0.f; L.fric[i] = L.damp[i] = 0.f; }
+#pragma unroll
+    for (int l = 0; l < kNumLinks; ++l) L.sc[l] = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { L.cw[0][k] = 0.f; L.cw[1][k] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) L.act[i] = 0.f;
+    if (liveA) dyn_lane_load<ACT_EM, RAND>(lead, base, lane, L);
+    {   // the 36 constant obs entries of this lane's tile slots: once per kernel (nothing else writes them)
+        const LaneConsts K0 = lane_consts(p);
+        if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K0, sink); }
+        else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K0, sink); }
+    }
+
+    const int T = P.T;
+    for (int t = 0; t < T; ++t) {
+        // ---- phase A: one env per lane
+        if (liveA) dyn_lane_advance<ACT_EM, RAND>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L);
+        dyn_write_handoff(hand, lane, L);
+        rst[lane] = 0.f;                                // no reset noted yet (episode counters are >= 1)
+        wave_lds_sync();
+
+        // ---- phase B: lane pairs
+        {
+            // everything phase B derives from the lane id (pair constants, tile and output addresses) is re-derived
+            // from an opaque copy each step: hoisted out of the t loop it would sit in registers during the sub-steps
+            int lane_b = lane;
+            asm volatile("" : "+v"(lane_b));
+            const int pb = lane_b & 1, elb = lane_b >> 1;
+            const LaneConsts Kb = lane_consts(pb);
+            {
+                DynTileRegs g;
+                dyn_read_handoff(hand, elb, pb, g);
+                dyn_rollout_tile<OBS_EM>(P, D, Kb, g, com + lane_b, tile, rst, base, t, lane_b, t > 0);
+            }
+            if (base + kEnvsPerWave < n) {
+                DynTileRegs g;
+                dyn_read_handoff(hand, kEnvsPerWave + elb, pb, g);
+                dyn_rollout_tile<OBS_EM>(P, D, Kb, g, com + kWave + lane_b, tile, rst, base + kEnvsPerWave, t, lane_b, true);
+            }
+            // ---- back to phase A: envs that were reset continue from the new draw
+            if (t + 1 < T) {
+                wave_lds_sync();
+                const uint32_t ep = __float_as_uint(rst[lane]);
+                if (liveA && ep != 0u) {
+#pragma unroll
+                    for (int j = 0; j < kDof; ++j) {
+                        L.r[j] = rst[(1 + j) * kDynEnvsPerWg + lane];
+                        L.a[j] = 0.f; L.v[j] = 0.f; L.q[j] = L.r[j]; L.qd[j] = 0.f;
+                    }
+                    if (RAND) dyn_draw_params(P, D, P.env_off + (unsigned long long)eA, ep - 1u, L.sc, L.fric, L.damp);
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -798,21 +1029,20 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     const DynParams& D = h->dbase;
     const bool oem = h->cfg.obs_layout == PNR_ENV_MAJOR, aem = h->cfg.action_layout == PNR_ENV_MAJOR;
     if (h->cfg.mode == PNR_MODE_DYNAMIC) {
-        // one launch per step: dyn_step_kernel runs the sub-steps one env per lane, then finishes the
-        // step (reward / TimeLimit / auto-reset / obs) as lane pairs
+        // one launch: dyn_step_kernel runs the sub-steps one env per lane, then finishes each step (reward /
+        // TimeLimit / auto-reset / obs) as lane pairs, T times
         const dim3 gridD((unsigned)((h->n + kDynEnvsPerWg - 1) / kDynEnvsPerWg));
         // link scales differ from 1 only under randomisation (or after pnr_set_dyn_state, which marks it)
         const bool rnd = h->cfg.randomize || h->dyn_set;
-        for (int t = 0; t < T; ++t) {
-            KParams Pt = P;
-            Pt.T = 1;
-            Pt.actions = actions + (long long)t * h->n * kDof;
-            Pt.obs = obs + (long long)t * h->n * kObsDim;
-            Pt.reward = reward + (long long)t * h->n;
-            Pt.done = done + (long long)t * h->n;
-            Pt.trunc = truncated ? truncated + (long long)t * h->n : nullptr;
-#define PNR_DYN_LAUNCH(O, A, R) hipLaunchKernelGGL((dyn_step_kernel<O, A, R>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, \
-                                              Pt.n, Pt.dt, Pt.eps, (float)h->cfg.max_v_to_r, Pt, D)
+        {
+            const KParams& Pt = P;
+            // T > 1: dyn_rollout_kernel loops over the steps inside the launch (state in registers, stores of step t
+            // under the sub-steps of t + 1); T == 1: the lean single-step kernel
+#define PNR_DYN_LAUNCH(O, A, R) do { \
+        if (T > 1) hipLaunchKernelGGL((dyn_rollout_kernel<O, A, R>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
+                                      Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); \
+        else hipLaunchKernelGGL((dyn_step_kernel<O, A, R>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
+                                Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); } while (0)
             if (oem) {
                 if (aem) { if (rnd) PNR_DYN_LAUNCH(true, true, true); else PNR_DYN_LAUNCH(true, true, false); }
                 else { if (rnd) PNR_DYN_LAUNCH(true, false, true); else PNR_DYN_LAUNCH(true, false, false); }

@@ -567,6 +567,166 @@ struct DynLead {
     long long n; double dt, eps; float max_v_to_r;
 };
 
+// What a phase-A lane keeps in registers for its env across the steps of one launch.
+struct DynLane {
+    float a[kDof], v[kDof], r[kDof];            // the kinematic command state
+    float q[kDof], qd[kDof];                    // the simulated joints
+    float sc[kNumLinks], fric[kDof], damp[kDof];
+    float cw[2][3];                             // the env's common words as loaded (target | potential, step, episode):
+                                                // passed on to phase B with the first hand-off, not used after it
+    float act[kDof];                            // the action of the NEXT advance, requested one step ahead
+};
+
+// All phase-A addresses are formed as (wave-uniform plane pointer incl. the workgroup's first env) + lane: the
+// uniform part is scalar arithmetic and the loads take the SGPR-base + 32-bit-offset form.  Written as
+// `ptr[i * n + e]` with a 64-bit per-lane `e`, the 40-odd plane addresses became v_mad_u64_u32 chains whose
+// temporaries overlapped load destinations, so the compiler split the load burst with s_waitcnt vmcnt(0) —
+// one more memory round trip per split before the first sub-step.
+template <bool ACT_EM>
+__device__ __forceinline__ void dyn_load_action(const float* __restrict__ actions, long long n, long long base, int lane,
+                                                float (&act)[kDof])
+{
+    if (ACT_EM) {
+        const float2* a2 = reinterpret_cast<const float2*>(actions + base * kDof);
+        const float2 x0 = a2[3 * lane], x1 = a2[3 * lane + 1], x2 = a2[3 * lane + 2];
+        act[0] = x0.x; act[1] = x0.y; act[2] = x1.x; act[3] = x1.y; act[4] = x2.x; act[5] = x2.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) act[i] = (actions + (long long)i * n + base)[lane];
+    }
+}
+
+// RAND = per-env link scales (domain randomisation): loaded from the dyn words; otherwise every scale
+// is 1 and the model folds into literals.  Every load of the kernel is issued here, before the first wait.
+template <bool ACT_EM, bool RAND>
+__device__ __forceinline__ void dyn_lane_load(const DynLead& in, long long base, int lane, DynLane& L)
+{
+    const long long n = in.n;
+    const long long n2 = 2 * n;
+    float4 k0[2], k1[2], k2[2];
+    const float4* s0 = in.state + 2 * base;                       // record 2 * env + p of plane 0 for this workgroup
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        k0[p] = s0[2 * lane + p]; k1[p] = (s0 + n2)[2 * lane + p]; k2[p] = (s0 + 2 * n2)[2 * lane + p];
+    }
+    // the 35 planar dyn words through ONE walking pointer (plane p at dyn + p * n): two address registers in all
+    const float* w = in.dyn + base + lane;
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { L.q[i] = *w; w += n; }
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { L.qd[i] = *w; w += n; }
+#pragma unroll
+    for (int l = 0; l < kNumLinks; ++l) { L.sc[l] = RAND ? *w : 1.0f; w += n; }
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { L.fric[i] = *w; w += n; }
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { L.damp[i] = *w; w += n; }
+    dyn_load_action<ACT_EM>(in.actions, n, base, lane, L.act);   // the first step's action, with everything else
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        L.a[3 * p] = k0[p].x; L.a[3 * p + 1] = k0[p].y; L.a[3 * p + 2] = k0[p].z; L.v[3 * p] = k0[p].w;
+        L.v[3 * p + 1] = k1[p].x; L.v[3 * p + 2] = k1[p].y; L.r[3 * p] = k1[p].z; L.r[3 * p + 1] = k1[p].w;
+        L.r[3 * p + 2] = k2[p].x;
+        L.cw[p][0] = k2[p].y; L.cw[p][1] = k2[p].z; L.cw[p][2] = k2[p].w;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Phase A of a dynamics step for ONE env in this lane: kinematic command integration (the
+// parity-mode integrator) with the action of this step, then nsub sub-steps of ABA + PD.
+// Nothing is stored here: pnr::dyn_step_kernel hands the results to its pair lanes through LDS.
+// ---------------------------------------------------------------------------------
+// The arithmetic of phase A, shared by the single-step and the rollout kernels (one text, so that both produce
+// the same bits): command integration with the action latched for the next step, then nsub sub-steps of ABA + PD.
+__device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, float (&a)[kDof], float (&v)[kDof],
+                                         float (&r)[kDof], float (&q)[kDof], float (&qd)[kDof], const float (&sc)[kNumLinks],
+                                         const float (&fric)[kDof], const float (&damp)[kDof], const float (&act)[kDof])
+{
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) {
+        integrate_joint(a[i], v[i], r[i], in.max_v_to_r * (limit_hi(i) - limit_lo(i)), limit_lo(i), limit_hi(i),
+                        in.dt, in.eps, v[i], r[i]);
+        a[i] = act[i];
+    }
+
+    DynModel M;
+    build_model(sc, M);
+
+    if (D.teleport) {   // resetJointState semantics: pioneer_knm_env.py:148, bullet_scene.py:157-165
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) { q[i] = r[i]; qd[i] = 0.f; }
+    }
+    // wave-uniform options folded into the arithmetic once, so the sub-step loop carries no branches:
+    // teleport = no motor torque (gains 0), no torque cap = cap at +inf
+    const float kp = D.teleport ? 0.f : D.kp, kd = D.teleport ? 0.f : D.kd;
+    const float tcap = D.tau_max > 0.f ? D.tau_max : __builtin_inff();
+    for (int k = 0; k < D.nsub; ++k) {
+        float tau[kDof], qdd[kDof];
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) {
+            float tq = kp * (r[i] - q[i]) + kd * (v[i] - qd[i]);
+            tq = fminf(fmaxf(tq, -tcap), tcap);
+            tq -= damp[i] * qd[i];
+            tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
+            tau[i] = tq;
+        }
+        aba(D, M, q, qd, tau, qdd);
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits (selects, no branches)
+            const float hi = limit_hi(i), lo = limit_lo(i);
+            const float qdn = qd[i] + qdd[i] * D.dt_sub;
+            const float qn = q[i] + qdn * D.dt_sub;
+            const bool over = qn > hi, under = qn < lo;
+            q[i] = over ? hi : (under ? lo : qn);
+            qd[i] = ((over && qdn > 0.f) || (under && qdn < 0.f)) ? 0.f : qdn;
+        }
+    }
+}
+
+template <bool ACT_EM, bool RAND>
+__device__ __forceinline__ void dyn_lane_advance(const DynLead& in, const DynParams& D, long long base, int lane,
+                                                 const float* __restrict__ next_actions, DynLane& L)
+{
+    float act[kDof];
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) act[i] = L.act[i];
+    // the action after this one is requested now: it arrives under the sub-steps (next_actions: null on the last step)
+    if (next_actions) dyn_load_action<ACT_EM>(next_actions, in.n, base, lane, L.act);
+    dyn_core(in, D, L.a, L.v, L.r, L.q, L.qd, L.sc, L.fric, L.damp, act);
+}
+
+// The per-env parameter draws of a reset: Philox blocks 3..8 of the env's counter (the joints and the target
+// use blocks 0..2, reset_env), 11 link-mass scales, 6 friction and 6 damping coefficients; the configured
+// defaults without randomisation.
+__device__ __forceinline__ void dyn_draw_params(const KParams& P, const DynParams& D, unsigned long long genv,
+                                                uint32_t episode_drawn, float (&sc)[kNumLinks], float (&fric)[kDof],
+                                                float (&damp)[kDof])
+{
+    float u[24] = {};
+    if (D.randomize) {
+#pragma unroll
+        for (uint32_t b = 0; b < 6; ++b) {
+            uint32_t o[4];
+            philox4x32_10(episode_drawn, (uint32_t)genv, (uint32_t)(genv >> 32), 3 + b, P.seed_lo, P.seed_hi, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[4 * b + k] = (float)u01(o[k]);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < kNumLinks; ++l) sc[l] = D.randomize ? (float)(D.mass_lo + D.mass_span * (double)u[l]) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < kDof; ++j) {
+        fric[j] = D.randomize ? (float)(D.fric_lo + D.fric_span * (double)u[11 + j]) : D.joint_friction;
+        damp[j] = D.randomize ? (float)(D.damp_lo + D.damp_span * (double)u[17 + j]) : D.joint_damping;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Single-step form of phase A (pnr_step): load, dyn_core, re-pack, in one piece.  Kept next to the rollout
+// kernel's dyn_lane_load + dyn_lane_advance: that split form has the same instruction counts but ran 2 % slower as
+// the single-step kernel (A/B inside one library: 32.15 vs 32.85 us per 65 536-env step; SQ_WAIT_INST_ANY +40 %).
+// In: nothing but the env index.  Out: the env's two state records as they lie in HBM (a, v, r updated), q, qd.
+// ---------------------------------------------------------------------------------
 template <bool ACT_EM, bool RAND>
 __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynParams& D, long long e,
                                                   float4 (&k0)[2], float4 (&k1)[2], float4 (&k2)[2],
@@ -604,49 +764,12 @@ __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynPa
 #pragma unroll
         for (int i = 0; i < kDof; ++i) act[i] = in.actions[(long long)i * n + e];
     }
-#pragma unroll
-    for (int i = 0; i < kDof; ++i) {
-        integrate_joint(a[i], v[i], r[i], in.max_v_to_r * (limit_hi(i) - limit_lo(i)), limit_lo(i), limit_hi(i), in.dt, in.eps, v[i], r[i]);
-        a[i] = act[i];
-    }
+    dyn_core(in, D, a, v, r, q, qd, sc, fric, damp, act);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         k0[p] = make_float4(a[3 * p], a[3 * p + 1], a[3 * p + 2], v[3 * p]);
         k1[p] = make_float4(v[3 * p + 1], v[3 * p + 2], r[3 * p], r[3 * p + 1]);
         k2[p].x = r[3 * p + 2];
-    }
-
-    DynModel M;
-    build_model(sc, M);
-
-    if (D.teleport) {   // resetJointState semantics: pioneer_knm_env.py:148, bullet_scene.py:157-165
-#pragma unroll
-        for (int i = 0; i < kDof; ++i) { q[i] = r[i]; qd[i] = 0.f; }
-    }
-    // wave-uniform options folded into the arithmetic once, so the sub-step loop carries no branches:
-    // teleport = no motor torque (gains 0), no torque cap = cap at +inf
-    const float kp = D.teleport ? 0.f : D.kp, kd = D.teleport ? 0.f : D.kd;
-    const float tcap = D.tau_max > 0.f ? D.tau_max : __builtin_inff();
-    for (int k = 0; k < D.nsub; ++k) {
-        float tau[kDof], qdd[kDof];
-#pragma unroll
-        for (int i = 0; i < kDof; ++i) {
-            float tq = kp * (r[i] - q[i]) + kd * (v[i] - qd[i]);
-            tq = fminf(fmaxf(tq, -tcap), tcap);
-            tq -= damp[i] * qd[i];
-            tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
-            tau[i] = tq;
-        }
-        aba(D, M, q, qd, tau, qdd);
-#pragma unroll
-        for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits (selects, no branches)
-            const float hi = limit_hi(i), lo = limit_lo(i);
-            const float qdn = qd[i] + qdd[i] * D.dt_sub;
-            const float qn = q[i] + qdn * D.dt_sub;
-            const bool over = qn > hi, under = qn < lo;
-            q[i] = over ? hi : (under ? lo : qn);
-            qd[i] = ((over && qdn > 0.f) || (under && qdn < 0.f)) ? 0.f : qdn;
-        }
     }
 }
 
@@ -661,32 +784,22 @@ __device__ __forceinline__ void dyn_reset_lane(const KParams& P, const DynParams
         D.dyn[(long long)(kJpl * p + i) * n + e] = s.r[i];
         D.dyn[(long long)(6 + kJpl * p + i) * n + e] = 0.f;
     }
-    float u[24] = {};
-    if (D.randomize) {
-#pragma unroll
-        for (uint32_t b = 0; b < 6; ++b) {
-            uint32_t o[4];
-            philox4x32_10(episode_drawn, (uint32_t)genv, (uint32_t)(genv >> 32), 3 + b, P.seed_lo, P.seed_hi, o);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u[4 * b + k] = (float)u01(o[k]);
-        }
-    }
+    float sc[kNumLinks], fric[kDof], damp[kDof];
+    dyn_draw_params(P, D, genv, episode_drawn, sc, fric, damp);
     // lane 0 writes the link scales, each lane its own joints' friction / damping
     if (p == 0) {
 #pragma unroll
-        for (int l = 0; l < kNumLinks; ++l)
-            D.dyn[(long long)(12 + l) * n + e] = D.randomize ? (float)(D.mass_lo + D.mass_span * (double)u[l]) : 1.0f;
+        for (int l = 0; l < kNumLinks; ++l) D.dyn[(long long)(12 + l) * n + e] = sc[l];
     }
 #pragma unroll
     for (int i = 0; i < kJpl; ++i) {
         const int j = kJpl * p + i;
-        // both candidates become plain register values first: left as `p ? u[a] : u[b]`, LLVM folds the
+        // both candidates become plain register values first: left as `p ? x[a] : x[b]`, LLVM folds the
         // select into the address and the whole array is demoted to scratch (cf. lane_consts)
-        float uf0 = u[11 + i], uf1 = u[11 + kJpl + i], ud0 = u[17 + i], ud1 = u[17 + kJpl + i];
-        asm volatile("" : "+v"(uf0), "+v"(uf1), "+v"(ud0), "+v"(ud1));
-        const float uf = p ? uf1 : uf0, ud = p ? ud1 : ud0;
-        D.dyn[(long long)(23 + j) * n + e] = D.randomize ? (float)(D.fric_lo + D.fric_span * (double)uf) : D.joint_friction;
-        D.dyn[(long long)(29 + j) * n + e] = D.randomize ? (float)(D.damp_lo + D.damp_span * (double)ud) : D.joint_damping;
+        float f0 = fric[i], f1 = fric[kJpl + i], d0 = damp[i], d1 = damp[kJpl + i];
+        asm volatile("" : "+v"(f0), "+v"(f1), "+v"(d0), "+v"(d1));
+        D.dyn[(long long)(23 + j) * n + e] = p ? f1 : f0;
+        D.dyn[(long long)(29 + j) * n + e] = p ? d1 : d0;
     }
 }
 
