@@ -241,3 +241,28 @@ def test_dynamic_rollout_with_randomised_resets_equals_steps(n):
     o1, r1, _, _ = e1.vector_step(a); o2, r2, _, _ = e2.vector_step(a)
     assert _close(o1, o2, ROLL_OBS_TOL) and _close(r1, r2, ROLL_REW_TOL)
     e1.close(); e2.close()
+
+
+def test_full_size_65536_rollout_properties():
+    """BASELINE config[4] size through the in-launch rollout kernel: finite outputs, joints inside their limits, every
+    env truncated exactly when its TimeLimit says so, counters consistent after the launch."""
+    n, T, cap = 65536, 12, 5
+    env, _ = make(n, seed=2, auto_reset=True, max_steps=cap, gravity=9.81, randomize=1)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = (torch.rand(T, n, 6, generator=g, device="cuda") * 2 - 1) * torch.from_numpy(env.a_max).cuda()
+    obs, rew, done, trunc = env.rollout(acts)
+    assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
+    q = obs[..., 0:6]
+    assert bool((q <= torch.from_numpy(env.r_hi).cuda() + 1e-6).all()) and bool((q >= torch.from_numpy(env.r_lo).cuda() - 1e-6).all())
+    ended = (done | trunc).bool()
+    # without early successes an env is cut at steps 5 and 10 (0-based 4 and 9) and nowhere else
+    no_success = ~done.bool().any(0)
+    sched = torch.zeros(T, dtype=torch.bool, device="cuda"); sched[cap - 1::cap] = True
+    assert bool((ended[:, no_success] == sched[:, None]).all())
+    st = env.get_state()
+    steps, episodes = st[22].long(), st[23].long()
+    assert bool((steps[no_success] == T % cap).all()) and bool((episodes[no_success] == 1 + T // cap).all())
+    dynw = env.get_dyn_state()
+    assert bool(torch.isfinite(dynw[:35]).all()) and float(dynw[12:23].min()) >= 0.5 and float(dynw[12:23].max()) <= 1.5
+    env.close()
