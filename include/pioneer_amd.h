@@ -181,7 +181,9 @@ int pnr_step(pnr_handle h, const float* actions, float* obs, float* reward,
  * T consecutive steps in ONE launch with open-loop actions (state stays in
  * registers between steps).  Buffers are the pnr_step ones with a leading
  * [T] axis: actions [T][N x 6], obs [T][N x 137], reward/done/truncated [T][N].
- * Same results as T calls of pnr_step.
+ * Same results as T calls of pnr_step: bit for bit in kinematic mode; in dynamics mode
+ * the simulated quantities agree to float32 rounding (two kernels, contraction allowed),
+ * command state, counters, targets and per-env draws bit for bit.
  */
 int pnr_rollout(pnr_handle h, int32_t T, const float* actions, float* obs,
                 float* reward, uint8_t* done, uint8_t* truncated, void* stream);
