@@ -1,26 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/sec of the Pioneer-arm hot path on N MI355X.
 
-One "step" = one pass of the hot path (BulletEnv.step of the reference:
-integrate + FK + reward + TimeLimit + auto-reset + 137-float observation) over
-the whole env batch of a rank, with synthetic actions already resident in HBM.
-N=1 workload = the configuration BASELINE.json's metric is quoted on: 65 536
-Pioneer-arm envs on one GPU.  For N>1 every rank steps its own 65 536-env shard
-(global env ids rank*65536..; no data-path collective — envs are independent),
-so scaling is "weak".  Extra legs in the same JSON line (never part of `value`): "fused_rollout"
-(pnr_rollout, T steps per launch), "large_batch" (262 144 envs per launch), at N>1 "strong_scaling"
-(65 536 envs IN TOTAL sharded over the ranks), "dynamics_randomized" (BASELINE config[4]) and "ppo_loop" (BASELINE config[2] at N=1, config[3] at
-N>1: the full rollout+learn loop with the gradient all-reduce over RCCL), "cpu_baseline" at N=1.
-Launch for N>1:
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line.
+One "step" = one pass of the hot path (BulletEnv.step of the reference: integrate + FK + reward +
+TimeLimit + auto-reset + 137-float observation) over the env batch, with synthetic actions already
+resident in HBM.  The workload is the configuration BASELINE.json's metric is quoted on: 65 536
+Pioneer-arm envs IN TOTAL.  At N=1 they all live on one GPU; at N>1 the env axis is sharded in
+contiguous blocks over the ranks (65 536 / N per GPU, global env ids, no data-path collective — envs
+are independent), so scaling is "strong" and `value` = 65 536 x K / (max over ranks of the wall time).
+
+Launch: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no torchrun environment the
+script starts its own N ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port P bench.py ...` as a child, before anything touches the GPU) and
+relays rank 0's line; started under torch.distributed.run it is one of the ranks.  Rank 0 prints ONE
+JSON line.
+
+Extra legs in the same line, never part of `value`: "fused_rollout" (pnr_rollout, T steps per launch),
+"large_batch" (262 144 envs per launch), "weak_scaling" at N>1 (65 536 envs PER GPU), "dynamics_randomized"
+(BASELINE config[4]), "ppo_loop" (config[2] at N=1: 16 384 envs; config[3] at N>1: 65 536 envs in total,
+the full rollout+learn loop on SURVEY 8(d)'s contract: T = 32, 4 epochs of 32 768-sample minibatches,
+gradients all-reduced over RCCL), "ppo_loop_large_minibatch" (the same loop with 131 072-sample
+minibatches, a labelled variant), "cpu_baseline" at N=1.
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,14 +39,16 @@ BYTES_PER_ENV_STEP = 750   # 24 action + 92 state in + 80 stat
 STEP_IO_BYTES = 24 + 548 + 6   # per env-step regardless of fusion
 STATE_BYTES = 92 + 80          # per env per LAUNCH (a fused rollout keeps state in registers)
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MIN_BLOCK_S = 0.05         # a timed K-step block shorter than this is repeated and the median reported
+REPEATS = 5
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=65536, help="envs IN TOTAL (sharded over the ranks)")
     ap.add_argument("--obs-layout", default="env_major", choices=["env_major", "feature_major"])
     ap.add_argument("--action-layout", default="env_major", choices=["env_major", "feature_major"])
     ap.add_argument("--fused", type=int, default=1,
@@ -46,8 +56,8 @@ def parse_args():
     ap.add_argument("--ring", type=int, default=32, help="obs ring depth (rollout-buffer slices)")
     ap.add_argument("--large-envs", type=int, default=262144,
                     help="also time pnr_step on this many envs per GPU and report it as \"large_batch\" (0 = skip)")
-    ap.add_argument("--strong-total", type=int, default=65536,
-                    help="N>1: also time this many envs IN TOTAL sharded over the ranks, reported as \"strong_scaling\" (0 = skip)")
+    ap.add_argument("--weak-envs", type=int, default=65536,
+                    help="N>1: also time this many envs PER GPU, reported as \"weak_scaling\" (0 = skip)")
     ap.add_argument("--dynamic-leg", type=int, default=1,
                     help="also time dynamics mode with per-env randomisation (BASELINE config[4]) as \"dynamics_randomized\"")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the per-step launches from a hipGraph")
@@ -64,8 +74,41 @@ def parse_args():
                          "\"ppo_loop\"; default 3 (0 in dynamics mode); at N>1 the gradients are all-reduced over RCCL")
     ap.add_argument("--ppo-envs", type=int, default=0,
                     help="TOTAL envs of the ppo_loop leg (0: 16 384 at N=1 = config[2]; 65 536 sharded over the ranks at N>1 = config[3])")
-    ap.add_argument("--ppo-timeout", type=float, default=240.0)
-    return ap.parse_args()
+    ap.add_argument("--ppo-minibatch", type=int, default=32768, help="GLOBAL sgd_minibatch_size of the ppo_loop leg (SURVEY 8(d) config 3)")
+    ap.add_argument("--ppo-large-minibatch", type=int, default=131072,
+                    help="also report the loop with this global minibatch size as \"ppo_loop_large_minibatch\" (0 = skip)")
+    ap.add_argument("--ppo-timeout", type=float, default=300.0)
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as ONE child process tree, before
+    this process has imported torch or touched the GPU, relay rank 0's JSON line and return the child's
+    exit code.  Nothing is re-exec'ed: this parent only waits."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "2")
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith("{") and '"metric"' in s:
+            print(s, flush=True)
+            lines += 1
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks exited 0 but printed {lines} result lines", file=sys.stderr)
+        rc = 4
+    return rc
 
 
 def usable_cores():
@@ -121,7 +164,6 @@ def cpu_baseline(n_envs, seconds):
     dt = run(k, best)
     # BASELINE.md plan B1: PyBullet single-process replay, only if pybullet exists on this host
     try:
-        import subprocess
         pyb = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pybullet_replay.py"),
                                          "--steps", "3000"], capture_output=True, text=True,
                                         timeout=120).stdout.strip().splitlines()[-1])
@@ -132,19 +174,63 @@ def cpu_baseline(n_envs, seconds):
                       f"{best} threads (host advertises {os.cpu_count()}), {dt:.1f} s"}
 
 
-def main():
-    args = parse_args()
+def shard_range(total, world, rank):
+    """pioneer_amd.dist.shard_range, restated so that the launcher-only dry run needs no GPU library."""
+    base, rem = divmod(int(total), int(world))
+    return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+
+
+def dry_run(args, rank, world):
+    """PNR_BENCH_DRYRUN=1: the rank plumbing alone (rendezvous, barriers, max over ranks, rank 0's line)
+    with a sleep in place of the kernels — what the CPU test of the self-launch path runs.  The line says
+    so (`data: dryrun`, value null): it can never be mistaken for a measurement."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    start, cnt = shard_range(args.envs, world, rank)
+    if os.environ.get("PNR_BENCH_DRYRUN_FAIL_RANK") == str(rank):     # test hook: a rank that dies
+        sys.exit(7)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(1e-5 * args.steps * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    cnts = torch.zeros(world, dtype=torch.int64)
+    cnts[rank] = cnt
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnts)
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/sec", "value": None, "unit": "env-steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(el) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                          "data": "dryrun",
+                          "config": {"workload": "launcher dry run, no kernels", "total_envs": int(cnts.sum()),
+                                     "envs_per_gpu": [int(x) for x in cnts], "parallelism": f"env-shard x{world}"}}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if os.environ.get("PNR_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
 
     import torch
     import torch.distributed as dist
-    from pioneer_amd import PioneerVectorEnv, EngineConfig, _lib
+    from pioneer_amd import PioneerVectorEnv, EngineConfig, SimulationConfig, _lib
     from pioneer_amd import dist as pdist
 
     # one process per GPU; PNR_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box) maps every rank to the
@@ -159,11 +245,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    backend = dist.get_backend() if world > 1 else None
 
-    n = args.envs
+    total_envs = args.envs
+    env_start, n = shard_range(total_envs, world, rank)      # this rank's block of the global env axis
     T = max(1, args.fused)
-    from pioneer_amd import SimulationConfig
-    env = PioneerVectorEnv(n, device=dev, seed=0, env_id_offset=rank * n,
+    env = PioneerVectorEnv(n, device=dev, seed=0, env_id_offset=env_start,
                            simulation_config=SimulationConfig(gravity=args.gravity),
                            engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
                                                       obs_layout=args.obs_layout,
@@ -200,9 +287,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_blocks(run, K):
+        """EXACTLY K steps between barrier + synchronize on both sides, wall time = max over ranks.  A block
+        shorter than MIN_BLOCK_S is repeated (REPEATS blocks in all) and the MEDIAN block is reported.
+        Returns (median wall s, median HIP-event ms of this rank, repeats, all wall times)."""
+        walls, evs = [], []
+        reps = 1
+        while len(walls) < reps:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            barrier()
+            t0 = time.perf_counter()
+            ev0.record(stream)       # torch's current stream == the stream pnr_step launches on
+            run(K)
+            ev1.record(stream)
+            barrier()
+            walls.append(max_over_ranks(time.perf_counter() - t0))
+            evs.append(ev0.elapsed_time(ev1))
+            if len(walls) == 1 and walls[0] < MIN_BLOCK_S:     # the same decision on every rank: walls[] is all-reduced
+                reps = REPEATS
+        return statistics.median(walls), statistics.median(evs), reps, walls
+
     def timed(T, K, W):
-        """K env-steps (after W warm-up steps) with T steps per kernel launch.  Returns
-        (wall seconds max over ranks, HIP-event ms on the launch stream, K)."""
+        """K env-steps (after W warm-up steps) with T steps per kernel launch."""
         if T == 1:
             calls = [(P(acts, i % n_act), P(obs, i % ring), P(rew, i % ring), P(done, i % ring), P(trunc, i % ring))
                      for i in range(math.lcm(n_act, ring))]
@@ -248,34 +362,20 @@ def main():
                     if rc:
                         _lib.check(rc, h)
         run(W)
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
-        ev0.record(stream)       # torch's current stream == the stream pnr_step launches on
-        run(K)
-        ev1.record(stream)
-        barrier()
-        el = time.perf_counter() - t0
-        ev_ms = ev0.elapsed_time(ev1)
-        if world > 1:
-            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el = float(tmax.item())
-        return el, ev_ms, K, W
+        el, ev_ms, reps, walls = timed_blocks(run, K)
+        return el, ev_ms, K, W, reps, walls
 
-    elapsed, ev_ms, K, W = timed(T, args.steps, args.warmup)
-    total_env_steps = float(n) * world * K
-    value = total_env_steps / elapsed
+    elapsed, ev_ms, K, W, repeats, walls = timed(T, args.steps, args.warmup)
+    value = float(total_envs) * K / elapsed
 
     fused = None
     if T == 1 and args.fused_leg > 1 and args.mode == "kinematic":
         Tf = min(args.fused_leg, ring)
-        fel, fev, fK, _ = timed(Tf, max(Tf, args.steps), max(Tf, args.warmup))
+        fel, fev, fK, _, freps, _ = timed(Tf, max(Tf, args.steps), max(Tf, args.warmup))
         fl_ms = fev / (fK // Tf)
         fb = n * (STEP_IO_BYTES * Tf + STATE_BYTES)
-        fused = {"value": float(n) * world * fK / fel, "unit": "env-steps/s", "steps_per_launch": Tf, "steps": fK,
-                 "ms_per_step": fel / fK * 1e3, "avg_launch_ms": fl_ms,
+        fused = {"value": float(total_envs) * fK / fel, "unit": "env-steps/s", "steps_per_launch": Tf, "steps": fK,
+                 "repeats": freps, "ms_per_step": fel / fK * 1e3, "avg_launch_ms": fl_ms,
                  "algorithmic_bytes_per_launch": fb, "achieved_GBps": fb / (fl_ms * 1e-3) / 1e9,
                  "frac": fb / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  "note": "pnr_rollout: same kernel, T steps per launch with open-loop actions; state stays in registers"}
@@ -306,17 +406,8 @@ def main():
                 if rc:
                     _lib.check(rc, lh)
         lrun(warm)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
-        e0.record(stream); lrun(k); e1.record(stream)
-        barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el = float(tmax.item())
-        lms = e0.elapsed_time(e1) / k
+        el, lev, lreps, _ = timed_blocks(lrun, k)
+        lms = lev / k
         roll = None
         if rollout_T > 1 and lring >= rollout_T:
             # the same steps as ONE pnr_rollout launch per rollout_T steps (open-loop actions)
@@ -325,55 +416,54 @@ def main():
             rcall = lambda: _lib.check(lib.pnr_rollout(lh, rollout_T, P(racts, 0), P(lobs, 0), P(lrew, 0), P(ldone, 0), P(ltr, 0), sp), lh)  # noqa: E731
             for _ in range(3):
                 rcall()
-            barrier()
-            r0 = time.perf_counter()
             reps = max(4, k // rollout_T)
-            for _ in range(reps):
-                rcall()
-            barrier()
-            rel = time.perf_counter() - r0
-            if world > 1:
-                tmax = torch.tensor([rel], dtype=torch.float64, device=dev)
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                rel = float(tmax.item())
-            roll = {"steps_per_launch": rollout_T, "steps": reps * rollout_T, "ms_per_step": rel / (reps * rollout_T) * 1e3,
+            rel, _, rreps, _ = timed_blocks(lambda kk: [rcall() for _ in range(kk)], reps)
+            roll = {"steps_per_launch": rollout_T, "steps": reps * rollout_T, "repeats": rreps,
+                    "ms_per_step": rel / (reps * rollout_T) * 1e3,
                     "value": float(nl) * world * reps * rollout_T / rel, "unit": "env-steps/s"}
         lenv.close()
         if roll:
             note = note + "; `rollout`: pnr_rollout, the steps looped inside one launch"
-        return {**({"rollout": roll} if roll else {}), "envs_per_gpu": nl, "steps": k, "avg_launch_ms": lms, "ms_per_step": el / k * 1e3,
+        return {**({"rollout": roll} if roll else {}), "envs_per_gpu": nl, "steps": k, "repeats": lreps,
+                "avg_launch_ms": lms, "ms_per_step": el / k * 1e3,
                 "value": float(nl) * world * k / el, "unit": "env-steps/s",
                 "env_steps_per_s_per_gpu": nl / (lms * 1e-3),
                 "achieved_GBps": bytes_per_env_step * nl / (lms * 1e-3) / 1e9,
                 "frac": bytes_per_env_step * nl / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "note": note}
 
+    id_base = total_envs            # the side legs use global env ids beyond the headline batch
     # the same kernel on a larger batch per launch (amortises the ~3.5 us launch + first-load floor)
     large = None
     if T == 1 and args.large_envs > n and args.mode == "kinematic":
-        large = side_leg(args.large_envs, world * n + rank * args.large_envs, 256, 32,
+        large = side_leg(args.large_envs, id_base + rank * args.large_envs, 256, 32,
                          "pnr_step, one launch per step, same kernel as `value`; avg_launch_ms/frac from rank 0's HIP events")
+    id_base += world * args.large_envs
 
     # BASELINE config[4]: dynamics mode (ABA + PD + limits, 10 sub-steps) with per-env randomised link
     # masses / friction / damping; parity unpinned (the reference never exercises dynamics).  VALU-bound:
     # `frac` is still quoted against HBM with SURVEY 8(d)'s 842 B per env-step.
     dynamic = None
     if T == 1 and args.mode == "kinematic" and args.dynamic_leg:
-        dynamic = side_leg(n, (2 * world + rank) * n + world * args.large_envs, 512, 64,
-                           "mode=dynamic, randomize=True, gravity 9.81: dyn_step_kernel (sub-steps one env per lane with packed "
+        dstart, dcnt = shard_range(total_envs, world, rank)
+        dynamic = side_leg(dcnt, id_base + dstart, 512, 64,
+                           f"{total_envs} envs in total over {world} rank(s); mode=dynamic, randomize=True, gravity 9.81: "
+                           "dyn_step_kernel (sub-steps one env per lane with packed "
                            "fp32 ABA, VALU-bound; then lane pairs finish reward/obs); algorithmic bytes 842 B per env-step",
                            bytes_per_env_step=842, sim=SimulationConfig(gravity=9.81), rollout_T=32, mode="dynamic", randomize=True)
+        dynamic["total_envs"] = total_envs
+        dynamic["value"] = float(total_envs) / (dynamic["ms_per_step"] * 1e-3)
+        if "rollout" in dynamic:
+            dynamic["rollout"]["value"] = float(total_envs) / (dynamic["rollout"]["ms_per_step"] * 1e-3)
+    id_base += total_envs
 
-    # BASELINE config[3] read literally: 65 536 envs IN TOTAL, sharded over the ranks (strong scaling;
-    # 8 192 envs per GPU at N=8, where one launch is shorter than the launch floor)
-    strong = None
-    if T == 1 and world > 1 and args.mode == "kinematic" and args.strong_total > 0:
-        start, cnt = pdist.shard_range(args.strong_total, world, rank)
-        strong = side_leg(cnt, start, max(256, args.steps), 64,
-                          f"{args.strong_total} envs in total sharded over {world} ranks (strong scaling of the named config)")
-        strong["total_envs"] = args.strong_total
-        strong["value"] = float(args.strong_total) / (strong["ms_per_step"] * 1e-3)
+    # weak scaling (the r01 headline): every rank steps its own 65 536-env shard
+    weak = None
+    if T == 1 and world > 1 and args.mode == "kinematic" and args.weak_envs > 0:
+        weak = side_leg(args.weak_envs, id_base + rank * args.weak_envs, max(256, args.steps), 64,
+                        f"{args.weak_envs} envs PER GPU on {world} ranks (weak scaling; not the metric's configuration)")
+        weak["total_envs"] = args.weak_envs * world
 
-    def ppo_leg(iters):
+    def ppo_leg(iters, global_mbs):
         """BASELINE config[2] at N=1 (16 384 envs, full rollout + learn loop) and config[3] at N>1
         (65 536 envs in total sharded over the ranks, gradients all-reduced over RCCL/xGMI)."""
         from pioneer_amd.ppo import PPOConfig, PPOTrainer
@@ -381,7 +471,7 @@ def main():
         start, cnt = pdist.shard_range(total, world, rank)
         penv = PioneerVectorEnv(cnt, device=dev, seed=0, env_id_offset=start,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=args.mode))
-        mbs = min(131072, 32 * cnt)
+        mbs = max(1, min(global_mbs // world, 32 * cnt))      # this rank's share of every global minibatch
         pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, amp_bf16=True)
         tr = PPOTrainer(penv, pcfg, use_graph=True)
         tr.train(); tr.train()                       # warm-up: eager iteration, then the graph-captured one
@@ -389,19 +479,24 @@ def main():
         tp = time.perf_counter()
         rs = [tr.train() for _ in range(iters)]
         barrier()
-        tp = time.perf_counter() - tp
+        tp = max_over_ranks(time.perf_counter() - tp)
         graphed = {"sampling": tr._graph is not None, "learner": tr.learner._graph is not None,
                    "learner_split_around_allreduce": bool(tr.learner._split)}
+        finite = all(math.isfinite(float(r[k])) for r in rs for k in ("kl", "total_loss"))
         penv.close()
+        del tr
+        torch.cuda.empty_cache()
         steps = iters * 32 * total
         return {"value": steps / tp, "unit": "env-steps/s", "total_envs": total, "envs_per_gpu": cnt, "rollout_T": 32,
-                "num_sgd_iter": 4, "sgd_minibatch_size_per_rank": mbs, "mlp_dtype": "bf16 autocast",
-                "hip_graph": graphed, "iters": iters,
-                "grad_allreduce": (f"{dist.get_backend()} flat 0.82 MB bucket per minibatch" if world > 1 else None),
+                "num_sgd_iter": 4, "sgd_minibatch_size": mbs * world, "sgd_minibatch_size_per_rank": mbs,
+                "sgd_updates_per_iter": 4 * ((32 * cnt) // mbs), "mlp_dtype": "bf16",
+                "hip_graph": graphed, "iters": iters, "losses_finite": finite,
+                "grad_allreduce": ({"backend": backend, "world_size": world, "bytes": 4 * 205581,
+                                    "per": "minibatch, one flat bucket"} if world > 1 else None),
                 "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                 "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
 
-    def emit(ppo_loop):
+    def emit(ppo_loop, ppo_large):
         if rank != 0:
             return
         launches = K // T
@@ -409,31 +504,37 @@ def main():
         # per launch: T steps of action/obs/reward/flags traffic + ONE state read and write
         algo_bytes = n * (STEP_IO_BYTES * T + STATE_BYTES)
         achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
                 rec = json.load(open(prof))
                 key = f"{args.mode}:{args.obs_layout}:{n}:{T}"
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+                if key in rec:
+                    traffic = rec[key].get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/pmc_traffic.json (" + str(rec[key].get("profile", "earlier rocprofv3 --pmc passes")) +
+                                      "; looked up, NOT measured in this run)")
             except Exception:
                 traffic = None
         kname = "pnr::step_kernel" if args.mode == "kinematic" else "pnr::dyn_step_kernel"
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_gpus": world, "steps": K, "warmup": W, "repeats": repeats, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n} Pioneer-arm envs per GPU, physics-only step "
+            "config": {"workload": f"{total_envs} Pioneer-arm envs in total ({n} per GPU on {world} GPU(s)), physics-only step "
                                    f"(integrate+FK+reward+TimeLimit(500)+auto-reset+obs[137]), random actions U(-a_max,a_max) resident in HBM",
-                       "envs_per_gpu": n, "total_envs": n * world, "mode": args.mode,
+                       "envs_per_gpu": n, "total_envs": total_envs, "mode": args.mode,
                        "randomize": bool(args.randomize), "gravity": args.gravity,
                        "obs_layout": args.obs_layout, "action_layout": args.action_layout,
-                       "steps_per_launch": T, "hip_graph": bool(args.graph and T == 1), "obs_ring_slices": ring, "parallelism": f"env-shard x{world}"},
+                       "steps_per_launch": T, "hip_graph": bool(args.graph and T == 1), "obs_ring_slices": ring,
+                       "parallelism": f"env-shard x{world}", "block_wall_s": walls},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "avg_launch_ms": launch_ms, "timing": "HIP events on the launch stream around the timed region / launches"},
+                         "avg_launch_ms": launch_ms,
+                         "timing": "HIP events on the launch stream around the timed K-step block / launches (rank 0; median block)"},
         }
         if fused:
             out["fused_rollout"] = fused
@@ -441,21 +542,25 @@ def main():
             out["large_batch"] = large
         if dynamic:
             out["dynamics_randomized"] = dynamic
-        if strong:
-            out["strong_scaling"] = strong
+        if weak:
+            out["weak_scaling"] = weak
         if ppo_loop:
             out["ppo_loop"] = ppo_loop
+        if ppo_large:
+            out["ppo_loop_large_minibatch"] = ppo_large
         if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    ppo_loop = None
+    ppo_loop = ppo_large = None
+    rc = 0
     if args.ppo_iters < 0:
         args.ppo_iters = 3 if args.mode == "kinematic" else 0
     if args.ppo_iters > 0:
-        # the extra leg must never take the main result down: exceptions are reported in place, and a
-        # leg that does not come back (e.g. ranks out of step in a collective) is cut off by a watchdog
-        # that prints the result line without it and ends the process
+        # the extra leg must never take the main result down: the line is still printed when it fails, but the
+        # process then ends NON-ZERO — exceptions are reported in place (rc 5), and a leg that does not come back
+        # (e.g. ranks out of step in a collective) is cut off by a watchdog that prints the line without it and
+        # ends the process with rc 3
         import threading
         lock, state = threading.Lock(), {"done": False}
 
@@ -464,26 +569,45 @@ def main():
                 if state["done"]:
                     return
                 state["done"] = True
-                emit({"error": f"ppo leg did not finish within {args.ppo_timeout:.0f} s"})
+                emit({"error": f"ppo leg did not finish within {args.ppo_timeout:.0f} s"}, None)
                 sys.stdout.flush()
-                os._exit(0)
+                os._exit(3)
         wd = threading.Timer(args.ppo_timeout, on_timeout)
         wd.daemon = True
         wd.start()
         try:
-            ppo_loop = ppo_leg(args.ppo_iters)
+            ppo_loop = ppo_leg(args.ppo_iters, args.ppo_minibatch)
+            if args.ppo_large_minibatch > 0 and args.ppo_large_minibatch != args.ppo_minibatch:
+                ppo_large = ppo_leg(args.ppo_iters, args.ppo_large_minibatch)
         except Exception as exc:
-            ppo_loop = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            err = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            if ppo_loop is None:
+                ppo_loop = err
+            else:
+                ppo_large = err
+            rc = 5
         with lock:
             state["done"] = True
         wd.cancel()
-    emit(ppo_loop)
+        for leg in (ppo_loop, ppo_large):
+            if leg and leg.get("losses_finite") is False:
+                rc = 5
+    emit(ppo_loop, ppo_large)
 
     env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

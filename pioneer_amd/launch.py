@@ -62,7 +62,11 @@ def train(results_dir: str,
         # default when no PPOConfig is given: the reference's learning rate, nets, filter and entropy schedule, but
         # GPU-scale batching: T = 32 steps of every env per iteration (131 072 samples per 4 096
         # envs instead of train_batch_size 8 000), 4 epochs of 32 768-sample minibatches instead of 20 x 128, bf16 GEMMs
-        cfg = ppo_config or PPOConfig(num_sgd_iter=4, sgd_minibatch_size=32768, amp_bf16=True)
+        # The entropy schedule keeps the reference's LENGTH IN ITERATIONS: 1 M timesteps of 8 000-sample batches
+        # = 125 iterations there (pioneer_knm_train.py:37-40, :62); left at 1 M timesteps it would be over after
+        # 8 of these 131 072-sample iterations (2 at 16 384 envs).
+        cfg = ppo_config or PPOConfig(num_sgd_iter=4, sgd_minibatch_size=max(1, 32768 // world), amp_bf16=True,   # 32 768 samples per GLOBAL minibatch
+                                      entropy_decay_steps=125 * 32 * total_envs)
         ent_rng = np.random.RandomState(cfg.seed + 7919 * trial)
         cfg = PPOConfig(**{**cfg.__dict__, "entropy_coeff_start": sample_entropy_start(ent_rng),
                            "seed": cfg.seed + trial})

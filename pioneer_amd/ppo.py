@@ -18,6 +18,11 @@ import torch.nn as nn
 
 from . import dist as pdist
 
+# Output rows of the two head GEMMs (12 and 1 wide) are padded to a multiple of this (zero rows, sliced off).
+# PNR_PPO_HEAD_PAD=1 runs them at their natural widths: only tools/graph_nan_repro.py sets it.
+import os as _os
+_HEAD_PAD = max(1, int(_os.environ.get("PNR_PPO_HEAD_PAD", "16")))
+
 
 @dataclass
 class PPOConfig:
@@ -63,7 +68,14 @@ def sample_entropy_start(rng: np.random.RandomState, min_start: float = 1e-3, ma
 class MeanStdFilter:
     """Running mean/std observation normaliser with RLlib MeanStdFilter semantics
     ((x - mean) / (std + 1e-8), clipped), kept on the device; per-iteration deltas are
-    all-reduced so every rank holds the same statistics (ConcurrentMeanStdFilter's role)."""
+    all-reduced so every rank holds the same statistics (ConcurrentMeanStdFilter's role).
+
+    Moments are accumulated as SHIFTED sums about a pivot row (the first sample of the pending delta):
+    a constant feature (36 of the 137 obs entries are the joint limits and their cos / sin) then has
+    exactly zero deviation sums, so its mean is the constant, its variance exactly 0 and its filtered value
+    exactly 0 — what RLlib's float64 RunningStat gives.  Plain float32 column sums of x and x^2 left such
+    a column with mean off by ~1e-6 and m2 <= 0, i.e. a filtered value of +-clip that depended on the
+    summation order."""
 
     def __init__(self, dim: int, device, clip: float = 10.0):
         self.n = torch.zeros((), dtype=torch.float64, device=device)
@@ -71,28 +83,49 @@ class MeanStdFilter:
         self.m2 = torch.zeros(dim, dtype=torch.float64, device=device)
         self.clip = clip
         self._dn = torch.zeros((), dtype=torch.float64, device=device)
-        self._dsum = torch.zeros(dim, dtype=torch.float64, device=device)
-        self._dsq = torch.zeros(dim, dtype=torch.float64, device=device)
+        self._dsum = torch.zeros(dim, dtype=torch.float64, device=device)     # sum of (x - pivot)
+        self._dsq = torch.zeros(dim, dtype=torch.float64, device=device)      # sum of (x - pivot)^2
+        self._pivot = torch.zeros(dim, dtype=torch.float32, device=device)
+        self._pending = 0       # observe() calls since the last sync(): the first one sets the pivot
 
     def observe(self, x: torch.Tensor) -> None:
-        """Accumulate a batch [..., dim] into the pending delta.  Partial sums over the last-but-one
-        axis run in float32 (<= 1e-5 relative on 16 384 terms), the accumulation across them and
-        across calls in float64."""
-        x = x.reshape(-1, x.shape[-2], x.shape[-1]) if x.dim() > 2 else x.unsqueeze(0)
-        self._dn += x.shape[0] * x.shape[1]
-        self._dsum += x.sum(1).double().sum(0)
-        self._dsq += (x * x).sum(1).double().sum(0)
+        """Accumulate a batch [..., dim] into the pending delta.  Partial sums of the deviations from the
+        pivot run in float32 over chunks of <= 16 384 rows, the accumulation across chunks and calls in
+        float64.  (Which call is the first after a sync() is host-side state: a captured hipGraph replays
+        the pattern it was captured with, i.e. collect -> sync -> collect.)"""
+        x = x.reshape(-1, x.shape[-1])
+        if self._pending == 0:
+            self._pivot.copy_(x[0])
+        self._pending += 1
+        m = x.shape[0]
+        chunk = m
+        for c in (16384, 8192, 4096, 2048, 1024):
+            if m % c == 0:
+                chunk = c
+                break
+        d = (x - self._pivot).view(m // chunk, chunk, -1)
+        self._dn += m
+        self._dsum += d.sum(1).double().sum(0)
+        self._dsq += (d * d).sum(1).double().sum(0)
 
     def sync(self) -> None:
         """Merge the pending deltas of all ranks into the running statistics (Chan et al.).
         In place and without host synchronisation, so a captured hipGraph keeps seeing them."""
-        packed = torch.cat([self._dn.reshape(1), self._dsum, self._dsq])
-        pdist.allreduce_sum_(packed)
         d = self.mean.numel()
-        dn, dsum, dsq = packed[0], packed[1:1 + d], packed[1 + d:]
+        dn_r = self._dn
+        dn_r_safe = torch.clamp(dn_r, min=1.0)
+        mean_r = self._pivot.double() + self._dsum / dn_r_safe
+        m2_r = torch.clamp(self._dsq - self._dsum * self._dsum / dn_r_safe, min=0.0)
+        # the ranks' (n, mean, m2) combined exactly: n = sum n_r, mean = sum n_r mean_r / n,
+        # m2 = sum (m2_r + n_r (mean_r - mean)^2); two small all-reduces
+        pack_a = torch.cat([dn_r.reshape(1), dn_r * mean_r])
+        pdist.allreduce_sum_(pack_a)
+        dn = pack_a[0]
         dn_safe = torch.clamp(dn, min=1.0)
-        bmean = dsum / dn_safe
-        bm2 = dsq - dn * bmean * bmean
+        bmean = pack_a[1:1 + d] / dn_safe
+        dev = mean_r - bmean
+        bm2 = m2_r + dn_r * dev * dev
+        pdist.allreduce_sum_(bm2)
         tot = self.n + dn
         tot_safe = torch.clamp(tot, min=1.0)
         delta = bmean - self.mean
@@ -100,6 +133,7 @@ class MeanStdFilter:
         self.mean.add_(delta * (dn / tot_safe))
         self.n.copy_(tot)
         self._dn.zero_(); self._dsum.zero_(); self._dsq.zero_()
+        self._pending = 0
 
     @property
     def std(self) -> torch.Tensor:
@@ -232,7 +266,7 @@ class ActorCritic(nn.Module):
         # the heads (12 and 1 output rows) run as 16-row GEMMs: on this BLAS library a bf16 GEMM + bias with
         # a 1- or 12-wide output corrupted memory when replayed from a hipGraph (NaNs in unrelated tensors)
         head = layers[-1]
-        rp = (-head.out_features) % 16
+        rp = (-head.out_features) % _HEAD_PAD
         out = _LinearSplitK.apply(h, nn.functional.pad(head.weight, (0, 0, 0, rp)), nn.functional.pad(head.bias, (0, rp)))
         return out if full else out[:, :head.out_features]
 
@@ -263,7 +297,7 @@ class ActorCritic(nn.Module):
                 dev = lins[0].weight.device
                 # every cached matrix is [rows padded to 16, K padded to 16]: the zero rows / columns cost nothing
                 # and keep the BLAS library on its aligned kernels (the 1-row value head is the odd one out)
-                p16 = lambda n: n + (-n) % 16                                  # noqa: E731
+                p16 = lambda n: n + (-n) % (_HEAD_PAD if n < 16 else 16)      # noqa: E731
                 ws = [torch.zeros((p16(l.out_features), l.in_features + (pad if i == 0 else 0)), dtype=dt, device=dev)
                       for i, l in enumerate(lins)]
                 bs = [torch.zeros(p16(l.out_features), dtype=dt, device=dev) for l in lins]
@@ -473,6 +507,15 @@ class PPOLearner:
         self._static_info = None
         self._eager_updates = 0
         self.fused_loss = self.device.type == "cuda" and cfg.act_dim == 6   # pnr_ppo_loss; torch ops otherwise (CPU)
+
+    def drop_graphs(self) -> None:
+        """Forget the captured minibatch update (it is re-captured after the eager warm-up updates)."""
+        if self._graph is not None or self._graph_b is not None:
+            torch.cuda.synchronize(self.device)
+        self._graph = self._graph_b = self._static = self._static_info = self._flat_grad = None
+        self._eager_updates = 0
+        for p in self.model.parameters():
+            p.grad = None                      # split mode made every .grad a view of the flat bucket
 
     def entropy_coeff(self) -> float:
         frac = min(1.0, self.timesteps_total / max(1, self.cfg.entropy_decay_steps))
@@ -733,22 +776,54 @@ class PPOTrainer:
         return res
 
     # -- checkpoint / resume (Tune's checkpoint_freq / checkpoint_at_end, pioneer_knm_train.py:72-73) --
+    def _env_state(self) -> Dict[str, torch.Tensor]:
+        st = {"env_state": self.env.get_state().cpu(), "env_id_offset": int(self.env.env_id_offset),
+              "num_envs": int(self.env.num_envs)}
+        if self.env.engine_config.mode == "dynamic":
+            st["dyn_state"] = self.env.get_dyn_state().cpu()        # q, qd and the per-env randomised parameters
+        return st
+
+    @staticmethod
+    def _env_path(path: str, rank: int) -> str:
+        return f"{path}.env_rank{rank}"
+
     def save(self, path: str) -> str:
+        """Rank 0 writes the learner (weights, optimiser, filter, counters) and its own env shard; every other
+        rank writes its env shard next to it (`<path>.env_rank<r>`), so restore_env gives each rank ITS envs back."""
+        est = self._env_state()
         if self.rank == 0:
             torch.save({"model": self.learner.model.state_dict(), "opt": self.learner.opt.state_dict(),
                         "filter": self.filter.state_dict(), "kl_coeff": self.learner.kl_coeff,
                         "timesteps_total": self.learner.timesteps_total, "iteration": self.iteration,
-                        "episodes_total": self.stats.total, "env_state": self.env.get_state().cpu(),
+                        "episodes_total": self.stats.total, "world": self.world, **est,
                         "cfg": self.cfg.__dict__}, path)
+        else:
+            torch.save(est, self._env_path(path, self.rank))
         pdist.barrier()
         return path
 
     def restore(self, path: str, restore_env: bool = False) -> None:
         ck = torch.load(path, map_location=self.device, weights_only=True)    # tensors and plain values only
         self.learner.model.load_state_dict(ck["model"]); self.learner.opt.load_state_dict(ck["opt"])
+        # load_state_dict REPLACES the optimiser's state tensors: a learner graph captured before this call would
+        # keep replaying on the old exp_avg / exp_avg_sq / step.  Drop the captures; they are rebuilt after the
+        # usual eager warm-up updates.  (Model weights and filter moments are copied in place: the sampling
+        # graph keeps seeing them.)
+        self.learner.drop_graphs()
         self.filter.load_state_dict(ck["filter"]); self.learner.kl_coeff = ck["kl_coeff"]
         self.learner.timesteps_total = ck["timesteps_total"]; self.iteration = ck["iteration"]
         self.stats.total = ck["episodes_total"]
-        if restore_env and ck["env_state"].shape[1] == self.env.num_envs:
-            self.env.set_state(ck["env_state"].to(self.device))
+        if restore_env:
+            est = ck if self.rank == 0 else torch.load(self._env_path(path, self.rank), map_location=self.device,
+                                                      weights_only=True)
+            if int(ck.get("world", 1)) != self.world or int(est.get("num_envs", est["env_state"].shape[1])) != self.env.num_envs \
+                    or int(est.get("env_id_offset", 0)) != int(self.env.env_id_offset):
+                raise AssertionError("restore_env: the checkpoint's env shards (world size, envs per rank, env id offsets) "
+                                     "do not match this run")
+            dynamic = self.env.engine_config.mode == "dynamic"
+            if dynamic != ("dyn_state" in est):
+                raise AssertionError("restore_env: the checkpoint's env mode (kinematic / dynamic) does not match this run")
+            self.env.set_state(est["env_state"].to(self.device))
+            if dynamic:
+                self.env.set_dyn_state(est["dyn_state"].to(self.device))
             self.raw_obs.copy_(self.env.observe())

@@ -69,11 +69,21 @@ def check_state_exact(env, orc):
     assert np.abs(pot - opot).max() <= POT_TOL
 
 
+def resync_forked(env, orc, forked):
+    """Envs whose `done` legitimately flipped (distance within float32 noise of done_distance) have forked: one side
+    reset, the other did not.  The oracle takes the GPU's state for exactly those envs and the run goes on."""
+    w_o = orc.state_words().copy()
+    w_g = env.get_state().cpu().numpy().view(np.uint32)
+    w_o[:, forked] = w_g[:, forked]
+    orc.load_state_words(w_o)
+
+
 def run_parity(n, steps, layout="env_major", act_layout="env_major", seed=3, action_scale=1.0, **kw):
     env, orc = make_pair(n, seed=seed, layout=layout, act_layout=act_layout, **kw)
     obs = env.reset()
     check_obs(to_env_major(env, obs), orc.reset())
     rng = np.random.RandomState(seed)
+    forks = 0
     for t in range(steps):
         act = (rng.uniform(-1, 1, size=(n, 6)) * env.a_max * action_scale).astype(np.float32)
         a_dev = torch.from_numpy(act.T.copy() if env.feature_major_act else act).cuda()
@@ -83,15 +93,18 @@ def run_parity(n, steps, layout="env_major", act_layout="env_major", seed=3, act
         # an env whose distance sits within float32 noise of done_distance may flip `done`
         borderline = np.abs(dist - orc.p.done_distance) < POS_TOL
         assert borderline.sum() <= max(1, n // 1000)
-        d = done.cpu().numpy()
-        assert np.array_equal(d[~borderline], odone[~borderline])
-        assert np.array_equal(trunc.cpu().numpy()[~borderline], otrunc[~borderline])
-        if borderline.any() and not np.array_equal(d, odone):
-            pytest.skip("done flipped on a borderline env; trajectories legitimately fork")
-        assert np.abs(rew.double().cpu().numpy() - orew).max() <= REW_TOL
-        assert np.abs(info.double().cpu().numpy()[:, :3] - oinfo[:, :3]).max() <= REW_TOL
-        assert np.abs(info.double().cpu().numpy()[:, 3] - oinfo[:, 3]).max() <= POS_TOL
-        check_obs(to_env_major(env, obs), oobs)
+        d, tr = done.cpu().numpy(), trunc.cpu().numpy()
+        forked = (d != odone) | (tr != otrunc)
+        assert not (forked & ~borderline).any(), "done / truncated may differ on borderline envs only"
+        ok = ~forked
+        assert np.abs(rew.double().cpu().numpy() - orew)[ok].max() <= REW_TOL
+        assert np.abs(info.double().cpu().numpy()[:, :3] - oinfo[:, :3])[ok].max() <= REW_TOL
+        assert np.abs(info.double().cpu().numpy()[:, 3] - oinfo[:, 3]).max() <= POS_TOL     # distance: every env
+        check_obs(to_env_major(env, obs)[ok], oobs[ok])
+        if forked.any():
+            forks += int(forked.sum())
+            resync_forked(env, orc, forked)
+    assert forks <= max(1, n // 1000), f"{forks} envs forked on a borderline done in {steps} steps"
     check_state_exact(env, orc)
     env.close()
 
@@ -305,19 +318,23 @@ def test_non_default_configs():
     assert env.dt == orc.dt == (1 / 120) * 7 and np.array_equal(env.v_max, orc.v_max) and np.array_equal(env.a_max, orc.a_max)
     check_obs(env.reset().double().cpu().numpy(), orc.reset())
     rng = np.random.RandomState(0)
-    n_done = 0
+    n_done = forks = 0
     for t in range(40):
         act = (rng.uniform(-1, 1, (n, 6)) * env.a_max).astype(np.float32)
         obs, rew, done, trunc, info = env.vector_step(torch.from_numpy(act).cuda(), want_info=True)
         oobs, orew, odone, otrunc, oinfo = orc.step(act, want_info=True)
         border = np.abs(oinfo[:, 3] - 6.0) < POS_TOL
-        if border.any() and not np.array_equal(done.cpu().numpy(), odone):
-            pytest.skip("done flipped on a borderline env")
-        assert np.array_equal(done.cpu().numpy(), odone) and np.array_equal(trunc.cpu().numpy(), otrunc)
-        assert np.abs(rew.double().cpu().numpy() - orew).max() <= REW_TOL
-        check_obs(obs.double().cpu().numpy(), oobs)
+        forked = (done.cpu().numpy() != odone) | (trunc.cpu().numpy() != otrunc)
+        assert not (forked & ~border).any(), "done / truncated may differ on borderline envs only"
+        ok = ~forked
+        assert np.abs(rew.double().cpu().numpy() - orew)[ok].max() <= REW_TOL
+        check_obs(obs.double().cpu().numpy()[ok], oobs[ok])
+        if forked.any():
+            forks += int(forked.sum())
+            resync_forked(env, orc, forked)
         n_done += int(odone.sum())
     assert n_done > 50            # the large done_distance makes real terminal resets happen (award_done path)
+    assert forks <= 2, f"{forks} envs forked on a borderline done"
     check_state_exact(env, orc)
     env.close()
 

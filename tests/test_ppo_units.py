@@ -62,3 +62,39 @@ def test_cached_inference_equals_forward():
     m.refresh_inference_cache(False)
     mean2 = m(obs)[0]
     assert torch.allclose(m.forward_cached(xin)[0][:, :6], mean2, atol=1e-6) and not torch.allclose(mean2, mean)
+
+
+def test_constant_obs_columns_filter_to_exactly_zero():
+    """36 of the 137 obs entries are per-env constants (joint limits and their cos / sin, obs[18:54]).  RLlib's float64
+    RunningStat gives them std 0 and a filtered value of exactly 0; float32 column sums gave +-clip."""
+    g = torch.Generator().manual_seed(3)
+    f = MeanStdFilter(5, "cpu", clip=10.0)
+    consts = torch.tensor([-3.1415927, 0.2588190, 1.309, 5.0e-8, -1.0])
+    for it in range(3):
+        x = torch.randn(3, 16384, 5, generator=g) * 3 + 7
+        x[..., 1:] = consts[1:]
+        x[..., 0] = consts[0] if it < 2 else x[..., 0]            # column 0 stops being constant in the third batch
+        f.observe(x[0]); f.observe(x[1:]); f.sync()
+        f.prepare()
+        row = x[0, :4]
+        y = f.apply_(row, out=torch.empty_like(row))
+        assert torch.equal(y[:, 1:], torch.zeros(4, 4)), y
+        assert torch.equal(f(row)[:, 1:], torch.zeros(4, 4))
+        assert torch.equal(f.mean[1:].float(), consts[1:]) and torch.equal(f.m2[1:], torch.zeros(4, dtype=torch.float64))
+        if it < 2:
+            assert torch.equal(y[:, 0], torch.zeros(4))
+        else:
+            assert float(f.std[0]) > 0.5 and float(y[:, 0].abs().max()) < 10.0
+
+
+def test_filter_moments_match_float64_reference():
+    g = torch.Generator().manual_seed(4)
+    f = MeanStdFilter(9, "cpu")
+    xs = []
+    for _ in range(4):
+        x = torch.randn(8192, 9, generator=g) * torch.arange(1, 10) + 100.0      # large mean, small spread
+        f.observe(x); f.sync(); xs.append(x)
+    allx = torch.cat(xs).double()
+    assert float(f.n) == allx.shape[0]
+    assert torch.allclose(f.mean, allx.mean(0), rtol=0, atol=1e-6)
+    assert torch.allclose(f.std, allx.std(0), rtol=1e-6)
