@@ -195,6 +195,16 @@ def _mlp(sizes: Sequence[int], out_dim: int, out_gain: float) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+_ONES_CACHE: Dict[Tuple, torch.Tensor] = {}
+
+
+def _ones_rows(S: int, k: int, dtype, device) -> torch.Tensor:
+    key = (S, k, dtype, str(device))
+    if key not in _ONES_CACHE:
+        _ONES_CACHE[key] = torch.ones((S, 8, k), dtype=dtype, device=device)
+    return _ONES_CACHE[key]
+
+
 class _LinearSplitK(torch.autograd.Function):
     """y = x W^T + b with a split-K weight gradient.
 
@@ -232,7 +242,14 @@ class _LinearSplitK(torch.autograd.Function):
             dw = torch.bmm(dyp.view(S, B // S, -1).transpose(1, 2), x2.view(S, B // S, -1)).sum(0, dtype=torch.float32)[:out]
         else:
             dw = (dy.t() @ x2).float()
-        db = dy.sum(0, dtype=torch.float32)          # one reduction with a float32 accumulator, no cast pass
+        if S > 1 and dy.is_cuda:
+            # the bias gradient as a GEMM too (eight rows of ones against the same slices): a torch column-sum over
+            # B rows takes the multi-block reduction path, which returned wrong sums from the second hipGraph replay
+            # on (tools/graph_reduce_probe.py); GEMMs replay exactly (profiles/r02_nan_repro_C_blas_backward.json)
+            ones = _ones_rows(S, B // S, dy.dtype, dy.device)
+            db = torch.bmm(ones, dy.view(S, B // S, -1)).sum(0, dtype=torch.float32)[0]
+        else:
+            db = dy.sum(0, dtype=torch.float32)      # one reduction with a float32 accumulator, no cast pass
         return dx, dw.to(weight.dtype), db.to(weight.dtype)
 
 
@@ -263,8 +280,9 @@ class ActorCritic(nn.Module):
         layers = list(net)[1:]
         for layer in layers[:-1]:
             h = _LinearSplitK.apply(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
-        # the heads (12 and 1 output rows) run as 16-row GEMMs: on this BLAS library a bf16 GEMM + bias with
-        # a 1- or 12-wide output corrupted memory when replayed from a hipGraph (NaNs in unrelated tensors)
+        # the heads (12 and 1 output rows) run as 16-row GEMMs (zero rows): aligned kernels, and the fused loss
+        # kernel consumes rows of 16.  (r01 blamed these widths for NaNs under graph replay; the cause was a torch
+        # reduction inside the captured loop, see PPOTrainer._collect_tail.)
         head = layers[-1]
         rp = (-head.out_features) % _HEAD_PAD
         out = _LinearSplitK.apply(h, nn.functional.pad(head.weight, (0, 0, 0, rp)), nn.functional.pad(head.bias, (0, rp)))
@@ -683,13 +701,17 @@ class PPOTrainer:
             "adv": torch.empty((T, N), **f32), "vtarg": torch.empty((T, N), **f32),
             "done": torch.empty((T, N), dtype=torch.uint8, device=self.device),
             "trunc": torch.empty((T, N), dtype=torch.uint8, device=self.device),
+            "term_u8": torch.empty((T, N), dtype=torch.uint8, device=self.device),
+            "terminals": torch.empty((T, N), **f32),                   # done | truncated as 0 / 1
         }
+        self._raw_prev = torch.empty((N, self.cfg.obs_dim), **f32)
 
     @torch.no_grad()
     def _collect_impl(self) -> None:
         """T steps into the static buffers; pure device work (capturable).  Per step only what the next
-        step needs (filter, nets on cached weights, action draw, pnr_step: ~25 kernels); log-probs, episode
-        statistics, filter moments and GAE are computed once, after the loop, from the [T, N] buffers."""
+        step needs (filter, nets on cached weights, action draw, pnr_step: ~25 kernels); log-probs and GAE are
+        computed once, after the loop, from the [T, N] buffers; episode statistics and filter moments in
+        _collect_tail(), outside any capture."""
         cfg, buf, model = self.cfg, self.buf, self.learner.model
         T, A = cfg.rollout_fragment_length, cfg.act_dim
         raw = self.raw_obs
@@ -717,18 +739,31 @@ class PPOTrainer:
             raw = buf["raw_obs"][t]
         mean, log_std = buf["head"][..., :A], buf["head"][..., A:]
         buf["logp"].copy_(gaussian_logp(buf["actions"], mean, log_std))
-        terminals = (buf["done"] | buf["trunc"]).float()
-        self.stats.rollout(buf["reward"], terminals)
-        # the filter only changes at sync(), so observing all inputs here, in one pass, is identical to
-        # observing them one by one inside the loop (32 small float64 column reductions per rollout)
-        self.filter.observe(self.raw_obs)
-        if T > 1:
-            self.filter.observe(buf["raw_obs"][:T - 1])
+        terminals = buf["terminals"]
+        torch.bitwise_or(buf["done"], buf["trunc"], out=buf["term_u8"])
+        terminals.copy_(buf["term_u8"])
+        self._raw_prev.copy_(self.raw_obs)                                 # what the eager tail's filter.observe() reads
         self.raw_obs.copy_(raw)
         xin[:, :cfg.obs_dim].copy_(self.filter.apply_(raw, out=self._xlast))
         last_v = model.forward_cached(xin)[1].squeeze(-1).float()      # bootstrap value of the state after the last step
         adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, terminals, cfg.gamma, cfg.lambda_)
         buf["adv"].copy_(adv); buf["vtarg"].copy_(vtarg)
+
+    def _collect_tail(self) -> None:
+        """The rollout's bookkeeping reductions — episode statistics and the filter's moments — run EAGERLY after
+        the (possibly replayed) loop, never inside a captured graph.  Root cause of the r01 "NaNs after graph replay"
+        finding (tools/graph_reduce_probe.py, profiles/r02_graph_reduce_probe.json): a torch reduction over the
+        middle axis of a large tensor ([31, 16384, 137].sum(1): the multi-block path with per-output semaphores that
+        the launcher zeroes by hipMemsetAsync) returns wrong sums from the SECOND replay of a hipGraph on (first
+        replay exact, eager always exact) — depending on the pool layout, which is why changing head widths or
+        minibatch sizes made it come and go.  It fed garbage into the filter's moments.  Nothing of the BLAS
+        library was involved.  The filter only changes at sync(), so observing all inputs here, in one pass, is
+        identical to observing them one by one inside the loop."""
+        buf, T = self.buf, self.cfg.rollout_fragment_length
+        self.stats.rollout(buf["reward"], buf["terminals"])
+        self.filter.observe(self._raw_prev)
+        if T > 1:
+            self.filter.observe(buf["raw_obs"][:T - 1])
 
     _capturing = False
 
@@ -747,6 +782,7 @@ class PPOTrainer:
             self._graph.replay()
         else:
             self._collect_impl()
+        self._collect_tail()
         buf = self.buf
         flat = lambda x: x.reshape(-1, *x.shape[2:])  # noqa: E731
         A = self.cfg.act_dim
