@@ -226,6 +226,32 @@ int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_valu
                  float* grad_head_policy, float* grad_head_value, float* partial_sums, int64_t partial_rows,
                  void* stream);
 
+/*
+ * Host-driver helpers (not part of the env surface): the two MLPs of the reference's PPO config — 'fcnet_hiddens':
+ * [256, 256] (pioneer/launch/pioneer_knm_train.py:59-61), tanh, separate policy (12 outputs: 6 means + 6 log-stds) and
+ * value (1 output) nets, RLlib's FullyConnectedNetwork with vf_share_layers False — as bf16 MFMA kernels.
+ *   params / grads  12 device pointers, net-major: policy w1 [256][137], b1 [256], w2 [256][256], b2 [256],
+ *                   w3 [n3][256], b3 [n3], then the value net's six; float32, torch nn.Linear layouts
+ *   wpack           pnr_mlp_pack_elems() bf16 values; bias: pnr_mlp_bias_elems() floats (written by pnr_mlp_pack)
+ *   obs             [rows][137] float32; idx [batch] int64 row gather or NULL; f_loc/f_inv/f_lo/f_hi [137] or all NULL:
+ *                   the nets see clamp((obs - loc) * inv, lo, hi), the MeanStdFilter of the reference's config (:66)
+ *   head            [2][batch][16] float32: policy rows = means 0..5, raw log-stds 6..11; value rows = v at column 0
+ *   xs [batch][144], h1 / h2 / dz1 / dz2 [2][batch][256] bf16: activations kept for / made by the backward pass
+ *   slabs           >= pnr_mlp_slab_floats(batch) floats of scratch (per-slice partial gradients, summed in order)
+ * pnr_mlp_backward = backward-data + weight gradients + reduction; gradients of the batch as given by g_head
+ * [2][batch][16] (d loss / d head), written (accumulate = 0) or added (1) to `grads`.
+ */
+int64_t pnr_mlp_pack_elems(void);
+int64_t pnr_mlp_bias_elems(void);
+int64_t pnr_mlp_slab_floats(int64_t batch);
+int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value, void* wpack, float* bias, void* stream);
+int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const float* f_loc, const float* f_inv,
+                    const float* f_lo, const float* f_hi, const void* wpack, const float* bias, float* head,
+                    void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, void* stream);
+int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
+                     void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
+                     int32_t n3_value, int32_t accumulate, void* stream);
+
 int64_t pnr_num_envs(pnr_handle h);
 
 /* Last error message of `h`, or of the calling thread when h == NULL. */

@@ -28,6 +28,7 @@
 #include "pnr_device.h"
 #include "pnr_dyn.h"
 #include "pnr_ppo.h"
+#include "pnr_mlp.h"
 
 namespace pnr {
 
@@ -1104,6 +1105,101 @@ int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_valu
     P.ent_coeff = entropy_coeff; P.g_head_p = grad_head_policy; P.g_head_v = grad_head_value; P.partials = partial_sums;
     P.B = batch; P.clip = clip_param; P.vf_clip = vf_clip_param; P.vf_coeff = vf_loss_coeff;
     hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)blocks), dim3(kPpoBlock), 0, (hipStream_t)stream, P);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+// ---- the host driver's MLPs (pnr_mlp.h) ------------------------------------------------------------------------
+static inline void mlp_slicing(long long B, long long* slices, long long* slice_rows)
+{
+    long long want = (B + kWgChunk - 1) / kWgChunk;          // at most one slice per 64-sample chunk ...
+    if (want > 64) want = 64;                                // ... and at most 64 slices (slab traffic)
+    if (want < 1) want = 1;
+    long long rows = (B + want - 1) / want;
+    rows = (rows + kWgChunk - 1) / kWgChunk * kWgChunk;
+    *slice_rows = rows;
+    *slices = (B + rows - 1) / rows;
+}
+
+int64_t pnr_mlp_slab_floats(int64_t batch)
+{
+    if (batch < 1) return 0;
+    long long slices, rows;
+    mlp_slicing(batch, &slices, &rows);
+    return (int64_t)(slices * kMlpNets * kGradElems);
+}
+
+int64_t pnr_mlp_pack_elems(void) { return (int64_t)kMlpNets * kPackElems; }
+int64_t pnr_mlp_bias_elems(void) { return (int64_t)kMlpNets * kBiasElems; }
+
+int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value, void* wpack, float* bias, void* stream)
+{
+    if (!params || !wpack || !bias) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: null argument");
+    if (n3_policy < 1 || n3_policy > kMlpHead || n3_value < 1 || n3_value > kMlpHead)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: head widths must be in 1..16");
+    MlpPackParams P;
+    for (int n = 0; n < kMlpNets; ++n) {
+        for (int k = 0; k < 6; ++k)
+            if (!params[6 * n + k]) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: null parameter %d of net %d", k, n);
+        P.net[n] = {params[6 * n + 0], params[6 * n + 1], params[6 * n + 2], params[6 * n + 3], params[6 * n + 4], params[6 * n + 5],
+                    n == 0 ? n3_policy : n3_value};
+    }
+    P.wpack = static_cast<__bf16*>(wpack); P.bias = bias;
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((kPackElems + kBiasElems + 255) / 256, kMlpNets), dim3(256), 0, (hipStream_t)stream, P);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const float* f_loc, const float* f_inv,
+                    const float* f_lo, const float* f_hi, const void* wpack, const float* bias, float* head,
+                    void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, void* stream)
+{
+    if (batch < 1 || !obs || !wpack || !bias || !head) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: null argument or empty batch");
+    if (first_net < 0 || n_nets < 1 || first_net + n_nets > kMlpNets) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: bad net range");
+    if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: the four filter vectors come together or not at all");
+    if ((h1 == nullptr) != (h2 == nullptr)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: h1 and h2 come together");
+    MlpFwdParams P;
+    P.obs = obs; P.idx = reinterpret_cast<const long long*>(idx); P.f_loc = f_loc; P.f_inv = f_inv; P.f_lo = f_lo; P.f_hi = f_hi;
+    P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
+    P.xs = static_cast<__bf16*>(xs); P.h1 = static_cast<__bf16*>(h1); P.h2 = static_cast<__bf16*>(h2);
+    P.B = batch; P.first_net = first_net; P.n_nets = n_nets;
+    hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kMlpThreads), 0,
+                       (hipStream_t)stream, P);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
+                     void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
+                     int32_t n3_value, int32_t accumulate, void* stream)
+{
+    if (batch < 1 || !g_head || !wpack || !xs || !h1 || !h2 || !dz1 || !dz2 || !slabs || !grads)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: null argument or empty batch");
+    long long slices, rows;
+    mlp_slicing(batch, &slices, &rows);
+    if (slab_floats < slices * kMlpNets * kGradElems)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: slabs hold %lld floats, the launch needs %lld",
+                    (long long)slab_floats, slices * kMlpNets * kGradElems);
+    hipStream_t st = (hipStream_t)stream;
+    MlpBwdParams Bp;
+    Bp.g_head = g_head; Bp.wpack = static_cast<const __bf16*>(wpack); Bp.h1 = static_cast<const __bf16*>(h1);
+    Bp.h2 = static_cast<const __bf16*>(h2); Bp.dz1 = static_cast<__bf16*>(dz1); Bp.dz2 = static_cast<__bf16*>(dz2); Bp.B = batch;
+    hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0, st, Bp);
+    MlpWgradParams Wp;
+    Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
+    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows;
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, 4, kMlpNets), dim3(kMlpThreads), 0, st, Wp);
+    MlpReduceParams Rp;
+    Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate;
+    for (int n = 0; n < kMlpNets; ++n) {
+        for (int k = 0; k < 6; ++k)
+            if (!grads[6 * n + k]) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: null gradient %d of net %d", k, n);
+        Rp.gw1[n] = grads[6 * n + 0]; Rp.gb1[n] = grads[6 * n + 1]; Rp.gw2[n] = grads[6 * n + 2];
+        Rp.gb2[n] = grads[6 * n + 3]; Rp.gw3[n] = grads[6 * n + 4]; Rp.gb3[n] = grads[6 * n + 5];
+    }
+    Rp.n3[0] = n3_policy; Rp.n3[1] = n3_value;
+    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((kGradElems + 255) / 256, kMlpNets), dim3(256), 0, st, Rp);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }

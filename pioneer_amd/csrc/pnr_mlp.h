@@ -1,0 +1,640 @@
+// pnr_mlp.h — the PPO host driver's two MLPs (policy 137-256-256-12, value 137-256-256-1, tanh; the nets of
+// pioneer/launch/pioneer_knm_train.py:59-61 under RLlib's FullyConnectedNetwork with vf_share_layers False) as
+// hand-written bf16 MFMA kernels for gfx950: forward (three layers fused, activations never leave the CU between
+// layers), backward-data (two layers fused), weight gradients (split over the batch axis into per-slice slabs,
+// reduced in a fixed order: deterministic) and the weight packing.  Master weights stay float32 in the caller's
+// tensors; bf16 copies (K padded 137 -> 144, head rows padded to 16, plus the transposes the backward pass reads)
+// are packed once per update.
+//
+// Orientation.  Every GEMM is computed TRANSPOSED, Y^T = W . X^T, with the weight matrix as the MFMA's A operand
+// (rows = output features; fragments are 16-byte loads straight from the packed row-major weights in L2) and the
+// activation tile as the B operand (columns = samples; fragments are ds_read_b128 from a row-major [sample][feature]
+// LDS tile).  A 32x32 accumulator block then holds, per lane, ONE sample (its column) and FOUR CONSECUTIVE features
+// per register quad (rows (reg&3) + 8 (reg>>2) + 4 (lane>>5)): bias + tanh run in registers and each quad leaves as
+// one 8-byte ds_write_b64 into the next layer's row-major tile — no 2-byte LDS stores, no lane shuffles.
+// Weight gradients sum over SAMPLES, so both operands must be sample-contiguous per lane: they are read from the
+// row-major LDS tiles with ds_read_b64_tr_b16 (the hardware 4x16 transpose read), rows strided 16 dwords mod 64 so
+// that the transposed reads are bank-conflict-free.
+//
+// Roofline: MFMA (bf16 dense ~2.5 PFLOP/s).  Per sample and net: forward 106 496 MAC, backward-data 69 632 MAC,
+// weight gradients 110 592 MAC.  Not HBM-bound: activations cost 1-2.5 KB per sample per pass.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pnr {
+
+constexpr int kMlpIn = 137;       // observation entries (pioneer_knm_env.py:194-211)
+constexpr int kMlpInPad = 144;    // K of the first layer, padded to a multiple of 16 (zero columns)
+constexpr int kMlpHid = 256;      // fcnet_hiddens [256, 256] (pioneer_knm_train.py:60)
+constexpr int kMlpHead = 16;      // head rows: 12 (6 means + 6 log-stds) or 1 (value), zero-padded to 16
+constexpr int kMlpNets = 2;       // policy, value
+constexpr int kMlpBM = 128;       // samples per workgroup tile (forward / backward-data)
+constexpr int kMlpThreads = 256;  // four waves
+
+// packed bf16 weights of ONE net, element offsets
+constexpr int kOffW1 = 0;                                  // [256][144]
+constexpr int kOffW2 = kOffW1 + kMlpHid * kMlpInPad;       // [256][256]
+constexpr int kOffW3 = kOffW2 + kMlpHid * kMlpHid;         // [16][256]
+constexpr int kOffW2T = kOffW3 + kMlpHead * kMlpHid;       // [256][256]  W2T[i][o] = W2[o][i]
+constexpr int kOffW3T = kOffW2T + kMlpHid * kMlpHid;       // [256][16]   W3T[f][r] = W3[r][f]
+constexpr int kPackElems = kOffW3T + kMlpHid * kMlpHead;   // 176 128
+constexpr int kBiasElems = 2 * kMlpHid + kMlpHead;         // b1[256] b2[256] b3[16], float32
+
+// gradient slab of ONE net and ONE batch slice, float32 element offsets (also the layout of the reduced gradient)
+constexpr int kGW1 = 0;                                    // [256][144]
+constexpr int kGW2 = kGW1 + kMlpHid * kMlpInPad;           // [256][256]
+constexpr int kGW3 = kGW2 + kMlpHid * kMlpHid;             // [16][256]
+constexpr int kGB1 = kGW3 + kMlpHead * kMlpHid;            // [256]
+constexpr int kGB2 = kGB1 + kMlpHid;                       // [256]
+constexpr int kGB3 = kGB2 + kMlpHid;                       // [16]
+constexpr int kGradElems = kGB3 + kMlpHead;                // 107 024
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS row strides (bf16 elements).  Tiles read with ds_read_b128 as the B operand: rows 16-byte aligned and
+// shifted 4 (12) dwords mod 64, conflict-free for the four 16-lane groups.  Tiles read with ds_read_b64_tr_b16:
+// rows shifted 16 dwords mod 64 (four rows x 16 dwords cover the 64 banks).
+constexpr int kXS = 152;          // [128][144] input tile
+constexpr int kHS = 264;          // [128][256] hidden tile
+constexpr int kGS = 24;           // [128][16] head-gradient tile
+constexpr int kTrH = 288;         // [64][256] tile for transposed reads (144 dwords = 16 mod 64)
+constexpr int kTrX = 160;         // [64][160] (80 dwords = 16 mod 64): 144 inputs, a column of ones, zeros
+constexpr int kTrHalf = 160;      // [64][128] half-width hidden tile (+32 pad)
+constexpr int kTrG = 32;          // [64][16] head-gradient tile (16 dwords)
+constexpr int kWgChunk = 64;      // samples per weight-gradient chunk
+
+struct MlpNetParams {             // float32 master parameters of one net (torch nn.Linear layouts)
+    const float* w1; const float* b1;   // [256][137], [256]
+    const float* w2; const float* b2;   // [256][256], [256]
+    const float* w3; const float* b3;   // [n3][256], [n3]
+    int n3;                             // 12 (policy) or 1 (value)
+};
+
+struct MlpPackParams { MlpNetParams net[kMlpNets]; __bf16* wpack; float* bias; };
+
+// One thread per packed element; the transposes and the zero padding happen here, once per update.
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpPackParams P)
+{
+    const int net = blockIdx.y;
+    const MlpNetParams& N = P.net[net];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    if (e < kPackElems) {
+        float v;
+        if (e < kOffW2) { const int o = e / kMlpInPad, k = e % kMlpInPad; v = k < kMlpIn ? N.w1[o * kMlpIn + k] : 0.f; }
+        else if (e < kOffW3) { v = N.w2[e - kOffW2]; }
+        else if (e < kOffW2T) { const int r = (e - kOffW3) / kMlpHid, f = (e - kOffW3) % kMlpHid; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; }
+        else if (e < kOffW3T) { const int i = (e - kOffW2T) / kMlpHid, o = (e - kOffW2T) % kMlpHid; v = N.w2[o * kMlpHid + i]; }
+        else { const int f = (e - kOffW3T) / kMlpHead, r = (e - kOffW3T) % kMlpHead; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; }
+        wp[e] = (__bf16)v;
+    } else if (e < kPackElems + kBiasElems) {
+        const int b = e - kPackElems;
+        float v;
+        if (b < kMlpHid) v = N.b1[b];
+        else if (b < 2 * kMlpHid) v = N.b2[b - kMlpHid];
+        else v = (b - 2 * kMlpHid) < N.n3 ? N.b3[b - 2 * kMlpHid] : 0.f;
+        P.bias[net * kBiasElems + b] = v;
+    }
+}
+
+// tanh through one exp2 and one reciprocal: 1 - 2 / (e^{2x} + 1); saturates correctly at +-inf.  Absolute error
+// ~1e-7, far below the bf16 rounding of the stored activation.
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // 2 log2(e)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+__device__ __forceinline__ bf16x8 ld_global_bf16x8(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// acc[rb][cb] += W[64 rows of this wave][K] . tile[128 samples][K]^T.  W: row-major, row stride K (global, L2);
+// tile: LDS, row stride STRIDE.  A fragments run three k-steps ahead of their use.
+template <int K, int STRIDE>
+__device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_rows, const __bf16* tile, f32x16 (&acc)[2][4], int lane)
+{
+    constexpr int KS = K / 16;
+    const int r = lane & 31, h = lane >> 5;
+    const __bf16* wa = w_rows + (size_t)r * K + 8 * h;
+    const __bf16* tb = tile + r * STRIDE + 8 * h;
+    bf16x8 a[3][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        a[p][0] = ld_global_bf16x8(wa + 16 * p);
+        a[p][1] = ld_global_bf16x8(wa + 32 * K + 16 * p);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 2 < KS) {
+            a[(ks + 2) % 3][0] = ld_global_bf16x8(wa + 16 * (ks + 2));
+            a[(ks + 2) % 3][1] = ld_global_bf16x8(wa + 32 * K + 16 * (ks + 2));
+        }
+        bf16x8 b[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % 3][rb], b[cb], acc[rb][cb], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void mlp_zero_acc(f32x16 (&acc)[2][4])
+{
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+}
+
+// copy a [128][256] bf16 tile between LDS (row stride kHS) and row-major global rows [row0, row0 + 128) of n_rows
+__device__ __forceinline__ void mlp_store_htile(const __bf16* tile, __bf16* __restrict__ dst, long long row0, long long n_rows, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
+        if (row0 + row < n_rows)
+            *reinterpret_cast<uint4*>(dst + (row0 + row) * kMlpHid + cc * 8) = *reinterpret_cast<const uint4*>(tile + row * kHS + cc * 8);
+    }
+}
+__device__ __forceinline__ void mlp_load_htile(__bf16* tile, const __bf16* __restrict__ src, long long row0, long long n_rows, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row0 + row < n_rows) v = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
+        *reinterpret_cast<uint4*>(tile + row * kHS + cc * 8) = v;
+    }
+}
+
+struct MlpFwdParams {
+    const float* obs;          // [rows][137] float32 observations (raw when the filter vectors are given)
+    const long long* idx;      // [B] row of `obs` for sample b (minibatch gather), or null: row b
+    const float* f_loc;        // [137] MeanStdFilter vectors of PPOTrainer.filter.prepare(), or null (identity):
+    const float* f_inv;        //   x = clamp((obs - loc) * inv, lo, hi)
+    const float* f_lo;
+    const float* f_hi;
+    const __bf16* wpack;       // [2][kPackElems]
+    const float* bias;         // [2][kBiasElems]
+    float* head;               // [2][B][16] raw head outputs (float32)
+    __bf16* xs;                // [B][144] the nets' input as they saw it (saved for dW1), or null
+    __bf16* h1;                // [2][B][256] tanh activations (saved for the backward pass), or null
+    __bf16* h2;                // [2][B][256]
+    long long B;
+    int first_net, n_nets;     // blockIdx.y + first_net = net
+};
+
+// Forward pass of one 128-sample tile through one net: grid (ceil(B / 128), nets), 256 threads.
+__global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdParams P)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 lds[kMlpBM * kXS + kMlpBM * kHS];
+    __bf16* xt = lds;
+    __bf16* ht = lds + kMlpBM * kXS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int net = blockIdx.y + P.first_net;
+    const long long row0 = (long long)blockIdx.x * kMlpBM;
+    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    const float* bias = P.bias + net * kBiasElems;
+
+    // ---- stage 0: the tile's observations, filtered, as bf16 pairs [128][144] (columns 137.. zero)
+    {
+        float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
+        if (P.f_loc) {
+            for (int i = tid; i < 4 * kMlpInPad; i += kMlpThreads) {
+                const int which = i / kMlpInPad, k = i % kMlpInPad;
+                const float* src = which == 0 ? P.f_loc : (which == 1 ? P.f_inv : (which == 2 ? P.f_lo : P.f_hi));
+                fv[i] = k < kMlpIn ? src[k] : 0.f;
+            }
+        }
+        __syncthreads();
+        constexpr int kPairs = kMlpInPad / 2;                     // 72 column pairs per row
+        for (int e = tid; e < kMlpBM * kPairs; e += kMlpThreads) {
+            const int row = e / kPairs, k = 2 * (e % kPairs);
+            float v0 = 0.f, v1 = 0.f;
+            const long long b = row0 + row;
+            if (b < P.B) {
+                const float* src = P.obs + (P.idx ? P.idx[b] : b) * kMlpIn;
+                if (k < kMlpIn) v0 = src[k];
+                if (k + 1 < kMlpIn) v1 = src[k + 1];
+                if (P.f_loc) {
+                    v0 = fminf(fmaxf((v0 - fv[k]) * fv[kMlpInPad + k], fv[2 * kMlpInPad + k]), fv[3 * kMlpInPad + k]);
+                    v1 = fminf(fmaxf((v1 - fv[k + 1]) * fv[kMlpInPad + k + 1], fv[2 * kMlpInPad + k + 1]), fv[3 * kMlpInPad + k + 1]);
+                    if (k >= kMlpIn) v0 = 0.f;
+                    if (k + 1 >= kMlpIn) v1 = 0.f;
+                }
+            }
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 pk = {(__bf16)v0, (__bf16)v1};
+            *reinterpret_cast<bf16x2*>(xt + row * kXS + k) = pk;
+        }
+        __syncthreads();
+        if (P.xs && net == 0) {                                   // the input is the same for both nets: saved once
+            for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kMlpThreads) {
+                const int row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                if (row0 + row < P.B)
+                    *reinterpret_cast<uint4*>(P.xs + (row0 + row) * kMlpInPad + cc * 8) = *reinterpret_cast<const uint4*>(xt + row * kXS + cc * 8);
+            }
+        }
+    }
+
+    const int c = lane & 31, h = lane >> 5;
+    f32x16 acc[2][4];
+    // bias + tanh in registers, each register quad = four consecutive features of one sample -> one ds_write_b64
+    const auto epilogue = [&](const float* b) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(b + 64 * w + 32 * rb + 8 * q + 4 * h);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)tanh_fast(acc[rb][cb][4 * q + j] + bq[q][j]);
+                    *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h) = pk;
+                }
+        }
+    };
+
+    // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
+    mlp_zero_acc(acc);
+    mlp_gemm_w_xt<kMlpInPad, kXS>(wp + kOffW1 + (size_t)64 * w * kMlpInPad, xt, acc, lane);
+    epilogue(bias);
+    __syncthreads();
+    if (P.h1) mlp_store_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+
+    // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it
+    mlp_zero_acc(acc);
+    mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2 + (size_t)64 * w * kMlpHid, ht, acc, lane);
+    __syncthreads();
+    epilogue(bias + kMlpHid);
+    __syncthreads();
+    if (P.h2) mlp_store_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+
+    // ---- layer 3: head^T [16][samples] = W3 . H2^T + b3 with 16x16x32 MFMAs; wave w owns samples 32w .. 32w+31
+    {
+        const int r16 = lane & 15, g = lane >> 4;
+        f32x4 a3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const __bf16* w3 = wp + kOffW3 + r16 * kMlpHid + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < kMlpHid / 32; ++ks) {
+            const bf16x8 a = ld_global_bf16x8(w3 + 32 * ks);
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (32 * w + 16 * sb + r16) * kHS + 32 * ks + 8 * g);
+                a3[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, a3[sb], 0, 0, 0);
+            }
+        }
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            const long long b = row0 + 32 * w + 16 * sb + r16;      // column = sample, rows 4g .. 4g+3 = head entries
+            if (b < P.B) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = a3[sb] + b3;
+        }
+    }
+}
+
+struct MlpBwdParams {
+    const float* g_head;       // [2][B][16] d loss / d head (float32)
+    const __bf16* wpack;       // [2][kPackElems]
+    const __bf16* h1;          // [2][B][256]
+    const __bf16* h2;          // [2][B][256]
+    __bf16* dz1;               // [2][B][256] d loss / d (pre-activation of layer 1)
+    __bf16* dz2;               // [2][B][256]
+    long long B;
+};
+
+// Backward-data of one 128-sample tile: dZ2 = (G W3) * (1 - H2^2), dZ1 = (dZ2 W2) * (1 - H1^2).
+__global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const MlpBwdParams P)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * kMlpBM * kHS + kMlpBM * kGS];
+    __bf16* ht = lds;                       // H2, then H1
+    __bf16* dz = lds + kMlpBM * kHS;        // dZ2, then dZ1
+    __bf16* gt = lds + 2 * kMlpBM * kHS;    // head gradients as bf16 [128][16]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int net = blockIdx.y;
+    const long long row0 = (long long)blockIdx.x * kMlpBM;
+    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    const int c = lane & 31, h = lane >> 5;
+
+    {   // head gradients: thread = (row, half): eight floats -> one ds_write_b128
+        const int row = tid >> 1, half = tid & 1;
+        bf16x8 pk;
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+        if (row0 + row < P.B) {
+            const float* gp = P.g_head + ((size_t)net * P.B + row0 + row) * kMlpHead + 8 * half;
+            g0 = *reinterpret_cast<const f32x4*>(gp); g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pk[j] = (__bf16)g0[j]; pk[4 + j] = (__bf16)g1[j]; }
+        *reinterpret_cast<bf16x8*>(gt + row * kGS + 8 * half) = pk;
+    }
+    mlp_load_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+    __syncthreads();
+
+    f32x16 acc[2][4];
+    // acc * (1 - h^2) with h from the activation tile, packed into the gradient tile (same quad layout as forward)
+    const auto epilogue = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h;
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(ht + off);
+                    bf16x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float hf = (float)hv[j]; pk[j] = (__bf16)(acc[rb][cb][4 * q + j] * (1.0f - hf * hf)); }
+                    *reinterpret_cast<bf16x4*>(dz + off) = pk;
+                }
+    };
+
+    // ---- dH2^T = W3^T . G^T: one k-step of 16 (the padded head rows are zero)
+    mlp_zero_acc(acc);
+    {
+        const __bf16* wa = wp + kOffW3T + (size_t)(64 * w + c) * kMlpHead + 8 * h;
+        bf16x8 a[2] = {ld_global_bf16x8(wa), ld_global_bf16x8(wa + 32 * kMlpHead)};
+        bf16x8 b[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+    }
+    epilogue();
+    __syncthreads();
+    mlp_store_htile(dz, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+    mlp_load_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);      // every wave is done with H2
+    __syncthreads();
+
+    // ---- dH1^T = W2^T . dZ2^T
+    mlp_zero_acc(acc);
+    mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2T + (size_t)64 * w * kMlpHid, dz, acc, lane);
+    __syncthreads();                         // all reads of dZ2 done before it is overwritten
+    epilogue();
+    __syncthreads();
+    mlp_store_htile(dz, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight gradients: dW = dZ^T . H over the samples of one batch slice, written to that slice's slab.
+// grid (slices, 4 parts, nets): part 0 / 1 = the two 128-column halves of dW2, part 2 = dW1 and db1 (the input tile
+// carries a column of ones at k = 144), part 3 = dW3, db3 and db2 (16x16x32 MFMAs, a fragment of ones).
+// ---------------------------------------------------------------------------------------------------------------
+struct MlpWgradParams {
+    const float* g_head;       // [2][B][16]
+    const __bf16* xs;          // [B][144]
+    const __bf16* h1;          // [2][B][256]
+    const __bf16* h2;
+    const __bf16* dz1;
+    const __bf16* dz2;
+    float* slabs;              // [slices][2][kGradElems]
+    long long B;
+    long long slice_rows;      // samples per slice, a multiple of kWgChunk
+};
+
+// stage `rows` x `cols` bf16 (cols a multiple of 8) from row-major global (row stride src_stride) into an LDS tile
+__device__ __forceinline__ void wg_stage(__bf16* tile, int tstride, const __bf16* __restrict__ src, long long src_stride,
+                                         long long row0, long long n_rows, int cols, int tid)
+{
+    const int cpr = cols / 8;
+    for (int ch = tid; ch < kWgChunk * cpr; ch += kMlpThreads) {
+        const int row = ch / cpr, cc = ch % cpr;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row0 + row < n_rows) v = *reinterpret_cast<const uint4*>(src + (row0 + row) * src_stride + cc * 8);
+        *reinterpret_cast<uint4*>(tile + row * tstride + cc * 8) = v;
+    }
+}
+
+// a 32x32x16 operand fragment whose k index is the SAMPLE: eight consecutive rows s0 + 8h .. +7 of column
+// col0 + (lane & 31) of a row-major tile, by two transposed 4x16 reads (cdna_hip_programming.md T10)
+__device__ __forceinline__ bf16x8 wg_frag32(const __bf16* tile, int tstride, int s0, int col0, int lane)
+{
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const __bf16* a = tile + (s0 + 8 * (G >> 1) + q) * tstride + col0 + 16 * (G & 1) + 4 * p;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * tstride));
+    // whole-vector bit cast: built element by element (f[j] = bit_cast<__bf16>(lo[j])), hipcc 7.2 replicated element 0
+    // of each read into all four slots (v_perm_b32 0x05040100 of one register with itself) — found in the ISA after
+    // every sample = 0 mod 4 came out weighted four times and the others not at all
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// the 16x16x32 form: rows s0 + 8g .. +7 (g = lane >> 4) of column col0 + (lane & 15)
+__device__ __forceinline__ bf16x8 wg_frag16(const __bf16* tile, int tstride, int s0, int col0, int lane)
+{
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const __bf16* a = tile + (s0 + 8 * g + q) * tstride + col0 + 4 * p;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * tstride));
+    // whole-vector bit cast: built element by element (f[j] = bit_cast<__bf16>(lo[j])), hipcc 7.2 replicated element 0
+    // of each read into all four slots (v_perm_b32 0x05040100 of one register with itself) — found in the ISA after
+    // every sample = 0 mod 4 came out weighted four times and the others not at all
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// store a 32x32 accumulator block to a row-major float32 matrix: rows row0.., cols col0.. (cols < ncols kept)
+__device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, int row0, int col0, int ncols, const f32x16& a, int lane)
+{
+    const int c = lane & 31, h = lane >> 5;
+    if (col0 + c < ncols) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[(size_t)(row0 + (i & 3) + 8 * (i >> 2) + 4 * h) * ld + col0 + c] = a[i];
+    }
+}
+
+__global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradParams P)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 lds[kWgChunk * kTrH + kWgChunk * kTrH + kWgChunk * kTrG];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int slice = blockIdx.x, part = blockIdx.y, net = blockIdx.z;
+    const long long s_begin = (long long)slice * P.slice_rows;
+    long long s_end = s_begin + P.slice_rows;
+    if (s_end > P.B) s_end = P.B;
+    float* slab = P.slabs + ((size_t)slice * kMlpNets + net) * kGradElems;
+    const size_t nb = (size_t)net * P.B * kMlpHid;
+
+    if (part < 2) {
+        // dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half]; waves 2 x 2, each 128 (o) x 64 (i)
+        __bf16* ta = lds;                        // dZ2 chunk [64][256], stride kTrH
+        __bf16* tb = lds + kWgChunk * kTrH;      // H1 chunk [64][128], stride kTrHalf
+        const int wo = w >> 1, wi = w & 1;
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        for (long long s = s_begin; s < s_end; s += kWgChunk) {
+            __syncthreads();
+            wg_stage(ta, kTrH, P.dz2 + nb, kMlpHid, s, s_end, kMlpHid, tid);
+            wg_stage(tb, kTrHalf, P.h1 + nb + 128 * part, kMlpHid, s, s_end, 128, tid);
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < kWgChunk / 16; ++ks) {
+                bf16x8 fa[4], fb[2];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) fa[a] = wg_frag32(ta, kTrH, 16 * ks, 128 * wo + 32 * a, lane);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fb[b] = wg_frag32(tb, kTrHalf, 16 * ks, 64 * wi + 32 * b, lane);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                wg_store_block(slab + kGW2, kMlpHid, 128 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
+    } else if (part == 2) {
+        // dW1 = dZ1^T . X (144 columns) and db1 = dZ1^T . 1 (the tile's column 144 is all ones); wave w: rows 64w..
+        __bf16* ta = lds;                        // dZ1 chunk [64][256]
+        __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
+        f32x16 acc[2][5];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        for (long long s = s_begin; s < s_end; s += kWgChunk) {
+            __syncthreads();
+            wg_stage(ta, kTrH, P.dz1 + nb, kMlpHid, s, s_end, kMlpHid, tid);
+            wg_stage(tb, kTrX, P.xs, kMlpInPad, s, s_end, kMlpInPad, tid);
+            if (tid < kWgChunk) {                                     // columns 144..159: a one (real rows only), zeros
+                bf16x8 one = {(__bf16)((s + tid < s_end) ? 1.0f : 0.0f), (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad) = one;
+                *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad + 8) = zero;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < kWgChunk / 16; ++ks) {
+                bf16x8 fa[2], fb[5];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fa[a] = wg_frag32(ta, kTrH, 16 * ks, 64 * w + 32 * a, lane);
+#pragma unroll
+                for (int b = 0; b < 5; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * b, lane);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 5; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int b = 0; b < 5; ++b) wg_store_block(slab + kGW1, kMlpInPad, 64 * w + 32 * a, 32 * b, kMlpInPad, acc[a][b], lane);
+            // column 144 of the product = db1: lane c == 16 of block b == 4
+            if ((lane & 31) == 16) {
+                const int hh = lane >> 5;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) slab[kGB1 + 64 * w + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[a][4][i];
+            }
+        }
+    } else {
+        // dW3 [16][256] = G^T . H2, db3 = G^T . 1, db2 = 1^T . dZ2, all with 16x16x32 MFMAs (32 samples per k-step)
+        __bf16* th = lds;                        // H2 chunk [64][256]
+        __bf16* tz = lds + kWgChunk * kTrH;      // dZ2 chunk [64][256]
+        __bf16* tg = lds + 2 * kWgChunk * kTrH;  // G chunk [64][16] as bf16
+        f32x4 aw3[4], ab2[4], ab3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { aw3[b] = ab3; ab2[b] = ab3; }
+        bf16x8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+        for (long long s = s_begin; s < s_end; s += kWgChunk) {
+            __syncthreads();
+            wg_stage(th, kTrH, P.h2 + nb, kMlpHid, s, s_end, kMlpHid, tid);
+            wg_stage(tz, kTrH, P.dz2 + nb, kMlpHid, s, s_end, kMlpHid, tid);
+            if (tid < 2 * kWgChunk) {
+                const int row = tid >> 1, half = tid & 1;
+                f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+                if (s + row < s_end) {
+                    const float* gp = P.g_head + ((size_t)net * P.B + s + row) * kMlpHead + 8 * half;
+                    g0 = *reinterpret_cast<const f32x4*>(gp); g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                }
+                bf16x8 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { pk[j] = (__bf16)g0[j]; pk[4 + j] = (__bf16)g1[j]; }
+                *reinterpret_cast<bf16x8*>(tg + row * kTrG + 8 * half) = pk;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < kWgChunk / 32; ++ks) {
+                const bf16x8 fg = wg_frag16(tg, kTrG, 32 * ks, 0, lane);          // A: rows = head entries
+                if (w == 0) ab3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, ones, ab3, 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {                                      // wave w: feature columns 64w + 16b ..
+                    const bf16x8 fh = wg_frag16(th, kTrH, 32 * ks, 64 * w + 16 * b, lane);
+                    aw3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, fh, aw3[b], 0, 0, 0);
+                    const bf16x8 fz = wg_frag16(tz, kTrH, 32 * ks, 64 * w + 16 * b, lane);
+                    ab2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fz, ab2[b], 0, 0, 0);
+                }
+            }
+        }
+        const int c16 = lane & 15, g = lane >> 4;                  // C: col = lane & 15, rows 4g .. 4g+3
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab[kGW3 + (4 * g + j) * kMlpHid + 64 * w + 16 * b + c16] = aw3[b][j];
+            if (g == 0) slab[kGB2 + 64 * w + 16 * b + c16] = ab2[b][0];            // every row of 1^T . dZ2 is db2
+        }
+        if (w == 0 && c16 == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab[kGB3 + 4 * g + j] = ab3[j];           // every column of G^T . 1 is db3
+        }
+    }
+}
+
+struct MlpReduceParams {
+    const float* slabs;        // [slices][2][kGradElems]
+    int slices;
+    float* gw1[kMlpNets]; float* gb1[kMlpNets];    // gradients in the master parameters' layouts
+    float* gw2[kMlpNets]; float* gb2[kMlpNets];
+    float* gw3[kMlpNets]; float* gb3[kMlpNets];
+    int n3[kMlpNets];
+    int accumulate;            // 1: add to what the gradient tensors hold (autograd accumulation), 0: overwrite
+};
+
+// Sum the slices' slabs in slice order (deterministic) and scatter into the parameter-shaped gradients.
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(const MlpReduceParams P)
+{
+    const int net = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kGradElems) return;
+    float* dst = nullptr;
+    if (e < kGW2) { const int o = e / kMlpInPad, k = e % kMlpInPad; if (k < kMlpIn) dst = P.gw1[net] + o * kMlpIn + k; }
+    else if (e < kGW3) dst = P.gw2[net] + (e - kGW2);
+    else if (e < kGB1) { const int r = (e - kGW3) / kMlpHid; if (r < P.n3[net]) dst = P.gw3[net] + (e - kGW3); }
+    else if (e < kGB2) dst = P.gb1[net] + (e - kGB1);
+    else if (e < kGB3) dst = P.gb2[net] + (e - kGB2);
+    else if (e - kGB3 < P.n3[net]) dst = P.gb3[net] + (e - kGB3);
+    if (!dst) return;
+    float s = 0.f;
+    const float* p = P.slabs + (size_t)net * kGradElems + e;
+    for (int k = 0; k < P.slices; ++k) s += p[(size_t)k * kMlpNets * kGradElems];
+    *dst = P.accumulate ? (*dst + s) : s;
+}
+
+}  // namespace pnr

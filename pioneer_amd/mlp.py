@@ -1,0 +1,145 @@
+"""The PPO driver's two MLPs on the hand-written bf16 MFMA kernels of csrc/pnr_mlp.h (C ABI: pnr_mlp_*).
+
+``HipMLP`` owns the packed bf16 weights and the activation / gradient workspaces for one ``ActorCritic`` and exposes
+
+* ``forward_nograd``  the sampling path: heads of a batch of RAW observations, the MeanStdFilter applied on load;
+* ``apply``           the learner path: an autograd function (forward kernel saves the activations; backward =
+                      backward-data + weight-gradient + reduction kernels) whose outputs are the two nets' raw head rows
+                      ``[B, 16]`` — what ``pnr_ppo_loss`` consumes — and whose gradients land on the float32 master
+                      parameters of the module, so torch's Adam (or any optimiser) keeps working unchanged.
+
+The master parameters stay float32 ``nn.Linear`` tensors (checkpoints, CPU tests, the reference's [256, 256] tanh nets of
+pioneer/launch/pioneer_knm_train.py:59-61); there is no fallback: without the HIP library this module raises.
+"""
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+HEAD = 16
+IN_PAD = 144
+HID = 256
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipMLP:
+    def __init__(self, model: nn.Module, max_batch: int, device):
+        self.lib = _lib.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise AssertionError("HipMLP needs a HIP device")
+        self.model = model
+        self.max_batch = int(max_batch)
+        pol = [l for l in model.policy if isinstance(l, nn.Linear)]
+        val = [l for l in model.value if isinstance(l, nn.Linear)]
+        for lins in (pol, val):
+            shapes = [tuple(l.weight.shape) for l in lins]
+            if len(lins) != 3 or shapes[0] != (HID, 137) or shapes[1] != (HID, HID) or shapes[2][1] != HID or shapes[2][0] > HEAD:
+                raise AssertionError(f"HipMLP is built for 137-256-256-n (n <= 16) nets, got {shapes}")
+        self.n3 = (pol[2].out_features, val[2].out_features)
+        self.params = [t for lins in (pol, val) for l in lins for t in (l.weight, l.bias)]     # 12, net-major
+        assert all(p.dtype == torch.float32 and p.is_contiguous() and p.device == self.device for p in self.params)
+        bf, f32 = dict(dtype=torch.bfloat16, device=self.device), dict(dtype=torch.float32, device=self.device)
+        self.wpack = torch.empty(int(self.lib.pnr_mlp_pack_elems()), **bf)
+        self.bias = torch.empty(int(self.lib.pnr_mlp_bias_elems()), **f32)
+        B = self.max_batch
+        self._train_ws = None
+
+    # -- plumbing ---------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _ptrs(tensors: Sequence[torch.Tensor]):
+        """A ctypes array of device pointers (read by the library during the call only)."""
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def _workspace(self):
+        if self._train_ws is None:
+            B = self.max_batch
+            bf, f32 = dict(dtype=torch.bfloat16, device=self.device), dict(dtype=torch.float32, device=self.device)
+            self._train_ws = {
+                "xs": torch.empty((B, IN_PAD), **bf),
+                "h1": torch.empty((2, B, HID), **bf), "h2": torch.empty((2, B, HID), **bf),
+                "dz1": torch.empty((2, B, HID), **bf), "dz2": torch.empty((2, B, HID), **bf),
+                "slabs": torch.empty(int(self.lib.pnr_mlp_slab_floats(B)), **f32),
+                "g": torch.empty((2, B, HEAD), **f32),
+            }
+        return self._train_ws
+
+    def pack(self) -> None:
+        """bf16 copies of the current master weights (padded, plus the transposes the backward pass reads)."""
+        _lib.check(self.lib.pnr_mlp_pack(self._ptrs(self.params), self.n3[0], self.n3[1], _p(self.wpack), _p(self.bias),
+                                         self._stream()))
+
+    def _launch_forward(self, B, obs, idx, filt, head, save):
+        ws = self._workspace() if save else None
+        f = filt if filt is not None else (None, None, None, None)
+        self._batch_of_ws(B)       # the kernels index the saved activations as [2][B][256] with the CURRENT batch size
+        _lib.check(self.lib.pnr_mlp_forward(B, _p(obs), _p(idx), _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(self.wpack), _p(self.bias),
+                                            _p(head), _p(ws["xs"]) if ws else None, _p(ws["h1"]) if ws else None,
+                                            _p(ws["h2"]) if ws else None, 0, 2, self._stream()))
+
+    def _batch_of_ws(self, B):
+        if B > self.max_batch:
+            raise AssertionError(f"batch {B} exceeds the workspace ({self.max_batch})")
+        return B
+
+    @staticmethod
+    def _check_inputs(obs, idx, filt, device):
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[-1] == 137 and obs.device == device
+        if idx is not None:
+            assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.device == device
+        if filt is not None:
+            assert len(filt) == 4 and all(v.dtype == torch.float32 and v.numel() == 137 and v.is_contiguous() for v in filt)
+
+    # -- the sampling path ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_nograd(self, obs: torch.Tensor, idx: Optional[torch.Tensor] = None, filt=None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Heads [2, B, 16] (policy rows: means 0..5, raw log-stds 6..11; value rows: v at column 0) of ``obs[idx]``
+        (or ``obs``) on the weights of the last ``pack()``."""
+        self._check_inputs(obs, idx, filt, self.device)
+        B = int(idx.numel()) if idx is not None else int(obs.numel() // 137)
+        head = out if out is not None else torch.empty((2, B, HEAD), dtype=torch.float32, device=self.device)
+        assert head.is_contiguous() and tuple(head.shape) == (2, B, HEAD)
+        self._launch_forward(B, obs, idx, filt, head, save=False)
+        return head
+
+    # -- the learner path -------------------------------------------------------------------------------------
+    def apply(self, obs: torch.Tensor, idx: Optional[torch.Tensor] = None, filt=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(head_policy [B, 16], head_value [B, 16]) with autograd through the HIP backward kernels.  Packs the
+        current weights first.  One application at a time: the saved activations live in this object's workspace."""
+        self._check_inputs(obs, idx, filt, self.device)
+        out = _FusedMLP.apply(self, obs, idx, filt, *self.params)
+        return out[0], out[1]
+
+
+class _FusedMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mlp: HipMLP, obs, idx, filt, *params):
+        B = int(idx.numel()) if idx is not None else int(obs.numel() // 137)
+        mlp._batch_of_ws(B)
+        mlp.pack()
+        head = torch.empty((2, B, HEAD), dtype=torch.float32, device=mlp.device)
+        mlp._launch_forward(B, obs, idx, filt, head, save=True)
+        ctx.mlp, ctx.B = mlp, B
+        return head
+
+    @staticmethod
+    def backward(ctx, g_head):
+        mlp, B = ctx.mlp, ctx.B
+        ws = mlp._workspace()
+        g = g_head.contiguous()
+        assert g.dtype == torch.float32 and tuple(g.shape) == (2, B, HEAD)
+        grads = [torch.empty_like(p) for p in mlp.params]
+        _lib.check(mlp.lib.pnr_mlp_backward(B, _p(g), _p(mlp.wpack), _p(ws["xs"]), _p(ws["h1"]), _p(ws["h2"]), _p(ws["dz1"]),
+                                            _p(ws["dz2"]), _p(ws["slabs"]), ws["slabs"].numel(), mlp._ptrs(grads),
+                                            mlp.n3[0], mlp.n3[1], 0, mlp._stream()))
+        return (None, None, None, None, *grads)

@@ -1,0 +1,148 @@
+"""The hand-written bf16 MFMA MLP kernels (csrc/pnr_mlp.h, pioneer_amd/mlp.py) against torch.
+
+Two references on the same weights and inputs: (a) plain float32 torch autograd of the ActorCritic module — the
+semantics; tolerance = what bf16 operands cost (relative L2 <= 1.5e-2 forward, 3e-2 gradients); (b) a float64
+restatement that rounds to bf16 exactly where the kernels do (weights, inputs, stored activations, propagated
+gradients) — the kernels' arithmetic; relative L2 <= 2e-3 (float32 accumulation order, the exp2-based tanh).
+Batches 1, 4 099 (ragged tiles and slices) and 131 072 (the large minibatch), with and without the row gather and
+the observation filter."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+NAMES = ["w1", "b1", "w2", "b2", "w3", "b3"] * 2
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf(x):
+    return x.to(torch.bfloat16).double()
+
+
+def make(B, seed, rows=None, with_filter=False):
+    from pioneer_amd.ppo import ActorCritic, PPOConfig
+    from pioneer_amd.mlp import HipMLP
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(seed)
+    model = ActorCritic(PPOConfig()).to(dev)
+    with torch.no_grad():                                   # heads of visible size, non-zero biases
+        for net in (model.policy, model.value):
+            for l in net:
+                if isinstance(l, torch.nn.Linear):
+                    l.bias.normal_(0, 0.1)
+        model.policy[4].weight.mul_(30.0)
+    g = torch.Generator(device=dev).manual_seed(seed + 1)
+    rows = rows or B
+    obs = torch.randn(rows, 137, generator=g, device=dev) * 2.0 + 0.3
+    idx = torch.randperm(rows, generator=g, device=dev)[:B].contiguous() if rows != B else None
+    filt = None
+    if with_filter:
+        loc = torch.randn(137, generator=g, device=dev) * 0.5
+        inv = torch.rand(137, generator=g, device=dev) + 0.5
+        hi = torch.full((137,), 2.5, device=dev)
+        filt = (loc, inv, -hi, hi)
+    return model, HipMLP(model, B, dev), obs, idx, filt
+
+
+def net_input(obs, idx, filt):
+    x = obs if idx is None else obs[idx]
+    if filt is not None:
+        x = torch.clamp((x - filt[0]) * filt[1], min=filt[2], max=filt[3])
+    return x
+
+
+def head_grads(B, dev, seed=5):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    g_head = torch.randn(2, B, 16, generator=g, device=dev) * (1.0 / B)
+    g_head[0, :, 12:] = 0
+    g_head[1, :, 1:] = 0                                    # the loss kernel never puts gradient on the padding rows
+    return g_head
+
+
+def emulate(model, x, g_head):
+    """float64 restatement with the kernels' bf16 rounding points.  Returns heads [2][B][16] and 12 gradients."""
+    heads, grads = [], []
+    xb = bf(x)
+    for n, net in enumerate((model.policy, model.value)):
+        W1, b1, W2, b2, W3, b3 = [t.detach() for l in net if isinstance(l, torch.nn.Linear) for t in (l.weight, l.bias)]
+        h1 = bf(torch.tanh(xb @ bf(W1).t() + b1.double()))
+        h2 = bf(torch.tanh(h1 @ bf(W2).t() + b2.double()))
+        n3 = W3.shape[0]
+        head = torch.zeros(x.shape[0], 16, dtype=torch.float64, device=x.device)
+        head[:, :n3] = h2 @ bf(W3).t() + b3.double()
+        heads.append(head)
+        gb = bf(g_head[n])[:, :n3]
+        dz2 = bf((gb @ bf(W3)) * (1 - h2 * h2))
+        dz1 = bf((dz2 @ bf(W2)) * (1 - h1 * h1))
+        grads += [dz1.t() @ xb, dz1.sum(0), dz2.t() @ h1, dz2.sum(0), gb.t() @ h2, gb.sum(0)]
+    return torch.stack(heads), grads
+
+
+@pytest.mark.parametrize("B,rows,with_filter", [(1, None, False), (4099, 6000, True), (131072, None, False), (32768, 40000, True)])
+def test_forward_and_backward_match_torch(B, rows, with_filter):
+    model, mlp, obs, idx, filt = make(B, seed=B % 97, rows=rows, with_filter=with_filter)
+    x = net_input(obs, idx, filt)
+    g_head = head_grads(B, obs.device)
+
+    # --- kernels
+    hp, hv = mlp.apply(obs, idx, filt)
+    assert hp.shape == (B, 16) and hv.shape == (B, 16)
+    got = torch.autograd.grad((hp * g_head[0]).sum() + (hv * g_head[1]).sum(), mlp.params)
+    assert bool((hp[:, 12:] == 0).all()) and bool((hv[:, 1:] == 0).all())   # zero rows of the padded heads
+
+    # --- (a) float32 torch autograd
+    ref_p, ref_v = model.policy(x), model.value(x)
+    ref = torch.autograd.grad((ref_p * g_head[0, :, :12]).sum() + (ref_v * g_head[1, :, :1]).sum(), mlp.params)
+    assert rel(hp[:, :12], ref_p) < 1.5e-2 and rel(hv[:, :1], ref_v) < 1.5e-2
+    for a, b, name in zip(got, ref, NAMES):
+        assert rel(a, b) < 3e-2, (name, rel(a, b))
+
+    # --- (b) the kernels' arithmetic restated in float64 with bf16 rounding points
+    e_heads, e_grads = emulate(model, x, g_head)
+    assert rel(hp, e_heads[0]) < 2e-3 and rel(hv, e_heads[1]) < 2e-3
+    for a, b, name in zip(got, e_grads, NAMES):
+        assert rel(a, b) < 2e-3, (name, rel(a, b))
+
+
+def test_nograd_forward_equals_training_forward_and_respects_bounds():
+    """The sampling path (no saved activations) gives the same heads and writes nothing behind its output."""
+    B = 3000
+    model, mlp, obs, idx, filt = make(B, seed=3, with_filter=True)
+    hp, hv = mlp.apply(obs, idx, filt)
+    guard = torch.full((2 * B * 16 + 4096,), 7.0, device=obs.device)
+    hb = guard[:2 * B * 16].view(2, B, 16)
+    h = mlp.forward_nograd(obs, idx, filt, out=hb)
+    assert torch.equal(h[0], hp) and torch.equal(h[1], hv)
+    assert bool((guard[2 * B * 16:] == 7.0).all())
+
+
+def test_graph_replay_of_the_learner_kernels_is_exact():
+    """Captured once, replayed on fresh inputs: bit-identical heads and gradients to eager launches, replay after
+    replay (no semaphores, no atomics, no library workspaces in these kernels; fixed-order slab reduction)."""
+    B = 8192
+    model, mlp, obs, idx, filt = make(B, seed=11)
+    dev = obs.device
+    g_head = head_grads(B, dev)
+    static_obs = obs.clone()
+
+    def run():
+        hp, hv = mlp.apply(static_obs)
+        return hp, hv, torch.autograd.grad((hp * g_head[0]).sum() + (hv * g_head[1]).sum(), mlp.params)
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        hp, hv, grads = run()
+    gen = torch.Generator(device=dev).manual_seed(0)
+    for it in range(4):
+        static_obs.copy_(torch.randn(B, 137, generator=gen, device=dev))
+        g_head.copy_(head_grads(B, dev, seed=100 + it))
+        gr.replay()
+        ehp, ehv, egrads = run()
+        assert torch.equal(hp, ehp) and torch.equal(hv, ehv)
+        for a, b in zip(grads, egrads):
+            assert torch.equal(a, b)
