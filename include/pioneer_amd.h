@@ -218,20 +218,23 @@ int pnr_diag_sincos(const float* x, float* sin_out, float* cos_out, int64_t n,
  * replays), forward and backward in one launch.  head_policy / head_value are the two nets' raw
  * outputs as rows of 16 floats (means 0..5, log-stds 6..11 | value 0); the gradients of the batch-mean
  * loss come back in the same layout; partial_sums [partial_rows][8] receives per-block sums of
- * (policy_loss, vf_loss, kl, entropy, total) with partial_rows >= ceil(batch / 256).  Device pointers. */
-int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_value, const float* actions,
+ * (policy_loss, vf_loss, kl, entropy, total) with partial_rows >= ceil(batch / 256).  idx (int64 [batch], or NULL) is
+ * the minibatch gather: sample i's rollout record (actions .. value_old) is row idx[i] of those arrays, while the
+ * head rows and their gradients are indexed by i.  means (8 floats, or NULL) receives the five batch means, summed from
+ * partial_sums in row order by a second small launch.  Device pointers. */
+int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, const float* head_value, const float* actions,
                  const float* logp_old, const float* mean_old, const float* log_std_old, const float* adv,
                  const float* value_target, const float* value_old, const float* kl_coeff,
                  const float* entropy_coeff, float clip_param, float vf_clip_param, float vf_loss_coeff,
                  float* grad_head_policy, float* grad_head_value, float* partial_sums, int64_t partial_rows,
-                 void* stream);
+                 float* means, void* stream);
 
 /*
  * Host-driver helpers (not part of the env surface): the two MLPs of the reference's PPO config — 'fcnet_hiddens':
  * [256, 256] (pioneer/launch/pioneer_knm_train.py:59-61), tanh, separate policy (12 outputs: 6 means + 6 log-stds) and
  * value (1 output) nets, RLlib's FullyConnectedNetwork with vf_share_layers False — as bf16 MFMA kernels.
  *   params / grads  12 device pointers, net-major: policy w1 [256][137], b1 [256], w2 [256][256], b2 [256],
- *                   w3 [n3][256], b3 [n3], then the value net's six; float32, torch nn.Linear layouts
+ *                   w3 [n3][256], b3 [n3], then the value net's six; float32, row-major [out][in] as the host keeps them
  *   wpack           pnr_mlp_pack_elems() bf16 values; bias: pnr_mlp_bias_elems() floats (written by pnr_mlp_pack)
  *   obs             [rows][137] float32; idx [batch] int64 row gather or NULL; f_loc/f_inv/f_lo/f_hi [137] or all NULL:
  *                   the nets see clamp((obs - loc) * inv, lo, hi), the MeanStdFilter of the reference's config (:66)
@@ -239,7 +242,8 @@ int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_valu
  *   xs [batch][144], h1 / h2 / dz1 / dz2 [2][batch][256] bf16: activations kept for / made by the backward pass
  *   slabs           >= pnr_mlp_slab_floats(batch) floats of scratch (per-slice partial gradients, summed in order)
  * pnr_mlp_backward = backward-data + weight gradients + reduction; gradients of the batch as given by g_head
- * [2][batch][16] (d loss / d head), written (accumulate = 0) or added (1) to `grads`.
+ * [2][batch][16] (d loss / d head), times the device scalar *scale when scale != NULL, written (accumulate = 0) or
+ * added (1) to `grads`.
  */
 int64_t pnr_mlp_pack_elems(void);
 int64_t pnr_mlp_bias_elems(void);
@@ -250,7 +254,7 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
                     void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, void* stream);
 int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
                      void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
-                     int32_t n3_value, int32_t accumulate, void* stream);
+                     int32_t n3_value, int32_t accumulate, const float* scale, void* stream);
 
 int64_t pnr_num_envs(pnr_handle h);
 

@@ -80,13 +80,13 @@ SIGNATURES = {
     "pnr_get_dyn_state": (C.c_int, [_VP, _VP, _VP]),
     "pnr_set_dyn_state": (C.c_int, [_VP, _VP, _VP]),
     "pnr_diag_sincos": (C.c_int, [_VP, _VP, _VP, C.c_int64, C.c_int, _VP]),
-    "pnr_ppo_loss": (C.c_int, [C.c_int64] + [_VP] * 11 + [C.c_float] * 3 + [_VP] * 3 + [C.c_int64, _VP]),
+    "pnr_ppo_loss": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_float] * 3 + [_VP] * 3 + [C.c_int64, _VP, _VP]),
     "pnr_mlp_pack_elems": (C.c_int64, []),
     "pnr_mlp_bias_elems": (C.c_int64, []),
     "pnr_mlp_slab_floats": (C.c_int64, [C.c_int64]),
     "pnr_mlp_pack": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     "pnr_mlp_forward": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_int32, C.c_int32, _VP]),
-    "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP]),
+    "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "pnr_num_envs": (C.c_int64, [_VP]),
     "pnr_last_error": (C.c_char_p, [_VP]),
 }

@@ -1086,11 +1086,11 @@ int pnr_diag_sincos(const float* x, float* sin_out, float* cos_out, int64_t n, i
     return PNR_OK;
 }
 
-int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_value, const float* actions,
+int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, const float* head_value, const float* actions,
                  const float* logp_old, const float* mean_old, const float* log_std_old, const float* adv,
                  const float* value_target, const float* value_old, const float* kl_coeff, const float* entropy_coeff,
                  float clip_param, float vf_clip_param, float vf_loss_coeff, float* grad_head_policy,
-                 float* grad_head_value, float* partial_sums, int64_t partial_rows, void* stream)
+                 float* grad_head_value, float* partial_sums, int64_t partial_rows, float* means, void* stream)
 {
     if (batch <= 0 || !head_policy || !head_value || !actions || !logp_old || !mean_old || !log_std_old || !adv ||
         !value_target || !value_old || !kl_coeff || !entropy_coeff || !grad_head_policy || !grad_head_value || !partial_sums)
@@ -1101,10 +1101,14 @@ int pnr_ppo_loss(int64_t batch, const float* head_policy, const float* head_valu
                     (long long)partial_rows, blocks);
     PpoLossParams P;
     P.head_p = head_policy; P.head_v = head_value; P.actions = actions; P.logp_old = logp_old; P.mean_old = mean_old;
+    P.idx = reinterpret_cast<const long long*>(idx);
     P.ls_old = log_std_old; P.adv = adv; P.vtarg = value_target; P.v_old = value_old; P.kl_coeff = kl_coeff;
     P.ent_coeff = entropy_coeff; P.g_head_p = grad_head_policy; P.g_head_v = grad_head_value; P.partials = partial_sums;
     P.B = batch; P.clip = clip_param; P.vf_clip = vf_clip_param; P.vf_coeff = vf_loss_coeff;
     hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)blocks), dim3(kPpoBlock), 0, (hipStream_t)stream, P);
+    if (means)
+        hipLaunchKernelGGL(ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_sums, (long long)blocks,
+                           (long long)batch, means);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }
@@ -1172,7 +1176,7 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
 
 int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
                      void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
-                     int32_t n3_value, int32_t accumulate, void* stream)
+                     int32_t n3_value, int32_t accumulate, const float* scale, void* stream)
 {
     if (batch < 1 || !g_head || !wpack || !xs || !h1 || !h2 || !dz1 || !dz2 || !slabs || !grads)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: null argument or empty batch");
@@ -1191,7 +1195,7 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows;
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, 4, kMlpNets), dim3(kMlpThreads), 0, st, Wp);
     MlpReduceParams Rp;
-    Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate;
+    Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate; Rp.scale = scale;
     for (int n = 0; n < kMlpNets; ++n) {
         for (int k = 0; k < 6; ++k)
             if (!grads[6 * n + k]) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: null gradient %d of net %d", k, n);

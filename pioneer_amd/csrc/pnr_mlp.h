@@ -615,6 +615,7 @@ struct MlpReduceParams {
     float* gw3[kMlpNets]; float* gb3[kMlpNets];
     int n3[kMlpNets];
     int accumulate;            // 1: add to what the gradient tensors hold (autograd accumulation), 0: overwrite
+    const float* scale;        // device scalar multiplied into the sums (the upstream d / d loss), or null: 1
 };
 
 // Sum the slices' slabs in slice order (deterministic) and scatter into the parameter-shaped gradients.
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const MlpReduceParams P
     float s = 0.f;
     const float* p = P.slabs + (size_t)net * kGradElems + e;
     for (int k = 0; k < P.slices; ++k) s += p[(size_t)k * kMlpNets * kGradElems];
+    if (P.scale) s *= *P.scale;
     *dst = P.accumulate ? (*dst + s) : s;
 }
 

@@ -29,6 +29,7 @@ struct PpoLossParams {
     const float* adv;       // [B]
     const float* vtarg;     // [B]
     const float* v_old;     // [B]
+    const long long* idx;   // [B] row of the rollout record (actions .. v_old) for sample i, or null: row i
     const float* kl_coeff;  // device scalars: their values change between graph replays
     const float* ent_coeff;
     float* g_head_p;        // [B][16]  d loss / d head_p
@@ -51,10 +52,11 @@ __global__ __launch_bounds__(kPpoBlock) void ppo_loss_kernel(const PpoLossParams
         const float m[6] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y};
         const float raw[6] = {h1.z, h1.w, h2.x, h2.y, h2.z, h2.w};
         const float v = P.head_v[i * kPpoHeadStride];
+        const long long r = P.idx ? P.idx[i] : i;                   // minibatch gather of the rollout record
         float a[6], m0[6], l0[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { a[j] = P.actions[i * 6 + j]; m0[j] = P.mean_old[i * 6 + j]; l0[j] = P.ls_old[i * 6 + j]; }
-        const float adv = P.adv[i], vt = P.vtarg[i], v0 = P.v_old[i], lp0 = P.logp_old[i];
+        for (int j = 0; j < 6; ++j) { a[j] = P.actions[r * 6 + j]; m0[j] = P.mean_old[r * 6 + j]; l0[j] = P.ls_old[r * 6 + j]; }
+        const float adv = P.adv[r], vt = P.vtarg[r], v0 = P.v_old[r], lp0 = P.logp_old[r];
 
         float ls[6], z[6], s[6];
         bool pass[6];
@@ -132,6 +134,20 @@ __global__ __launch_bounds__(kPpoBlock) void ppo_loss_kernel(const PpoLossParams
         }
         P.partials[(long long)blockIdx.x * kPpoSums + threadIdx.x] = x;
     }
+}
+
+// Sum the per-block partial rows in row order (one block, deterministic) and divide by the batch: the five reported
+// means.  A separate tiny launch instead of a last-block-done atomic: nothing here needs zeroed counters.
+__global__ __launch_bounds__(64) void ppo_loss_finish_kernel(const float* __restrict__ partials, long long rows, long long B,
+                                                             float* __restrict__ means)
+{
+    const int k = threadIdx.x & 7, part = threadIdx.x >> 3;       // 8 lanes per sum slot walk the rows 8 apart
+    float s = 0.f;
+    for (long long r = part; r < rows; r += 8) s += partials[r * kPpoSums + k];
+    s += __shfl_down(s, 32, 64);
+    s += __shfl_down(s, 16, 64);
+    s += __shfl_down(s, 8, 64);
+    if (threadIdx.x < kPpoSums) means[k] = s / (float)B;
 }
 
 }  // namespace pnr

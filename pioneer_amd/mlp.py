@@ -69,7 +69,8 @@ class HipMLP:
                 "h1": torch.empty((2, B, HID), **bf), "h2": torch.empty((2, B, HID), **bf),
                 "dz1": torch.empty((2, B, HID), **bf), "dz2": torch.empty((2, B, HID), **bf),
                 "slabs": torch.empty(int(self.lib.pnr_mlp_slab_floats(B)), **f32),
-                "g": torch.empty((2, B, HEAD), **f32),
+                "head": torch.empty(2 * B * HEAD, **f32), "g": torch.empty(2 * B * HEAD, **f32),
+                "partials": torch.empty(((B + 255) // 256, 8), **f32),
             }
         return self._train_ws
 
@@ -121,6 +122,56 @@ class HipMLP:
         return out[0], out[1]
 
 
+    def policy_loss(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float) -> torch.Tensor:
+        """The whole differentiable part of one PPO minibatch update in six launches: weight packing, the fused
+        forward of both nets, the loss kernel (pnr_ppo_loss: values + d loss / d head) and its finishing sum; the
+        backward pass (backward-data, weight gradients, reduction) runs when autograd reaches the returned tensor.
+        Returns the batch means [8] = (policy_loss, vf_loss, kl, entropy, total, ...); differentiate means[4].
+        ``rec``: the rollout record (actions [R, 6], logp, mean [R, 6], log_std [R, 6], adv, vtarg, values [R]); with
+        ``idx`` (int64 [B]) sample i is row idx[i] of ``obs`` and of the record."""
+        self._check_inputs(obs, idx, filt, self.device)
+        R = obs.shape[0]
+        for k in ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values"):
+            v = rec[k]
+            assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
+        assert tuple(rec["actions"].shape) == tuple(rec["mean"].shape) == tuple(rec["log_std"].shape) == (R, 6)
+        return _HipPolicyLoss.apply(self, obs, idx, filt, rec, kl_c, ent_c, float(clip), float(vf_clip), float(vf_coeff),
+                                    *self.params)
+
+
+class _HipPolicyLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mlp: HipMLP, obs, idx, filt, rec, kl_c, ent_c, clip, vf_clip, vf_coeff, *params):
+        B = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        mlp._batch_of_ws(B)
+        ws = mlp._workspace()
+        head = ws["head"][:2 * B * HEAD].view(2, B, HEAD)
+        g = ws["g"][:2 * B * HEAD].view(2, B, HEAD)
+        mlp.pack()
+        mlp._launch_forward(B, obs, idx, filt, head, save=True)
+        rows = (B + 255) // 256
+        means = torch.empty(8, dtype=torch.float32, device=mlp.device)
+        _lib.check(mlp.lib.pnr_ppo_loss(B, _p(idx), _p(head[0]), _p(head[1]), _p(rec["actions"]), _p(rec["logp"]), _p(rec["mean"]),
+                                        _p(rec["log_std"]), _p(rec["adv"]), _p(rec["vtarg"]), _p(rec["values"]), _p(kl_c),
+                                        _p(ent_c), C.c_float(clip), C.c_float(vf_clip), C.c_float(vf_coeff), _p(g[0]), _p(g[1]),
+                                        _p(ws["partials"]), rows, _p(means), mlp._stream()))
+        ctx.mlp, ctx.B = mlp, B
+        return means
+
+    @staticmethod
+    def backward(ctx, g_means):
+        mlp, B = ctx.mlp, ctx.B
+        ws = mlp._workspace()
+        g_means = g_means.contiguous()
+        assert g_means.dtype == torch.float32 and g_means.numel() == 8
+        grads = [torch.empty_like(p) for p in mlp.params]
+        scale = C.c_void_p(g_means.data_ptr() + 4 * 4)            # d / d means[4]: the total loss
+        _lib.check(mlp.lib.pnr_mlp_backward(B, _p(ws["g"]), _p(mlp.wpack), _p(ws["xs"]), _p(ws["h1"]), _p(ws["h2"]), _p(ws["dz1"]),
+                                            _p(ws["dz2"]), _p(ws["slabs"]), ws["slabs"].numel(), mlp._ptrs(grads),
+                                            mlp.n3[0], mlp.n3[1], 0, scale, mlp._stream()))
+        return (None,) * 10 + tuple(grads)
+
+
 class _FusedMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mlp: HipMLP, obs, idx, filt, *params):
@@ -141,5 +192,5 @@ class _FusedMLP(torch.autograd.Function):
         grads = [torch.empty_like(p) for p in mlp.params]
         _lib.check(mlp.lib.pnr_mlp_backward(B, _p(g), _p(mlp.wpack), _p(ws["xs"]), _p(ws["h1"]), _p(ws["h2"]), _p(ws["dz1"]),
                                             _p(ws["dz2"]), _p(ws["slabs"]), ws["slabs"].numel(), mlp._ptrs(grads),
-                                            mlp.n3[0], mlp.n3[1], 0, mlp._stream()))
+                                            mlp.n3[0], mlp.n3[1], 0, None, mlp._stream()))
         return (None, None, None, None, *grads)

@@ -386,12 +386,12 @@ class FusedPPOLoss(torch.autograd.Function):
         g_p, g_v = torch.empty_like(head_p), torch.empty_like(head_v)
         rows = (B + 255) // 256
         partials = torch.empty((rows, 8), dtype=torch.float32, device=head_p.device)
+        means = torch.empty(8, dtype=torch.float32, device=head_p.device)   # policy_loss, vf_loss, kl, entropy, total
         P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
-        _lib.check(lib.pnr_ppo_loss(B, P(head_p), P(head_v), P(t["actions"]), P(t["logp"]), P(t["mean"]), P(t["log_std"]),
+        _lib.check(lib.pnr_ppo_loss(B, None, P(head_p), P(head_v), P(t["actions"]), P(t["logp"]), P(t["mean"]), P(t["log_std"]),
                                     P(t["adv"]), P(t["vtarg"]), P(t["values"]), P(kl_c), P(ent_c),
                                     C.c_float(clip), C.c_float(vf_clip), C.c_float(vf_coeff), P(g_p), P(g_v), P(partials),
-                                    rows, C.c_void_p(torch.cuda.current_stream(head_p.device).cuda_stream)))
-        means = partials.sum(0) / B          # policy_loss, vf_loss, kl, entropy, total
+                                    rows, P(means), C.c_void_p(torch.cuda.current_stream(head_p.device).cuda_stream)))
         ctx.save_for_backward(g_p, g_v)
         ctx.mark_non_differentiable(means)
         return means[4].clone(), means
@@ -525,6 +525,12 @@ class PPOLearner:
         self._static_info = None
         self._eager_updates = 0
         self.fused_loss = self.device.type == "cuda" and cfg.act_dim == 6   # pnr_ppo_loss; torch ops otherwise (CPU)
+        # the hand-written MLP kernels (csrc/pnr_mlp.h) carry the whole differentiable part of an update when the nets are
+        # the reference's (137-256-256, pioneer_knm_train.py:59-61) and bf16 GEMMs were asked for; float32 runs stay on torch
+        self.hip = (self.fused_loss and bool(cfg.amp_bf16) and cfg.obs_dim == 137 and tuple(cfg.fcnet_hiddens) == (256, 256))
+        self._mlp = None            # HipMLP with a workspace for one minibatch
+        self._own = None            # pointer-stable copies of the update's batch (HIP path)
+        self._idx = None            # static minibatch row indices
 
     def drop_graphs(self) -> None:
         """Forget the captured minibatch update (it is re-captured after the eager warm-up updates)."""
@@ -541,6 +547,19 @@ class PPOLearner:
 
     def loss(self, mb: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         cfg = self.cfg
+        if self.hip and mb["obs"].is_cuda:
+            idx = mb.get("idx")
+            B = int(idx.numel()) if idx is not None else int(mb["obs"].shape[0])
+            if self._mlp is None or self._mlp.max_batch < B:
+                from .mlp import HipMLP
+                self._mlp = HipMLP(self.model, B, self.device)
+            m = self._mlp.policy_loss(mb["obs"], idx, mb.get("filt"), mb, self._kl_c, self._ent_c, cfg.clip_param,
+                                      cfg.vf_clip_param, cfg.vf_loss_coeff)
+            # the reported means are DETACHED views: kept across minibatches (agg, _static_info) they must not keep the
+            # autograd graph alive — its AccumulateGrad nodes would remember the stream of an earlier eager update, and
+            # replaying them under capture on the capture stream tied the two streams together (segfault at capture_end)
+            d = m.detach()
+            return m[4], {"policy_loss": d[0], "vf_loss": d[1], "kl": d[2], "entropy": d[3], "total_loss": d[4]}
         if self.fused_loss and mb["obs"].is_cuda:
             hp, hv = self.model.forward_heads(mb["obs"], cfg.amp_bf16)
             total, m = FusedPPOLoss.apply(hp, hv, mb, self._kl_c, self._ent_c, float(cfg.clip_param),
@@ -572,11 +591,28 @@ class PPOLearner:
         pdist.allreduce_sum_(stats)
         mu = stats[0] / stats[2]
         sd = torch.sqrt(torch.clamp(stats[1] / stats[2] - mu * mu, min=1e-12))
-        batch = dict(batch, adv=((adv - mu.float()) / (sd.float() + 1e-8)))
+        adv_n = (adv - mu.float()) / (sd.float() + 1e-8)
         self._kl_c.fill_(self.kl_coeff)
         self._ent_c.fill_(self.entropy_coeff())
         agg: Dict[str, torch.Tensor] = {}
         nmb = 0
+        filt = batch.get("filt")
+        tens = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        tens["adv"] = adv_n
+        hip = self.hip and adv.is_cuda
+        if hip:
+            # HIP path: the kernels gather minibatch rows themselves (idx), so the batch is kept whole in buffers this
+            # learner owns — their addresses are what a captured update replays on
+            if self._own is None or any(self._own[k].shape != v.shape for k, v in tens.items()):
+                self.drop_graphs()
+                self._own = {k: torch.empty_like(v, memory_format=torch.contiguous_format) for k, v in tens.items()}
+                self._idx = torch.empty(mbs, dtype=torch.int64, device=adv.device)
+            for k, v in tens.items():
+                self._own[k].copy_(v)
+            if self._idx.numel() != mbs:
+                self.drop_graphs()
+                self._idx = torch.empty(mbs, dtype=torch.int64, device=adv.device)
+            full = dict(self._own, idx=self._idx, filt=filt)
 
         def eager_step(mb):
             loss, info = self.loss(mb)
@@ -588,23 +624,26 @@ class PPOLearner:
             self.opt.step()
             return info
 
-        graph_ok = self.use_graph and (self._static is None or self._static["obs"].shape[0] == mbs)
+        graph_ok = self.use_graph and (self._static is None or self._static["obs"].shape[0] == (B if hip else mbs))
         for _ in range(cfg.num_sgd_iter):
             perm = torch.randperm(B, device=adv.device, generator=generator)
             for s in range(0, B - mbs + 1, mbs):
                 idx = perm[s:s + mbs]
+                if hip:
+                    self._idx.copy_(idx)
                 if graph_ok and self._graph is None and self._eager_updates >= 3:
-                    self._capture(batch, idx)                       # after a few eager updates (warm-up)
+                    self._capture(full if hip else tens, idx)       # after a few eager updates (warm-up)
                 if graph_ok and self._graph is not None:
-                    for k, v in batch.items():
-                        torch.index_select(v, 0, idx, out=self._static[k])
+                    if not hip:
+                        for k, v in tens.items():
+                            torch.index_select(v, 0, idx, out=self._static[k])
                     self._graph.replay()
                     if self._split:
                         pdist.allreduce_mean_(self._flat_grad)      # the one 0.82 MB bucket, eager
                         self._graph_b.replay()
                     info = self._static_info
                 else:
-                    info = eager_step({k: v[idx] for k, v in batch.items()})
+                    info = eager_step(full if hip else {k: v[idx] for k, v in tens.items()})
                     self._eager_updates += 1
                 for k, v in info.items():
                     agg[k] = agg.get(k, 0) + v
@@ -628,7 +667,10 @@ def _learner_capture(self, batch, idx):
     """Capture one minibatch update on static buffers: one hipGraph (single rank) or two with the
     gradient all-reduce between them (several ranks).  The capture pass only records work."""
     try:
-        self._static = {k: v[idx].clone() for k, v in batch.items()}
+        if self.hip and "idx" in batch:
+            self._static = batch                     # the learner's own whole-batch buffers + the static index vector
+        else:
+            self._static = {k: v[idx].clone() for k, v in batch.items()}
         torch.cuda.synchronize(self.device)
         if not self._split:
             self.opt.zero_grad(set_to_none=True)
@@ -665,9 +707,11 @@ PPOLearner._capture = _learner_capture
 class PPOTrainer:
     """Rollout + learn loop over a PioneerVectorEnv shard (one process per GPU).
 
-    ``use_graph=True`` captures the whole T-step sampling loop (obs filter, policy forward, action
-    sampling, ``pnr_step``, episode statistics, GAE) into ONE hipGraph after an eager warm-up
-    iteration: the loop is launch-bound (~60 small kernels around a 5 us env kernel per step)."""
+    ``use_graph=True`` captures the whole T-step sampling loop (policy forward, action sampling, ``pnr_step``,
+    log-probs, GAE) into ONE hipGraph after an eager warm-up iteration.  With the reference's nets and bf16 GEMMs
+    (``PPOLearner.hip``) the nets run on the hand-written MFMA kernels: one launch per step computes both heads from
+    the RAW observation the env kernel left in the rollout buffer (the MeanStdFilter is applied on load), and the
+    learner reads the same raw buffer through a row index — filtered observations are never materialised."""
 
     def __init__(self, env, cfg: Optional[PPOConfig] = None, use_graph: bool = False):
         self.env = env
@@ -675,6 +719,7 @@ class PPOTrainer:
         self.device = env.device
         self.rank, _, self.world = pdist.world_info()
         self.learner = PPOLearner(self.cfg, self.device, use_graph=use_graph)
+        self.hip = self.learner.hip
         self.filter = (MeanStdFilter(self.cfg.obs_dim, self.device, self.cfg.filter_clip)
                        if self.cfg.observation_filter in ("MeanStdFilter", "ConcurrentMeanStdFilter") else NoFilter())
         self.stats = EpisodeStats(env.num_envs, self.device)
@@ -685,17 +730,18 @@ class PPOTrainer:
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._graph = None
         self._xin = None
-        self._xlast = torch.empty((env.num_envs, self.cfg.obs_dim), dtype=torch.float32, device=self.device)
-        self._env_act = torch.empty((env.num_envs, self.cfg.act_dim), dtype=torch.float32, device=self.device)
-        T, N = self.cfg.rollout_fragment_length, env.num_envs
+        T, N, D, A = self.cfg.rollout_fragment_length, env.num_envs, self.cfg.obs_dim, self.cfg.act_dim
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.raw_obs = torch.empty((N, self.cfg.obs_dim), **f32)       # static: the obs the next rollout starts from
-        self.raw_obs.copy_(env.reset())
+        self._xlast = torch.empty((N, D), **f32)
+        self._env_act = torch.empty((N, A), **f32)
+        # raw observations: slot 0 = what the rollout starts from, slot t + 1 = written in place by pnr_step at step t;
+        # the nets' inputs of a rollout are slots 0 .. T-1, slot T carries over to the next rollout's slot 0
+        self.raw_in = torch.empty((T + 1, N, D), **f32)
+        self.raw_in[T].copy_(env.reset())
         self.buf = {
-            "raw_obs": torch.empty((T, N, self.cfg.obs_dim), **f32),   # written in place by pnr_step
-            "obs": torch.empty((T, N, self.cfg.obs_dim), **f32),       # filtered, what the nets saw
-            "actions": torch.empty((T, N, self.cfg.act_dim), **f32),
-            "head": torch.empty((T, N, 2 * self.cfg.act_dim), **f32),  # policy head: means | clamped log-stds
+            "raw_obs": self.raw_in[1:],
+            "actions": torch.empty((T, N, A), **f32),
+            "mean": torch.empty((T, N, A), **f32), "log_std": torch.empty((T, N, A), **f32),   # the policy head, clamped log-stds
             "logp": torch.empty((T, N), **f32), "values": torch.empty((T, N), **f32),
             "reward": torch.empty((T, N), **f32),
             "adv": torch.empty((T, N), **f32), "vtarg": torch.empty((T, N), **f32),
@@ -704,50 +750,83 @@ class PPOTrainer:
             "term_u8": torch.empty((T, N), dtype=torch.uint8, device=self.device),
             "terminals": torch.empty((T, N), **f32),                   # done | truncated as 0 / 1
         }
-        self._raw_prev = torch.empty((N, self.cfg.obs_dim), **f32)
+        if self.hip:
+            from .mlp import HipMLP
+            self.sample_mlp = HipMLP(self.learner.model, N, self.device)   # packed weights for the rollout's T forwards
+            self.buf["heads"] = torch.empty((T, 2, N, 16), **f32)      # raw head rows of both nets
+            self._last_heads = torch.empty((2, N, 16), **f32)
+        else:
+            self.buf["obs"] = torch.empty((T, N, D), **f32)            # filtered, what the nets saw
+
+    @property
+    def raw_obs(self) -> torch.Tensor:
+        """The observation the next rollout starts from."""
+        return self.raw_in[self.cfg.rollout_fragment_length]
+
+    def _filt(self):
+        f = self.filter
+        return (f._loc, f._inv, f._lo, f._hi) if isinstance(f, MeanStdFilter) else None
+
+    def _noise(self):
+        shape = tuple(self.buf["actions"].shape)
+        # in-graph noise comes from the default (graph-safe) generator
+        return torch.randn(shape, device=self.device) if self._capturing else torch.randn(shape, generator=self.gen, device=self.device)
+
+    def _finish_rollout(self, last_v: torch.Tensor) -> None:
+        cfg, buf = self.cfg, self.buf
+        buf["logp"].copy_(gaussian_logp(buf["actions"], buf["mean"], buf["log_std"]))
+        torch.bitwise_or(buf["done"], buf["trunc"], out=buf["term_u8"])
+        buf["terminals"].copy_(buf["term_u8"])
+        adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, buf["terminals"], cfg.gamma, cfg.lambda_)
+        buf["adv"].copy_(adv); buf["vtarg"].copy_(vtarg)
+
+    def _env_step(self, t: int, act: torch.Tensor) -> None:
+        buf = self.buf
+        env_act = torch.clamp(act, self._a_lo, self.a_max, out=self._env_act) if self.cfg.clip_actions else act
+        self.env.vector_step(env_act, out={"obs": self.raw_in[t + 1], "reward": buf["reward"][t], "done": buf["done"][t],
+                                           "truncated": buf["trunc"][t]})
 
     @torch.no_grad()
     def _collect_impl(self) -> None:
-        """T steps into the static buffers; pure device work (capturable).  Per step only what the next
-        step needs (filter, nets on cached weights, action draw, pnr_step: ~25 kernels); log-probs and GAE are
-        computed once, after the loop, from the [T, N] buffers; episode statistics and filter moments in
-        _collect_tail(), outside any capture."""
+        """T steps into the static buffers; pure device work (capturable).  Log-probs and GAE are computed once, after
+        the loop, from the [T, N] buffers; episode statistics and filter moments in _collect_tail(), outside any
+        capture."""
         cfg, buf, model = self.cfg, self.buf, self.learner.model
         T, A = cfg.rollout_fragment_length, cfg.act_dim
-        raw = self.raw_obs
-        model.refresh_inference_cache(cfg.amp_bf16)
+        self.raw_in[0].copy_(self.raw_in[T])
         self.filter.prepare()
+        noise = self._noise()
+        if self.hip:
+            # per step: ONE launch for both nets on the raw observation (filter applied on load), the action draw, pnr_step
+            mlp, filt = self.sample_mlp, self._filt()
+            mlp.pack()
+            for t in range(T):
+                heads = mlp.forward_nograd(self.raw_in[t], None, filt, out=buf["heads"][t])
+                buf["mean"][t].copy_(heads[0, :, :A])
+                log_std = torch.clamp(heads[0, :, A:2 * A], -20.0, 2.0, out=buf["log_std"][t])
+                buf["values"][t].copy_(heads[1, :, 0])
+                act = torch.addcmul(buf["mean"][t], torch.exp(log_std), noise[t], out=buf["actions"][t])
+                self._env_step(t, act)
+            last = mlp.forward_nograd(self.raw_in[T], None, filt, out=self._last_heads)
+            self._finish_rollout(last[1, :, 0])          # bootstrap value of the state after the last step
+            return
+        model.refresh_inference_cache(cfg.amp_bf16)
         cdt = model._icache["dtype"]
         if self._xin is None or self._xin.dtype != cdt:
-            self._xin = torch.zeros((raw.shape[0], cfg.obs_dim + (-cfg.obs_dim) % 16), dtype=cdt, device=self.device)
+            self._xin = torch.zeros((self.raw_in.shape[1], cfg.obs_dim + (-cfg.obs_dim) % 16), dtype=cdt, device=self.device)
         xin = self._xin
-        noise = (torch.randn((T,) + tuple(buf["actions"].shape[1:]), device=self.device) if self._capturing
-                 else torch.randn((T,) + tuple(buf["actions"].shape[1:]), generator=self.gen, device=self.device))
         for t in range(T):
             x = buf["obs"][t]
-            self.filter.apply_(raw, out=x)
+            self.filter.apply_(self.raw_in[t], out=x)
             xin[:, :cfg.obs_dim].copy_(x)
             head, v = model.forward_cached(xin)
-            buf["head"][t].copy_(head)
+            buf["mean"][t].copy_(head[:, :A])
+            log_std = torch.clamp(head[:, A:], -20.0, 2.0, out=buf["log_std"][t])
             buf["values"][t].copy_(v.squeeze(-1))
-            mean, log_std = buf["head"][t][:, :A], buf["head"][t][:, A:]
-            log_std.clamp_(-20.0, 2.0)
-            act = torch.addcmul(mean, torch.exp(log_std), noise[t], out=buf["actions"][t])
-            env_act = torch.clamp(act, self._a_lo, self.a_max, out=self._env_act) if cfg.clip_actions else act
-            out = {"obs": buf["raw_obs"][t], "reward": buf["reward"][t], "done": buf["done"][t], "truncated": buf["trunc"][t]}
-            self.env.vector_step(env_act, out=out)
-            raw = buf["raw_obs"][t]
-        mean, log_std = buf["head"][..., :A], buf["head"][..., A:]
-        buf["logp"].copy_(gaussian_logp(buf["actions"], mean, log_std))
-        terminals = buf["terminals"]
-        torch.bitwise_or(buf["done"], buf["trunc"], out=buf["term_u8"])
-        terminals.copy_(buf["term_u8"])
-        self._raw_prev.copy_(self.raw_obs)                                 # what the eager tail's filter.observe() reads
-        self.raw_obs.copy_(raw)
-        xin[:, :cfg.obs_dim].copy_(self.filter.apply_(raw, out=self._xlast))
-        last_v = model.forward_cached(xin)[1].squeeze(-1).float()      # bootstrap value of the state after the last step
-        adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, terminals, cfg.gamma, cfg.lambda_)
-        buf["adv"].copy_(adv); buf["vtarg"].copy_(vtarg)
+            act = torch.addcmul(buf["mean"][t], torch.exp(log_std), noise[t], out=buf["actions"][t])
+            self._env_step(t, act)
+        xin[:, :cfg.obs_dim].copy_(self.filter.apply_(self.raw_in[T], out=self._xlast))
+        self._finish_rollout(model.forward_cached(xin)[1].squeeze(-1).float())
 
     def _collect_tail(self) -> None:
         """The rollout's bookkeeping reductions — episode statistics and the filter's moments — run EAGERLY after
@@ -761,9 +840,7 @@ class PPOTrainer:
         identical to observing them one by one inside the loop."""
         buf, T = self.buf, self.cfg.rollout_fragment_length
         self.stats.rollout(buf["reward"], buf["terminals"])
-        self.filter.observe(self._raw_prev)
-        if T > 1:
-            self.filter.observe(buf["raw_obs"][:T - 1])
+        self.filter.observe(self.raw_in[:T])
 
     _capturing = False
 
@@ -783,12 +860,15 @@ class PPOTrainer:
         else:
             self._collect_impl()
         self._collect_tail()
-        buf = self.buf
+        buf, T = self.buf, self.cfg.rollout_fragment_length
         flat = lambda x: x.reshape(-1, *x.shape[2:])  # noqa: E731
-        A = self.cfg.act_dim
-        return {"obs": flat(buf["obs"]), "actions": flat(buf["actions"]), "mean": flat(buf["head"][..., :A]),
-                "log_std": flat(buf["head"][..., A:]), "logp": flat(buf["logp"]), "values": flat(buf["values"]),
-                "adv": flat(buf["adv"]), "vtarg": flat(buf["vtarg"])}
+        batch = {"actions": flat(buf["actions"]), "mean": flat(buf["mean"]), "log_std": flat(buf["log_std"]),
+                 "logp": flat(buf["logp"]), "values": flat(buf["values"]), "adv": flat(buf["adv"]), "vtarg": flat(buf["vtarg"])}
+        if self.hip:
+            batch.update(obs=flat(self.raw_in[:T]), filt=self._filt())      # raw: the kernels filter on load
+        else:
+            batch["obs"] = flat(buf["obs"])
+        return batch
 
     def train(self) -> Dict[str, float]:
         t0 = time.perf_counter()
