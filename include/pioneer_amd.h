@@ -256,6 +256,39 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
                      void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
                      int32_t n3_value, int32_t accumulate, const float* scale, void* stream);
 
+/*
+ * One PPO minibatch update of both nets in seven launches, nothing of it on the host: fused forward (activations
+ * saved), the loss kernel and its finishing sum (which also counts the update in *adam_step), backward-data, weight
+ * gradients per batch slice, then EITHER the fused slab-reduction + Adam + bf16 repacking (flat_grad == NULL) OR the
+ * reduction into flat_grad [pnr_mlp_grad_floats()] with no update: a multi-GPU run all-reduces that bucket and calls
+ * PLACEHOLDER
+ * config, pioneer_knm_train.py:64; betas 0.9 / 0.999, eps 1e-8; no weight decay) with its state m, v kept as
+ * [pnr_mlp_grad_floats()] floats each.  wpack / bias must hold the CURRENT weights on entry (pnr_mlp_pack once, then
+ * every update refreshes them).  All pointers are device pointers; `means` receives (policy_loss, vf_loss, kl,
+ * entropy, total, 0, 0, 0).
+ */
+typedef struct pnr_mlp_step {
+    uint32_t struct_size;   /* sizeof(pnr_mlp_step) */
+    int64_t batch;
+    const float* obs; const int64_t* idx;
+    const float* f_loc; const float* f_inv; const float* f_lo; const float* f_hi;
+    const float* actions; const float* logp_old; const float* mean_old; const float* log_std_old;
+    const float* adv; const float* value_target; const float* value_old;
+    const float* kl_coeff; const float* entropy_coeff;
+    float clip_param, vf_clip_param, vf_loss_coeff;
+    float* params[12]; int32_t n3_policy, n3_value;
+    void* wpack; float* bias;
+    float* adam_m; float* adam_v; float* adam_step;
+    float lr, beta1, beta2, eps;
+    float* head; float* g_head; void* xs; void* h1; void* h2; void* dz1; void* dz2;
+    float* partials; int64_t partial_rows; float* slabs; int64_t slab_floats;
+    float* means;
+    float* flat_grad;
+} pnr_mlp_step;
+int64_t pnr_mlp_grad_floats(void);
+int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream);
+int pnr_mlp_adam(const pnr_mlp_step* s, const float* flat_grad, float grad_scale, void* stream);
+
 int64_t pnr_num_envs(pnr_handle h);
 
 /* Last error message of `h`, or of the calling thread when h == NULL. */

@@ -62,6 +62,27 @@ class PnrConstants(C.Structure):
     ]
 
 
+class PnrMlpStep(C.Structure):
+    """pnr_mlp_step of include/pioneer_amd.h (one PPO minibatch update, pnr_mlp_train_step)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("batch", C.c_int64),
+        ("obs", C.c_void_p), ("idx", C.c_void_p),
+        ("f_loc", C.c_void_p), ("f_inv", C.c_void_p), ("f_lo", C.c_void_p), ("f_hi", C.c_void_p),
+        ("actions", C.c_void_p), ("logp_old", C.c_void_p), ("mean_old", C.c_void_p), ("log_std_old", C.c_void_p),
+        ("adv", C.c_void_p), ("value_target", C.c_void_p), ("value_old", C.c_void_p),
+        ("kl_coeff", C.c_void_p), ("entropy_coeff", C.c_void_p),
+        ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float),
+        ("params", C.c_void_p * 12), ("n3_policy", C.c_int32), ("n3_value", C.c_int32),
+        ("wpack", C.c_void_p), ("bias", C.c_void_p),
+        ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_step", C.c_void_p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("head", C.c_void_p), ("g_head", C.c_void_p), ("xs", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p),
+        ("dz1", C.c_void_p), ("dz2", C.c_void_p),
+        ("partials", C.c_void_p), ("partial_rows", C.c_int64), ("slabs", C.c_void_p), ("slab_floats", C.c_int64),
+        ("means", C.c_void_p), ("flat_grad", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); the list tests check against include/pioneer_amd.h
 _VP = C.c_void_p
 SIGNATURES = {
@@ -87,6 +108,9 @@ SIGNATURES = {
     "pnr_mlp_pack": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     "pnr_mlp_forward": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_int32, C.c_int32, _VP]),
     "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
+    "pnr_mlp_grad_floats": (C.c_int64, []),
+    "pnr_mlp_train_step": (C.c_int, [C.POINTER(PnrMlpStep), _VP]),
+    "pnr_mlp_adam": (C.c_int, [C.POINTER(PnrMlpStep), _VP, C.c_float, _VP]),
     "pnr_num_envs": (C.c_int64, [_VP]),
     "pnr_last_error": (C.c_char_p, [_VP]),
 }

@@ -1108,7 +1108,7 @@ int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, co
     hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)blocks), dim3(kPpoBlock), 0, (hipStream_t)stream, P);
     if (means)
         hipLaunchKernelGGL(ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_sums, (long long)blocks,
-                           (long long)batch, means);
+                           (long long)batch, means, (float*)nullptr);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }
@@ -1204,6 +1204,100 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     }
     Rp.n3[0] = n3_policy; Rp.n3[1] = n3_value;
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((kGradElems + 255) / 256, kMlpNets), dim3(256), 0, st, Rp);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int64_t pnr_mlp_grad_floats(void) { return (int64_t)kMlpNets * kGradElems; }
+
+static int mlp_step_check(const pnr_mlp_step* s, const char* who)
+{
+    if (!s) return fail(nullptr, PNR_ERR_INVALID, "%s: null argument block", who);
+    if (s->struct_size != sizeof(pnr_mlp_step))
+        return fail(nullptr, PNR_ERR_INVALID, "%s: pnr_mlp_step size mismatch (got %u, want %zu)", who, s->struct_size, sizeof(pnr_mlp_step));
+    for (int k = 0; k < 12; ++k)
+        if (!s->params[k]) return fail(nullptr, PNR_ERR_INVALID, "%s: null parameter %d", who, k);
+    if (!s->wpack || !s->bias || !s->adam_m || !s->adam_v || !s->adam_step)
+        return fail(nullptr, PNR_ERR_INVALID, "%s: null weight / optimiser buffer", who);
+    if (s->n3_policy < 1 || s->n3_policy > kMlpHead || s->n3_value < 1 || s->n3_value > kMlpHead)
+        return fail(nullptr, PNR_ERR_INVALID, "%s: head widths must be in 1..16", who);
+    return PNR_OK;
+}
+
+static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices, float scale, hipStream_t st)
+{
+    MlpAdamParams A;
+    A.grad = grad; A.slices = slices; A.grad_scale = scale;
+    for (int n = 0; n < kMlpNets; ++n) {
+        A.w1[n] = s->params[6 * n + 0]; A.b1[n] = s->params[6 * n + 1]; A.w2[n] = s->params[6 * n + 2];
+        A.b2[n] = s->params[6 * n + 3]; A.w3[n] = s->params[6 * n + 4]; A.b3[n] = s->params[6 * n + 5];
+    }
+    A.n3[0] = s->n3_policy; A.n3[1] = s->n3_value;
+    A.m = s->adam_m; A.v = s->adam_v; A.step = s->adam_step;
+    A.lr = s->lr; A.beta1 = s->beta1; A.beta2 = s->beta2; A.eps = s->eps;
+    A.wpack = static_cast<__bf16*>(s->wpack); A.bias = s->bias;
+    hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256, kMlpNets), dim3(256), 0, st, A);
+}
+
+int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
+{
+    int rc = mlp_step_check(s, "pnr_mlp_train_step");
+    if (rc) return rc;
+    const long long B = s->batch;
+    if (B < 1 || !s->obs || !s->actions || !s->logp_old || !s->mean_old || !s->log_std_old || !s->adv || !s->value_target ||
+        !s->value_old || !s->kl_coeff || !s->entropy_coeff || !s->head || !s->g_head || !s->xs || !s->h1 || !s->h2 || !s->dz1 ||
+        !s->dz2 || !s->partials || !s->slabs || !s->means)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: null argument or empty batch");
+    if ((s->f_loc || s->f_inv || s->f_lo || s->f_hi) && !(s->f_loc && s->f_inv && s->f_lo && s->f_hi))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: the four filter vectors come together or not at all");
+    long long slices, rows;
+    mlp_slicing(B, &slices, &rows);
+    if (s->slab_floats < slices * kMlpNets * kGradElems)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: slabs hold %lld floats, the launch needs %lld",
+                    (long long)s->slab_floats, slices * kMlpNets * kGradElems);
+    const long long blocks = (B + kPpoBlock - 1) / kPpoBlock;
+    if (s->partial_rows < blocks) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: partials too small");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), kMlpNets), thr(kMlpThreads);
+
+    MlpFwdParams F;
+    F.obs = s->obs; F.idx = reinterpret_cast<const long long*>(s->idx); F.f_loc = s->f_loc; F.f_inv = s->f_inv; F.f_lo = s->f_lo; F.f_hi = s->f_hi;
+    F.wpack = static_cast<const __bf16*>(s->wpack); F.bias = s->bias; F.head = s->head;
+    F.xs = static_cast<__bf16*>(s->xs); F.h1 = static_cast<__bf16*>(s->h1); F.h2 = static_cast<__bf16*>(s->h2);
+    F.B = B; F.first_net = 0; F.n_nets = kMlpNets;
+    hipLaunchKernelGGL(mlp_forward_kernel, tiles, thr, 0, st, F);
+
+    PpoLossParams L;
+    L.head_p = s->head; L.head_v = s->head + (size_t)B * kMlpHead; L.actions = s->actions; L.logp_old = s->logp_old;
+    L.mean_old = s->mean_old; L.ls_old = s->log_std_old; L.adv = s->adv; L.vtarg = s->value_target; L.v_old = s->value_old;
+    L.idx = F.idx; L.kl_coeff = s->kl_coeff; L.ent_coeff = s->entropy_coeff;
+    L.g_head_p = s->g_head; L.g_head_v = s->g_head + (size_t)B * kMlpHead; L.partials = s->partials;
+    L.B = B; L.clip = s->clip_param; L.vf_clip = s->vf_clip_param; L.vf_coeff = s->vf_loss_coeff;
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)blocks), dim3(kPpoBlock), 0, st, L);
+    hipLaunchKernelGGL(ppo_loss_finish_kernel, dim3(1), dim3(64), 0, st, s->partials, blocks, B, s->means, s->adam_step);
+
+    MlpBwdParams Bp;
+    Bp.g_head = s->g_head; Bp.wpack = F.wpack; Bp.h1 = F.h1; Bp.h2 = F.h2;
+    Bp.dz1 = static_cast<__bf16*>(s->dz1); Bp.dz2 = static_cast<__bf16*>(s->dz2); Bp.B = B;
+    hipLaunchKernelGGL(mlp_backward_data_kernel, tiles, thr, 0, st, Bp);
+    MlpWgradParams Wp;
+    Wp.g_head = s->g_head; Wp.xs = F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
+    Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows;
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, 4, kMlpNets), thr, 0, st, Wp);
+    if (s->flat_grad)
+        hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((kMlpNets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad);
+    else
+        mlp_launch_adam(s, s->slabs, (int)slices, 1.0f, st);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_mlp_adam(const pnr_mlp_step* s, const float* flat_grad, float grad_scale, void* stream)
+{
+    int rc = mlp_step_check(s, "pnr_mlp_adam");
+    if (rc) return rc;
+    if (!flat_grad) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_adam: null gradient");
+    mlp_launch_adam(s, flat_grad, 1, grad_scale, (hipStream_t)stream);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }

@@ -639,4 +639,80 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const MlpReduceParams P
     *dst = P.accumulate ? (*dst + s) : s;
 }
 
+// slabs -> one flat gradient [2][kGradElems] (the bucket a multi-GPU run all-reduces), summed in slice order
+__global__ __launch_bounds__(256) void mlp_reduce_flat_kernel(const float* __restrict__ slabs, int slices, float* __restrict__ flat)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kMlpNets * kGradElems) return;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * kMlpNets * kGradElems + i];
+    flat[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam on the float32 master parameters, fused with the slab reduction in front of it and with the bf16 weight
+// packing behind it: one launch turns per-slice partial gradients into the next forward's operands.  torch.optim.Adam
+// semantics (no weight decay, no amsgrad): m += (g - m)(1 - b1); v = b2 v + (1 - b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = *step (incremented once per update by the loss
+// kernel's finishing launch).  State m, v live in the padded slab layout [2][kGradElems].
+// ---------------------------------------------------------------------------------------------------------------
+struct MlpAdamParams {
+    const float* grad;         // slices x [2][kGradElems] partial gradients (slabs), or one flat all-reduced gradient
+    int slices;                // 1 for a flat gradient
+    float grad_scale;          // e.g. 1 / world size after a summing all-reduce
+    float* w1[kMlpNets]; float* b1[kMlpNets];      // master parameters (the caller's tensors)
+    float* w2[kMlpNets]; float* b2[kMlpNets];
+    float* w3[kMlpNets]; float* b3[kMlpNets];
+    int n3[kMlpNets];
+    float* m; float* v;        // [2][kGradElems]
+    const float* step;         // device scalar: number of updates including this one
+    float lr, beta1, beta2, eps;
+    __bf16* wpack;             // [2][kPackElems]: refreshed in place
+    float* bias;               // [2][kBiasElems]
+};
+
+__global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
+{
+    const int net = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kGradElems) return;
+    float* dst = nullptr;
+    int wp0 = -1, wp1 = -1, bp = -1;               // where the bf16 / bias copies of this element go
+    if (e < kGW2) {
+        const int o = e / kMlpInPad, k = e % kMlpInPad;
+        wp0 = kOffW1 + e;
+        if (k < kMlpIn) dst = P.w1[net] + o * kMlpIn + k;
+    } else if (e < kGW3) {
+        const int r = e - kGW2, o = r / kMlpHid, i = r % kMlpHid;
+        dst = P.w2[net] + r; wp0 = kOffW2 + r; wp1 = kOffW2T + i * kMlpHid + o;
+    } else if (e < kGB1) {
+        const int r = e - kGW3, row = r / kMlpHid, f = r % kMlpHid;
+        wp0 = kOffW3 + r; wp1 = kOffW3T + f * kMlpHead + row;
+        if (row < P.n3[net]) dst = P.w3[net] + r;
+    } else if (e < kGB2) { dst = P.b1[net] + (e - kGB1); bp = e - kGB1; }
+    else if (e < kGB3) { dst = P.b2[net] + (e - kGB2); bp = kMlpHid + (e - kGB2); }
+    else { bp = 2 * kMlpHid + (e - kGB3); if (e - kGB3 < P.n3[net]) dst = P.b3[net] + (e - kGB3); }
+
+    float pv = 0.f;
+    if (dst) {
+        float g = 0.f;
+        const float* gp = P.grad + (size_t)net * kGradElems + e;
+        for (int k = 0; k < P.slices; ++k) g += gp[(size_t)k * kMlpNets * kGradElems];
+        g *= P.grad_scale;
+        const size_t si = (size_t)net * kGradElems + e;
+        const float t = *P.step;
+        float m = P.m[si], v = P.v[si];
+        m = m + (g - m) * (1.0f - P.beta1);
+        v = P.beta2 * v + (1.0f - P.beta2) * g * g;
+        const float bc1 = 1.0f - powf(P.beta1, t), bc2 = 1.0f - powf(P.beta2, t);
+        const float denom = sqrtf(v) / sqrtf(bc2) + P.eps;
+        pv = *dst - (P.lr / bc1) * (m / denom);
+        P.m[si] = m; P.v[si] = v; *dst = pv;
+    }
+    __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    if (wp0 >= 0) wp[wp0] = (__bf16)pv;
+    if (wp1 >= 0) wp[wp1] = (__bf16)pv;
+    if (bp >= 0) P.bias[net * kBiasElems + bp] = pv;
+}
+
 }  // namespace pnr

@@ -139,8 +139,9 @@ __global__ __launch_bounds__(kPpoBlock) void ppo_loss_kernel(const PpoLossParams
 // Sum the per-block partial rows in row order (one block, deterministic) and divide by the batch: the five reported
 // means.  A separate tiny launch instead of a last-block-done atomic: nothing here needs zeroed counters.
 __global__ __launch_bounds__(64) void ppo_loss_finish_kernel(const float* __restrict__ partials, long long rows, long long B,
-                                                             float* __restrict__ means)
+                                                             float* __restrict__ means, float* __restrict__ step_counter)
 {
+    if (step_counter && threadIdx.x == 0) *step_counter += 1.0f;    // the optimiser's update count (single block)
     const int k = threadIdx.x & 7, part = threadIdx.x >> 3;       // 8 lanes per sum slot walk the rows 8 apart
     float s = 0.f;
     for (long long r = part; r < rows; r += 8) s += partials[r * kPpoSums + k];

@@ -122,6 +122,66 @@ class HipMLP:
         return out[0], out[1]
 
 
+    # -- the learner path without autograd: one PPO minibatch update = pnr_mlp_train_step (seven launches) ------
+    def adam_state(self):
+        """(m, v, step): Adam's moments in the padded gradient layout [pnr_mlp_grad_floats()] and the update count."""
+        if not hasattr(self, "_adam"):
+            n = int(self.lib.pnr_mlp_grad_floats())
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._adam = (torch.zeros(n, **f32), torch.zeros(n, **f32), torch.zeros((), **f32))
+        return self._adam
+
+    def _step_args(self, lr, betas, eps):
+        s = _lib.PnrMlpStep()
+        s.struct_size = C.sizeof(_lib.PnrMlpStep)
+        for k, prm in enumerate(self.params):
+            s.params[k] = prm.data_ptr()
+        s.n3_policy, s.n3_value = self.n3
+        m, v, step = self.adam_state()
+        s.wpack, s.bias = self.wpack.data_ptr(), self.bias.data_ptr()
+        s.adam_m, s.adam_v, s.adam_step = m.data_ptr(), v.data_ptr(), step.data_ptr()
+        s.lr, s.beta1, s.beta2, s.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        return s
+
+    def train_step(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float, means_out: torch.Tensor,
+                   lr: float, betas=(0.9, 0.999), eps: float = 1e-8, flat_grad: Optional[torch.Tensor] = None) -> None:
+        """Forward, loss, backward and — unless ``flat_grad`` is given — the Adam update of the float32 master
+        parameters plus the refresh of the packed bf16 weights, all on the device (pnr_mlp_train_step).  With
+        ``flat_grad`` ([pnr_mlp_grad_floats()]) the reduced gradient lands there instead and nothing is updated: all-reduce
+        it and call ``adam(flat_grad, 1 / world)``.  ``pack()`` must have run once after the parameters last changed
+        behind this object's back (construction, restore)."""
+        self._check_inputs(obs, idx, filt, self.device)
+        B = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        self._batch_of_ws(B)
+        ws = self._workspace()
+        R = obs.shape[0]
+        for k in ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values"):
+            v = rec[k]
+            assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
+        assert means_out.dtype == torch.float32 and means_out.numel() >= 8 and means_out.is_contiguous()
+        s = self._step_args(lr, betas, eps)
+        s.batch = B
+        s.obs, s.idx = obs.data_ptr(), (idx.data_ptr() if idx is not None else None)
+        if filt is not None:
+            s.f_loc, s.f_inv, s.f_lo, s.f_hi = (t.data_ptr() for t in filt)
+        s.actions, s.logp_old, s.mean_old, s.log_std_old = (rec[k].data_ptr() for k in ("actions", "logp", "mean", "log_std"))
+        s.adv, s.value_target, s.value_old = (rec[k].data_ptr() for k in ("adv", "vtarg", "values"))
+        s.kl_coeff, s.entropy_coeff = kl_c.data_ptr(), ent_c.data_ptr()
+        s.clip_param, s.vf_clip_param, s.vf_loss_coeff = float(clip), float(vf_clip), float(vf_coeff)
+        s.head, s.g_head = ws["head"].data_ptr(), ws["g"].data_ptr()
+        s.xs, s.h1, s.h2, s.dz1, s.dz2 = (ws[k].data_ptr() for k in ("xs", "h1", "h2", "dz1", "dz2"))
+        s.partials, s.partial_rows = ws["partials"].data_ptr(), ws["partials"].shape[0]
+        s.slabs, s.slab_floats = ws["slabs"].data_ptr(), ws["slabs"].numel()
+        s.means = means_out.data_ptr()
+        if flat_grad is not None:
+            assert flat_grad.dtype == torch.float32 and flat_grad.is_contiguous() and flat_grad.numel() == int(self.lib.pnr_mlp_grad_floats())
+            s.flat_grad = flat_grad.data_ptr()
+        _lib.check(self.lib.pnr_mlp_train_step(C.byref(s), self._stream()))
+
+    def adam(self, flat_grad: torch.Tensor, grad_scale: float, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        s = self._step_args(lr, betas, eps)
+        _lib.check(self.lib.pnr_mlp_adam(C.byref(s), _p(flat_grad), C.c_float(grad_scale), self._stream()))
+
     def policy_loss(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float) -> torch.Tensor:
         """The whole differentiable part of one PPO minibatch update in six launches: weight packing, the fused
         forward of both nets, the loss kernel (pnr_ppo_loss: values + d loss / d head) and its finishing sum; the

@@ -529,8 +529,8 @@ class PPOLearner:
         # the reference's (137-256-256, pioneer_knm_train.py:59-61) and bf16 GEMMs were asked for; float32 runs stay on torch
         self.hip = (self.fused_loss and bool(cfg.amp_bf16) and cfg.obs_dim == 137 and tuple(cfg.fcnet_hiddens) == (256, 256))
         self._mlp = None            # HipMLP with a workspace for one minibatch
-        self._own = None            # pointer-stable copies of the update's batch (HIP path)
-        self._idx = None            # static minibatch row indices
+        self._means = None          # [minibatches, 8] per-update loss means (HIP path)
+        self._hip_dirty = True      # the packed bf16 weights are stale (construction, restore)
 
     def drop_graphs(self) -> None:
         """Forget the captured minibatch update (it is re-captured after the eager warm-up updates)."""
@@ -550,10 +550,7 @@ class PPOLearner:
         if self.hip and mb["obs"].is_cuda:
             idx = mb.get("idx")
             B = int(idx.numel()) if idx is not None else int(mb["obs"].shape[0])
-            if self._mlp is None or self._mlp.max_batch < B:
-                from .mlp import HipMLP
-                self._mlp = HipMLP(self.model, B, self.device)
-            m = self._mlp.policy_loss(mb["obs"], idx, mb.get("filt"), mb, self._kl_c, self._ent_c, cfg.clip_param,
+            m = self.hip_mlp(B).policy_loss(mb["obs"], idx, mb.get("filt"), mb, self._kl_c, self._ent_c, cfg.clip_param,
                                       cfg.vf_clip_param, cfg.vf_loss_coeff)
             # the reported means are DETACHED views: kept across minibatches (agg, _static_info) they must not keep the
             # autograd graph alive — its AccumulateGrad nodes would remember the stream of an earlier eager update, and
@@ -599,20 +596,9 @@ class PPOLearner:
         filt = batch.get("filt")
         tens = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
         tens["adv"] = adv_n
-        hip = self.hip and adv.is_cuda
-        if hip:
-            # HIP path: the kernels gather minibatch rows themselves (idx), so the batch is kept whole in buffers this
-            # learner owns — their addresses are what a captured update replays on
-            if self._own is None or any(self._own[k].shape != v.shape for k, v in tens.items()):
-                self.drop_graphs()
-                self._own = {k: torch.empty_like(v, memory_format=torch.contiguous_format) for k, v in tens.items()}
-                self._idx = torch.empty(mbs, dtype=torch.int64, device=adv.device)
-            for k, v in tens.items():
-                self._own[k].copy_(v)
-            if self._idx.numel() != mbs:
-                self.drop_graphs()
-                self._idx = torch.empty(mbs, dtype=torch.int64, device=adv.device)
-            full = dict(self._own, idx=self._idx, filt=filt)
+        if self.hip and adv.is_cuda:
+            out = self._update_hip(tens, filt, B, mbs, generator)
+            return self._finish_update(out, adv.device)
 
         def eager_step(mb):
             loss, info = self.loss(mb)
@@ -624,33 +610,34 @@ class PPOLearner:
             self.opt.step()
             return info
 
-        graph_ok = self.use_graph and (self._static is None or self._static["obs"].shape[0] == (B if hip else mbs))
+        graph_ok = self.use_graph and (self._static is None or self._static["obs"].shape[0] == mbs)
         for _ in range(cfg.num_sgd_iter):
             perm = torch.randperm(B, device=adv.device, generator=generator)
             for s in range(0, B - mbs + 1, mbs):
                 idx = perm[s:s + mbs]
-                if hip:
-                    self._idx.copy_(idx)
                 if graph_ok and self._graph is None and self._eager_updates >= 3:
-                    self._capture(full if hip else tens, idx)       # after a few eager updates (warm-up)
+                    self._capture(tens, idx)                        # after a few eager updates (warm-up)
                 if graph_ok and self._graph is not None:
-                    if not hip:
-                        for k, v in tens.items():
-                            torch.index_select(v, 0, idx, out=self._static[k])
+                    for k, v in tens.items():
+                        torch.index_select(v, 0, idx, out=self._static[k])
                     self._graph.replay()
                     if self._split:
                         pdist.allreduce_mean_(self._flat_grad)      # the one 0.82 MB bucket, eager
                         self._graph_b.replay()
                     info = self._static_info
                 else:
-                    info = eager_step(full if hip else {k: v[idx] for k, v in tens.items()})
+                    info = eager_step({k: v[idx] for k, v in tens.items()})
                     self._eager_updates += 1
                 for k, v in info.items():
                     agg[k] = agg.get(k, 0) + v
                 nmb += 1
         out = {k: float(v) / max(1, nmb) for k, v in agg.items()}
+        return self._finish_update(out, adv.device)
+
+    def _finish_update(self, out: Dict[str, float], device) -> Dict[str, float]:
+        cfg = self.cfg
         # adaptive KL (RLlib PPO: update_kl)
-        kl_t = torch.tensor([out.get("kl", 0.0)], dtype=torch.float64, device=adv.device)
+        kl_t = torch.tensor([out.get("kl", 0.0)], dtype=torch.float64, device=device)
         pdist.allreduce_sum_(kl_t)
         kl = float(kl_t) / (pdist.dist.get_world_size() if pdist.is_dist() else 1)
         if kl > 2.0 * cfg.kl_target:
@@ -662,15 +649,75 @@ class PPOLearner:
         out["entropy_coeff"] = self.entropy_coeff()
         return out
 
+    def optimizer_state(self):
+        """torch.optim.Adam's state_dict on the torch path; on the HIP path Adam's moments as the fused kernel keeps them
+        (padded gradient layout) and its update count."""
+        if self.hip and self._mlp is not None:
+            m, v, step = self._mlp.adam_state()
+            return {"hip_adam": {"m": m, "v": v, "step": step}}
+        return self.opt.state_dict()
+
+    def load_optimizer_state(self, sd) -> None:
+        if "hip_adam" in sd:
+            if not self.hip:
+                raise AssertionError("the checkpoint holds the HIP path's optimiser state; this learner runs on torch")
+            mlp = self.hip_mlp(max(1, min(self.cfg.sgd_minibatch_size, 1 << 20)))
+            for dst, k in zip(mlp.adam_state(), ("m", "v", "step")):
+                dst.copy_(sd["hip_adam"][k])
+        elif not (self.hip and not sd.get("state")):
+            self.opt.load_state_dict(sd)
+        self._hip_dirty = True           # the master weights changed behind the packed bf16 copies
+
+    # -- the HIP path: every minibatch update is pnr_mlp_train_step, seven launches, no autograd, no hipGraph needed ----
+    def hip_mlp(self, batch: int):
+        if self._mlp is None or self._mlp.max_batch < batch:
+            from .mlp import HipMLP
+            old = self._mlp
+            self._mlp = HipMLP(self.model, batch, self.device)
+            if old is not None:                                   # keep the optimiser state across a workspace resize
+                for a, b in zip(self._mlp.adam_state(), old.adam_state()):
+                    a.copy_(b)
+            self._hip_dirty = True
+        return self._mlp
+
+    def _update_hip(self, tens, filt, B, mbs, generator) -> Dict[str, float]:
+        """The minibatch loop on the hand-written kernels.  The kernels gather minibatch rows themselves (a slice of the
+        epoch's permutation is the row index), the float32 master parameters are updated in place by the fused
+        reduction + Adam kernel, which also refreshes the packed bf16 weights for the next forward.  Several ranks:
+        the reduced gradient goes to one flat bucket, is all-reduced (RCCL), and pnr_mlp_adam applies the mean."""
+        cfg, dev = self.cfg, self.device
+        mlp = self.hip_mlp(mbs)
+        if self._hip_dirty:
+            mlp.pack()
+            self._hip_dirty = False
+        rec = {k: v.contiguous() for k, v in tens.items()}
+        nmb_epoch = len(range(0, B - mbs + 1, mbs))
+        total = cfg.num_sgd_iter * nmb_epoch
+        if self._means is None or self._means.shape[0] != total:
+            self._means = torch.zeros((total, 8), dtype=torch.float32, device=dev)
+        multi = pdist.is_dist()
+        world = pdist.dist.get_world_size() if multi else 1
+        if multi and self._flat_grad is None:
+            self._flat_grad = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), dtype=torch.float32, device=dev)
+        k = 0
+        for _ in range(cfg.num_sgd_iter):
+            perm = torch.randperm(B, device=dev, generator=generator)
+            for s in range(0, B - mbs + 1, mbs):
+                mlp.train_step(rec["obs"], perm[s:s + mbs], filt, rec, self._kl_c, self._ent_c, cfg.clip_param, cfg.vf_clip_param,
+                               cfg.vf_loss_coeff, self._means[k], cfg.lr, flat_grad=self._flat_grad if multi else None)
+                if multi:
+                    pdist.allreduce_sum_(self._flat_grad)          # the one 0.86 MB bucket
+                    mlp.adam(self._flat_grad, 1.0 / world, cfg.lr)
+                k += 1
+        m = self._means.mean(0).tolist()
+        return {"policy_loss": m[0], "vf_loss": m[1], "kl": m[2], "entropy": m[3], "total_loss": m[4]}
+
 
 def _learner_capture(self, batch, idx):
     """Capture one minibatch update on static buffers: one hipGraph (single rank) or two with the
     gradient all-reduce between them (several ranks).  The capture pass only records work."""
     try:
-        if self.hip and "idx" in batch:
-            self._static = batch                     # the learner's own whole-batch buffers + the static index vector
-        else:
-            self._static = {k: v[idx].clone() for k, v in batch.items()}
+        self._static = {k: v[idx].clone() for k, v in batch.items()}
         torch.cuda.synchronize(self.device)
         if not self._split:
             self.opt.zero_grad(set_to_none=True)
@@ -908,7 +955,7 @@ class PPOTrainer:
         rank writes its env shard next to it (`<path>.env_rank<r>`), so restore_env gives each rank ITS envs back."""
         est = self._env_state()
         if self.rank == 0:
-            torch.save({"model": self.learner.model.state_dict(), "opt": self.learner.opt.state_dict(),
+            torch.save({"model": self.learner.model.state_dict(), "opt": self.learner.optimizer_state(),
                         "filter": self.filter.state_dict(), "kl_coeff": self.learner.kl_coeff,
                         "timesteps_total": self.learner.timesteps_total, "iteration": self.iteration,
                         "episodes_total": self.stats.total, "world": self.world, **est,
@@ -920,7 +967,7 @@ class PPOTrainer:
 
     def restore(self, path: str, restore_env: bool = False) -> None:
         ck = torch.load(path, map_location=self.device, weights_only=True)    # tensors and plain values only
-        self.learner.model.load_state_dict(ck["model"]); self.learner.opt.load_state_dict(ck["opt"])
+        self.learner.model.load_state_dict(ck["model"]); self.learner.load_optimizer_state(ck["opt"])
         # load_state_dict REPLACES the optimiser's state tensors: a learner graph captured before this call would
         # keep replaying on the old exp_avg / exp_avg_sq / step.  Drop the captures; they are rebuilt after the
         # usual eager warm-up updates.  (Model weights and filter moments are copied in place: the sampling

@@ -50,4 +50,4 @@ def test_two_ranks_self_launched_on_the_metric_configuration():
     assert "error" not in p and p["losses_finite"]
     assert p["total_envs"] == 2048 and p["envs_per_gpu"] == 1024 and p["sgd_minibatch_size_per_rank"] == 4096
     assert p["grad_allreduce"]["world_size"] == 2 and p["grad_allreduce"]["backend"] == "gloo"
-    assert p["hip_graph"]["learner_split_around_allreduce"]
+    assert p["hip_graph"]["sampling"] and p["hip_graph"]["learner"].startswith("hip kernels")

@@ -146,3 +146,58 @@ def test_graph_replay_of_the_learner_kernels_is_exact():
         assert torch.equal(hp, ehp) and torch.equal(hv, ehv)
         for a, b in zip(grads, egrads):
             assert torch.equal(a, b)
+
+
+def _record(B, dev, seed=9):
+    from pioneer_amd.ppo import gaussian_logp
+    g = torch.Generator(device=dev).manual_seed(seed)
+    R = lambda *s: torch.randn(*s, generator=g, device=dev)   # noqa: E731
+    act, mean, ls = R(B, 6), 0.1 * R(B, 6), 0.1 * R(B, 6)
+    return {"actions": act, "mean": mean, "log_std": ls, "logp": gaussian_logp(act, mean, ls), "values": R(B), "adv": R(B), "vtarg": R(B)}
+
+
+def test_train_step_equals_autograd_plus_torch_adam():
+    """pnr_mlp_train_step (fused slab reduction + Adam + repacking, update count on the device) against the same HIP
+    gradients taken through autograd and applied by torch.optim.Adam, over several updates on changing minibatches; the
+    flat-bucket form (reduce -> [all-reduce] -> pnr_mlp_adam) must equal the fused form bit for bit."""
+    import copy
+    from pioneer_amd.mlp import HipMLP
+    R, B, lr = 20000, 8192, 1e-3
+    model, mlp, obs, _, filt = make(B, seed=21, rows=R, with_filter=True)
+    dev = obs.device
+    rec = _record(R, dev)
+    klc = torch.tensor(0.2, device=dev); entc = torch.tensor(0.01, device=dev)
+    model_t = copy.deepcopy(model); mlp_t = HipMLP(model_t, B, dev)
+    model_f = copy.deepcopy(model); mlp_f = HipMLP(model_f, B, dev)
+    opt = torch.optim.Adam(model_t.parameters(), lr=lr)
+    means = torch.zeros(6, 8, device=dev); means_f = torch.zeros(6, 8, device=dev)
+    flat = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), device=dev)
+    mlp.pack(); mlp_f.pack()
+    g = torch.Generator(device=dev).manual_seed(1)
+    for it in range(6):
+        idx = torch.randperm(R, generator=g, device=dev)[:B].contiguous()
+        mlp.train_step(obs, idx, filt, rec, klc, entc, 0.3, 10.0, 1.0, means[it], lr)
+        mlp_f.train_step(obs, idx, filt, rec, klc, entc, 0.3, 10.0, 1.0, means_f[it], lr, flat_grad=flat)
+        mlp_f.adam(flat, 1.0, lr)
+        m = mlp_t.policy_loss(obs, idx, filt, dict(rec, obs=obs), klc, entc, 0.3, 10.0, 1.0)
+        opt.zero_grad(set_to_none=True)
+        m[4].backward()
+        opt.step()
+        if it == 0:
+            # same weights, same (deterministic) gradient kernels: only the optimiser arithmetic differs.  Adam's first
+            # step moves every element by lr * g / (|g| + eps'): compare to a few ulps of the step size
+            assert torch.equal(means[0, :5], m.detach()[:5])
+            for a, b in zip(mlp.params, mlp_t.params):
+                assert float((a - b).abs().max()) <= 1e-3 * lr, float((a - b).abs().max())
+        # later steps: an element whose gradient is ~0 may take its +-lr step the other way after a last-bit difference,
+        # so the trajectories are compared loosely
+        assert torch.allclose(means[it, :5], m.detach()[:5], rtol=2e-3, atol=1e-5), (it, means[it], m)
+    assert float(mlp.adam_state()[2]) == 6.0
+    for a, b, c in zip(mlp.params, mlp_t.params, mlp_f.params):
+        assert torch.equal(a, c)                                  # fused == flat-bucket form
+        d = (a - b).abs()
+        assert float((d <= 1e-2 * lr).float().mean()) > 0.999 and float(d.max()) <= 12 * lr
+    assert float((mlp.params[2] - model.policy[2].weight).abs().max()) == 0.0     # the module's own tensors were updated
+    w_now = mlp.wpack.clone(); b_now = mlp.bias.clone()
+    mlp.pack()
+    assert torch.equal(w_now, mlp.wpack) and torch.equal(b_now, mlp.bias)         # the refreshed bf16 copies are exact

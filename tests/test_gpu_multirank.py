@@ -118,7 +118,7 @@ tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=16, num_sgd_iter=3, sgd_m
                                amp_bf16=True), use_graph=True)
 rows = [tr.train() for _ in range(5)]
 json.dump({"backend": dist.get_backend(), "sampling_graph": tr._graph is not None,
-           "split": bool(tr.learner._split), "graph_a": tr.learner._graph is not None, "graph_b": tr.learner._graph_b is not None,
+           "hip": bool(tr.learner.hip), "flat_bucket": tr.learner._flat_grad is not None,
            "kl": [r["kl"] for r in rows], "total_loss": [r["total_loss"] for r in rows],
            "timesteps_total": rows[-1]["timesteps_total"], "episodes_total": rows[-1]["episodes_total"]},
           open(os.path.join(os.environ["PNR_OUT"], "rccl.json"), "w"))
@@ -128,9 +128,9 @@ dist.destroy_process_group()
 
 
 def test_graph_captured_loop_with_an_rccl_process_group(tmp_path):
-    """The N>1 code paths (sampling hipGraph, learner graphs split around the flat-bucket all-reduce,
-    filter/metric all-reduces) against a real RCCL process group — one rank, all this box has — so that
-    capture next to RCCL's watchdog thread and eager collectives between graph replays are exercised."""
+    """The N>1 code paths (sampling hipGraph, the HIP learner's flat gradient bucket all-reduced between the
+    gradient kernels and pnr_mlp_adam, filter/metric all-reduces) against a real RCCL process group — one rank, all this
+    box has — so that capture next to RCCL's watchdog thread and eager collectives are exercised."""
     script = tmp_path / "rccl.py"
     script.write_text(RCCL_WORKER)
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
@@ -139,6 +139,6 @@ def test_graph_captured_loop_with_an_rccl_process_group(tmp_path):
     assert res.returncode == 0, res.stderr[-3000:]
     r = json.load(open(tmp_path / "rccl.json"))
     assert r["backend"] == "nccl"
-    assert r["sampling_graph"] and r["split"] and r["graph_a"] and r["graph_b"], r
+    assert r["sampling_graph"] and r["hip"] and r["flat_bucket"], r      # HIP learner: reduce -> RCCL all-reduce -> pnr_mlp_adam
     assert r["timesteps_total"] == 5 * 16 * 2048 and r["episodes_total"] > 0
     assert all(np.isfinite(x) for x in r["kl"] + r["total_loss"]), r
