@@ -114,7 +114,7 @@ __device__ __forceinline__ float tanh_fast(float x)
 __device__ __forceinline__ bf16x8 ld_global_bf16x8(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 // acc[rb][cb] += W[64 rows of this wave][K] . tile[128 samples][K]^T.  W: row-major, row stride K (global, L2);
-// tile: LDS, row stride STRIDE.  A fragments run three k-steps ahead of their use.
+// tile: LDS, row stride STRIDE.
 template <int K, int STRIDE>
 __device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_rows, const __bf16* tile, f32x16 (&acc)[2][4], int lane)
 {
@@ -122,17 +122,20 @@ __device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_rows,
     const int r = lane & 31, h = lane >> 5;
     const __bf16* wa = w_rows + (size_t)r * K + 8 * h;
     const __bf16* tb = tile + r * STRIDE + 8 * h;
-    bf16x8 a[3][2];
+    constexpr int D = 5;                      // A fragments run D - 1 k-steps ahead of their use (L2 latency ~ 2-3 k-steps of MFMAs)
+    bf16x8 a[D][2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        a[p][0] = ld_global_bf16x8(wa + 16 * p);
-        a[p][1] = ld_global_bf16x8(wa + 32 * K + 16 * p);
+    for (int p = 0; p < D - 1; ++p) {
+        if (p < KS) {
+            a[p][0] = ld_global_bf16x8(wa + 16 * p);
+            a[p][1] = ld_global_bf16x8(wa + 32 * K + 16 * p);
+        }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 2 < KS) {
-            a[(ks + 2) % 3][0] = ld_global_bf16x8(wa + 16 * (ks + 2));
-            a[(ks + 2) % 3][1] = ld_global_bf16x8(wa + 32 * K + 16 * (ks + 2));
+        if (ks + D - 1 < KS) {
+            a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 16 * (ks + D - 1));
+            a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 32 * K + 16 * (ks + D - 1));
         }
         bf16x8 b[4];
 #pragma unroll
@@ -141,7 +144,7 @@ __device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_rows,
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb)
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % 3][rb], b[cb], acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][rb], b[cb], acc[rb][cb], 0, 0, 0);
     }
 }
 
@@ -216,25 +219,42 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
             }
         }
         __syncthreads();
-        constexpr int kPairs = kMlpInPad / 2;                     // 72 column pairs per row
-        for (int e = tid; e < kMlpBM * kPairs; e += kMlpThreads) {
-            const int row = e / kPairs, k = 2 * (e % kPairs);
-            float v0 = 0.f, v1 = 0.f;
+        // two threads per row, 72 columns each: every load of the thread (18 unaligned 16-byte loads; a row starts on a
+        // 4-byte boundary only) is issued before the first use.  Written as a loop over (row, column pair) with one
+        // dependent idx -> row load per iteration this stage was a chain of ~36 memory round trips per thread:
+        // 35.8 us of a 16 384-sample launch (rocprof r02_b) against ~3 us of MFMA time.
+        {
+            const int row = tid >> 1, half = tid & 1;
             const long long b = row0 + row;
-            if (b < P.B) {
-                const float* src = P.obs + (P.idx ? P.idx[b] : b) * kMlpIn;
-                if (k < kMlpIn) v0 = src[k];
-                if (k + 1 < kMlpIn) v1 = src[k + 1];
-                if (P.f_loc) {
-                    v0 = fminf(fmaxf((v0 - fv[k]) * fv[kMlpInPad + k], fv[2 * kMlpInPad + k]), fv[3 * kMlpInPad + k]);
-                    v1 = fminf(fmaxf((v1 - fv[k + 1]) * fv[kMlpInPad + k + 1], fv[2 * kMlpInPad + k + 1]), fv[3 * kMlpInPad + k + 1]);
-                    if (k >= kMlpIn) v0 = 0.f;
-                    if (k + 1 >= kMlpIn) v1 = 0.f;
+            const bool live = b < P.B;
+            const float* src = P.obs + (live ? (P.idx ? P.idx[b] : b) : 0) * kMlpIn + 72 * half;
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            f32x4 v[18];
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                const int col = 72 * half + 4 * j;                // compile-time per half: 0..68 | 72..140
+                v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    if (half == 0 || j < 16) v[j] = *reinterpret_cast<const f32x4u*>(src + 4 * j);      // cols .. 135
+                    else if (j == 16) v[j][0] = src[64];                                               // col 136
                 }
+                (void)col;
             }
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            bf16x2 pk = {(__bf16)v0, (__bf16)v1};
-            *reinterpret_cast<bf16x2*>(xt + row * kXS + k) = pk;
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {
+                const int col = 72 * half + 4 * j;
+                f32x4 x = v[j];
+                if (P.f_loc) {
+                    const f32x4 loc = *reinterpret_cast<const f32x4*>(fv + col), inv = *reinterpret_cast<const f32x4*>(fv + kMlpInPad + col);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(fv + 2 * kMlpInPad + col), hi = *reinterpret_cast<const f32x4*>(fv + 3 * kMlpInPad + col);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] = fminf(fmaxf((x[k] - loc[k]) * inv[k], lo[k]), hi[k]);
+                }
+                bf16x4 pk;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pk[k] = (__bf16)((live && col + k < kMlpIn) ? x[k] : 0.f);
+                *reinterpret_cast<bf16x4*>(xt + row * kXS + col) = pk;
+            }
         }
         __syncthreads();
         if (P.xs && net == 0) {                                   // the input is the same for both nets: saved once
@@ -375,10 +395,25 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
             for (int cb = 0; cb < 4; ++cb)
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
     }
+    // the H1 tile is requested now (16 x 16 bytes per thread, held in registers) and lands under the epilogue below
+    uint4 h1r[16];
+    {
+        const __bf16* src = P.h1 + (size_t)net * P.B * kMlpHid;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
+            h1r[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (row0 + row < P.B) h1r[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
+        }
+    }
     epilogue();
-    __syncthreads();
+    __syncthreads();                                                               // every wave is done with H2
     mlp_store_htile(dz, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
-    mlp_load_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);      // every wave is done with H2
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
+        *reinterpret_cast<uint4*>(ht + row * kHS + cc * 8) = h1r[i];
+    }
     __syncthreads();
 
     // ---- dH1^T = W2^T . dZ2^T
@@ -407,18 +442,33 @@ struct MlpWgradParams {
     long long slice_rows;      // samples per slice, a multiple of kWgChunk
 };
 
-// stage `rows` x `cols` bf16 (cols a multiple of 8) from row-major global (row stride src_stride) into an LDS tile
-__device__ __forceinline__ void wg_stage(__bf16* tile, int tstride, const __bf16* __restrict__ src, long long src_stride,
-                                         long long row0, long long n_rows, int cols, int tid)
-{
-    const int cpr = cols / 8;
-    for (int ch = tid; ch < kWgChunk * cpr; ch += kMlpThreads) {
-        const int row = ch / cpr, cc = ch % cpr;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row0 + row < n_rows) v = *reinterpret_cast<const uint4*>(src + (row0 + row) * src_stride + cc * 8);
-        *reinterpret_cast<uint4*>(tile + row * tstride + cc * 8) = v;
+// A 64-row chunk of COLS bf16 columns (a multiple of 8) on its way from row-major global memory (row stride src_stride)
+// into an LDS tile: loaded into registers first (every load of the chunk in flight together), written later — the
+// weight-gradient loop requests chunk c + 1 before it multiplies chunk c.
+template <int COLS>
+struct WgChunk {
+    static constexpr int kPerThread = (kWgChunk * (COLS / 8) + kMlpThreads - 1) / kMlpThreads;
+    uint4 v[kPerThread];
+    __device__ __forceinline__ void load(const __bf16* __restrict__ src, long long src_stride, long long row0, long long n_rows, int tid)
+    {
+        constexpr int cpr = COLS / 8;
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const int ch = tid + kMlpThreads * i, row = ch / cpr, cc = ch % cpr;
+            v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (ch < kWgChunk * cpr && row0 + row < n_rows) v[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * src_stride + cc * 8);
+        }
     }
-}
+    __device__ __forceinline__ void store(__bf16* tile, int tstride, int tid) const
+    {
+        constexpr int cpr = COLS / 8;
+#pragma unroll
+        for (int i = 0; i < kPerThread; ++i) {
+            const int ch = tid + kMlpThreads * i, row = ch / cpr, cc = ch % cpr;
+            if (ch < kWgChunk * cpr) *reinterpret_cast<uint4*>(tile + row * tstride + cc * 8) = v[i];
+        }
+    }
+};
 
 // a 32x32x16 operand fragment whose k index is the SAMPLE: eight consecutive rows s0 + 8h .. +7 of column
 // col0 + (lane & 31) of a row-major tile, by two transposed 4x16 reads (cdna_hip_programming.md T10)
@@ -481,11 +531,17 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        WgChunk<kMlpHid> ca; WgChunk<128> cb;
+        ca.load(P.dz2 + nb, kMlpHid, s_begin, s_end, tid);
+        cb.load(P.h1 + nb + 128 * part, kMlpHid, s_begin, s_end, tid);
         for (long long s = s_begin; s < s_end; s += kWgChunk) {
+            __syncthreads();                                         // every wave is done with the previous chunk
+            ca.store(ta, kTrH, tid); cb.store(tb, kTrHalf, tid);
             __syncthreads();
-            wg_stage(ta, kTrH, P.dz2 + nb, kMlpHid, s, s_end, kMlpHid, tid);
-            wg_stage(tb, kTrHalf, P.h1 + nb + 128 * part, kMlpHid, s, s_end, 128, tid);
-            __syncthreads();
+            if (s + kWgChunk < s_end) {                              // the next chunk travels while this one is multiplied
+                ca.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
+                cb.load(P.h1 + nb + 128 * part, kMlpHid, s + kWgChunk, s_end, tid);
+            }
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 16; ++ks) {
                 bf16x8 fa[4], fb[2];
@@ -516,10 +572,12 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
             for (int b = 0; b < 5; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        WgChunk<kMlpHid> ca; WgChunk<kMlpInPad> cb;
+        ca.load(P.dz1 + nb, kMlpHid, s_begin, s_end, tid);
+        cb.load(P.xs, kMlpInPad, s_begin, s_end, tid);
         for (long long s = s_begin; s < s_end; s += kWgChunk) {
             __syncthreads();
-            wg_stage(ta, kTrH, P.dz1 + nb, kMlpHid, s, s_end, kMlpHid, tid);
-            wg_stage(tb, kTrX, P.xs, kMlpInPad, s, s_end, kMlpInPad, tid);
+            ca.store(ta, kTrH, tid); cb.store(tb, kTrX, tid);
             if (tid < kWgChunk) {                                     // columns 144..159: a one (real rows only), zeros
                 bf16x8 one = {(__bf16)((s + tid < s_end) ? 1.0f : 0.0f), (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
                 bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -527,6 +585,10 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
                 *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad + 8) = zero;
             }
             __syncthreads();
+            if (s + kWgChunk < s_end) {
+                ca.load(P.dz1 + nb, kMlpHid, s + kWgChunk, s_end, tid);
+                cb.load(P.xs, kMlpInPad, s + kWgChunk, s_end, tid);
+            }
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 16; ++ks) {
                 bf16x8 fa[2], fb[5];
@@ -563,10 +625,12 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
         bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+        WgChunk<kMlpHid> ch2, cz2;
+        ch2.load(P.h2 + nb, kMlpHid, s_begin, s_end, tid);
+        cz2.load(P.dz2 + nb, kMlpHid, s_begin, s_end, tid);
         for (long long s = s_begin; s < s_end; s += kWgChunk) {
             __syncthreads();
-            wg_stage(th, kTrH, P.h2 + nb, kMlpHid, s, s_end, kMlpHid, tid);
-            wg_stage(tz, kTrH, P.dz2 + nb, kMlpHid, s, s_end, kMlpHid, tid);
+            ch2.store(th, kTrH, tid); cz2.store(tz, kTrH, tid);
             if (tid < 2 * kWgChunk) {
                 const int row = tid >> 1, half = tid & 1;
                 f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
@@ -580,6 +644,10 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
                 *reinterpret_cast<bf16x8*>(tg + row * kTrG + 8 * half) = pk;
             }
             __syncthreads();
+            if (s + kWgChunk < s_end) {
+                ch2.load(P.h2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
+                cz2.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
+            }
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 32; ++ks) {
                 const bf16x8 fg = wg_frag16(tg, kTrG, 32 * ks, 0, lane);          // A: rows = head entries
