@@ -51,6 +51,12 @@ enum pnr_layout {
     PNR_FEATURE_MAJOR = 1  /* [F][num_envs] — feature planes (first Linear as W . X^T)      */
 };
 
+/* The reference's motor forms (Joint.control_position / control_velocity, bullet_scene.py:123-155). */
+enum pnr_control {
+    PNR_CONTROL_POSITION = 0, /* POSITION_CONTROL: positionGain pd_kp, velocityGain pd_kd, force torque_limit, maxVelocity */
+    PNR_CONTROL_VELOCITY = 1  /* VELOCITY_CONTROL: the motor tracks the commanded velocity only (gain pd_kd, force torque_limit) */
+};
+
 enum pnr_mode {
     PNR_MODE_KINEMATIC = 0, /* the reference's live semantics ("parity mode")   */
     PNR_MODE_DYNAMIC = 1    /* ABA forward dynamics + PD torque tracking         */
@@ -110,6 +116,11 @@ typedef struct pnr_config {
     double obstacle_position[3];
     double obstacle_half_extents[3];
     double pointer_radius;        /* 0.2: the pointer's sphere (urdf:190-196) */
+    int32_t control_mode;         /* enum pnr_control; dynamics mode, teleport 0 */
+    int32_t link_contacts;        /* 1: sample spheres along every moving link collide with the plane / box too (capsules
+                                   * fitted to the URDF's visual boxes; the URDF itself has no <collision>) */
+    double max_velocity;          /* control_position's maxVelocity (bullet_scene.py:126,136): cap on the velocity the
+                                   * motor asks for, rad/s; <= 0 = none */
 } pnr_config;
 
 typedef struct pnr_env_s* pnr_handle;

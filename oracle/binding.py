@@ -191,7 +191,12 @@ class OrcDynParams(C.Structure):
         ("ground_z", C.c_double), ("contact_kp", C.c_double), ("contact_kd", C.c_double),
         ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
         ("pointer_radius", C.c_double),
+        ("control_mode", C.c_int32), ("link_contacts", C.c_int32), ("max_velocity", C.c_double),
     ]
+
+
+class OrcContactSample(C.Structure):
+    _fields_ = [("body", C.c_int32), ("c", C.c_double * 3), ("radius", C.c_double)]
 
 
 DYN_STATE_DTYPE = np.dtype([
@@ -260,6 +265,27 @@ class DynOracle(COracle):
         self.lib.orc_dyn_aba(self._one(e), _ptr(tau, C.c_double), C.c_double(gravity), _ptr(f, C.c_double),
                              _ptr(qdd, C.c_double))
         return qdd
+
+    def aba_ext(self, tau, gravity=0.0, fext=None, e=0):
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        qdd = np.empty(DOF)
+        f = None if fext is None else np.ascontiguousarray(fext, dtype=np.float64).reshape(DOF, 6)
+        self.lib.orc_dyn_aba_ext(self._one(e), _ptr(tau, C.c_double), C.c_double(gravity), _ptr(f, C.c_double), _ptr(qdd, C.c_double))
+        return qdd
+
+    def motor_torque(self, r_ref, v_ref, q, qd):
+        self.lib.orc_dyn_motor_torque.restype = C.c_double
+        return self.lib.orc_dyn_motor_torque(C.byref(self.d), C.c_double(r_ref), C.c_double(v_ref), C.c_double(q), C.c_double(qd))
+
+    def contact_samples(self):
+        arr = (OrcContactSample * 23)()
+        n = self.lib.orc_dyn_contact_samples(C.byref(self.d), arr)
+        return [(arr[i].body, np.array(arr[i].c[:]), arr[i].radius) for i in range(n)]
+
+    def contact_wrenches(self, e=0):
+        f = np.zeros((DOF, 6))
+        any_ = self.lib.orc_dyn_contact_wrenches(C.byref(self.d), self._one(e), _ptr(f, C.c_double))
+        return bool(any_), f
 
     def energy(self, gravity=0.0, e=0):
         ke, pe = C.c_double(), C.c_double()

@@ -142,6 +142,20 @@ static void body_velocities(const orc_dyn_state* s, mat6 X[ORC_DOF], vec6 v[ORC_
 void orc_dyn_aba(const orc_dyn_state* s, const double tau[ORC_DOF], double gravity,
                  const double f_tip_world[3], double qdd[ORC_DOF])
 {
+    if (!f_tip_world) { orc_dyn_aba_ext(s, tau, gravity, NULL, qdd); return; }
+    /* external force on the pointer, expressed in body-6 coordinates at its origin */
+    double fext[ORC_DOF][6], R0[ORC_DOF][3][3], p0[ORC_DOF][3], fb[3], nb[3];
+    memset(fext, 0, sizeof(fext));
+    world_poses(s->q, R0, p0);
+    for (int a = 0; a < 3; a++) { fb[a] = 0; for (int k = 0; k < 3; k++) fb[a] += R0[5][k][a] * f_tip_world[k]; }
+    cross3(TIP, fb, nb);
+    for (int a = 0; a < 3; a++) { fext[5][a] = nb[a]; fext[5][3 + a] = fb[a]; }
+    orc_dyn_aba_ext(s, tau, gravity, (const double (*)[6])fext, qdd);
+}
+
+void orc_dyn_aba_ext(const orc_dyn_state* s, const double tau[ORC_DOF], double gravity,
+                     const double fext[ORC_DOF][6], double qdd[ORC_DOF])
+{
     mat6 I[ORC_DOF], X[ORC_DOF], IA[ORC_DOF];
     vec6 v[ORC_DOF], c[ORC_DOF], pA[ORC_DOF], U[ORC_DOF];
     double mass[ORC_DOF], h[ORC_DOF][3], D[ORC_DOF], u[ORC_DOF];
@@ -157,14 +171,9 @@ void orc_dyn_aba(const orc_dyn_state* s, const double tau[ORC_DOF], double gravi
         matvec6(I[i], v[i], Iv);
         crf(v[i], Iv, pA[i]);
     }
-    if (f_tip_world) {
-        /* external force on the pointer, expressed in body-6 coordinates at its origin */
-        double R0[ORC_DOF][3][3], p0[ORC_DOF][3], fb[3], nb[3];
-        world_poses(s->q, R0, p0);
-        for (int a = 0; a < 3; a++) { fb[a] = 0; for (int k = 0; k < 3; k++) fb[a] += R0[5][k][a] * f_tip_world[k]; }
-        cross3(TIP, fb, nb);
-        for (int a = 0; a < 3; a++) { pA[5][a] -= nb[a]; pA[5][3 + a] -= fb[a]; }
-    }
+    if (fext)
+        for (int i = 0; i < ORC_DOF; i++)
+            for (int r = 0; r < 6; r++) pA[i][r] -= fext[i][r];
     /* pass 2: articulated inertias, tip to base */
     for (int i = ORC_DOF - 1; i >= 0; i--) {
         int k = AXIS[i];
@@ -233,12 +242,93 @@ void orc_dyn_tip(const orc_dyn_state* s, double pos[3], double vel[3])
     }
 }
 
+static int contact_force_sphere(const orc_dyn_params* d, const double pos[3], const double vel[3], double radius, double f[3]);
+
 int orc_dyn_contact_force(const orc_dyn_params* d, const double pos[3], const double vel[3], double f[3])
+{
+    return contact_force_sphere(d, pos, vel, d->pointer_radius, f);
+}
+
+/* Contact sample spheres.  The pointer sphere is the reference's only sphere (urdf:190-196); the link samples are capsules
+ * fitted to the URDF's VISUAL boxes (arm1 urdf:78-90, arm2 :92-104, rotator2 + hinge2 :106-132, arm3 :134-153,
+ * effector :169-188): the reference URDF has no <collision> elements, so this geometry is build-defined. */
+static const struct { int body; double a[3], b[3]; int n; double radius; } CAPSULES[5] = {
+    {1, {0, 0, 0}, {0, 0, 11}, 8, 0.7},            /* arm1: 12 x 1 x 2 beam along its z */
+    {2, {-1, 1, 0}, {9, 1, 0}, 7, 0.7},            /* arm2: 10 x 1 x 2 beam along its x at y = 1 */
+    {3, {9, 0, 0}, {11, 0, 0}, 2, 0.7},            /* rotator2 + hinge2 on the roll axis */
+    {4, {-0.5, 0, 0}, {2.5, 0, 0}, 3, 0.6},        /* arm3: the two 3 x 0.5 x 1 cheeks */
+    {5, {3.6, 0, -0.75}, {3.6, 0, 1.9}, 3, -1.0},  /* the effector's needle; its last sample is the pointer sphere itself */
+};
+
+int orc_dyn_contact_samples(const orc_dyn_params* d, orc_contact_sample* out)
+{
+    if (!d->link_contacts) {
+        out[0].body = 5; memcpy(out[0].c, TIP, sizeof(TIP)); out[0].radius = -1.0;
+        return 1;
+    }
+    int k = 0;
+    for (int c = 0; c < 5; c++)
+        for (int i = 0; i < CAPSULES[c].n; i++, k++) {
+            double t = CAPSULES[c].n > 1 ? (double)i / (CAPSULES[c].n - 1) : 0.0;
+            out[k].body = CAPSULES[c].body;
+            for (int a = 0; a < 3; a++) out[k].c[a] = CAPSULES[c].a[a] + t * (CAPSULES[c].b[a] - CAPSULES[c].a[a]);
+            out[k].radius = CAPSULES[c].radius;
+        }
+    return k;
+}
+
+int orc_dyn_contact_wrenches(const orc_dyn_params* d, const orc_dyn_state* s, double fext[ORC_DOF][6])
+{
+    mat6 X[ORC_DOF]; vec6 v[ORC_DOF];
+    double R0[ORC_DOF][3][3], p0[ORC_DOF][3];
+    orc_contact_sample smp[ORC_CONTACT_SAMPLES];
+    int n = orc_dyn_contact_samples(d, smp), any = 0;
+    memset(fext, 0, ORC_DOF * 6 * sizeof(double));
+    body_velocities(s, X, v);
+    world_poses(s->q, R0, p0);
+    for (int k = 0; k < n; k++) {
+        const int b = smp[k].body;
+        const double* c = smp[k].c;
+        double wxc[3], vb[3], pos[3], vel[3], f[3], fb[3], nb[3];
+        cross3(v[b], c, wxc);
+        for (int a = 0; a < 3; a++) vb[a] = v[b][3 + a] + wxc[a];
+        for (int a = 0; a < 3; a++) {
+            pos[a] = p0[b][a]; vel[a] = 0;
+            for (int m = 0; m < 3; m++) { pos[a] += R0[b][a][m] * c[m]; vel[a] += R0[b][a][m] * vb[m]; }
+        }
+        if (!contact_force_sphere(d, pos, vel, smp[k].radius < 0 ? d->pointer_radius : smp[k].radius, f)) continue;
+        any = 1;
+        for (int a = 0; a < 3; a++) { fb[a] = 0; for (int m = 0; m < 3; m++) fb[a] += R0[b][m][a] * f[m]; }
+        cross3(c, fb, nb);
+        for (int a = 0; a < 3; a++) { fext[b][a] += nb[a]; fext[b][3 + a] += fb[a]; }
+    }
+    return any;
+}
+
+double orc_dyn_motor_torque(const orc_dyn_params* d, double r_ref, double v_ref, double q, double qd)
+{
+    /* One law for the three motor forms of bullet_scene.py:123-155, written as a velocity servo:
+     *   tau = clip(Kp (r - q) + kd (v* - qd), +-force),   v* = clamp(v + c (r - q), +-maxVelocity)
+     * POSITION_CONTROL without maxVelocity: Kp = kp, c = 0 (plain PD, the r01 arithmetic, bit for bit);
+     * with maxVelocity: Kp = 0, c = kp / kd (the same PD when the cap is inactive, the asked-for speed capped otherwise);
+     * VELOCITY_CONTROL: Kp = 0, c = 0. */
+    const int capped = d->max_velocity > 0;
+    const double Kp = (d->control_mode == 1 || capped) ? 0.0 : d->kp;
+    const double c = (d->control_mode == 0 && capped) ? d->kp / d->kd : 0.0;
+    double vs = v_ref + c * (r_ref - q);
+    if (capped) vs = vs > d->max_velocity ? d->max_velocity : (vs < -d->max_velocity ? -d->max_velocity : vs);
+    double t = Kp * (r_ref - q) + d->kd * (vs - qd);
+    if (d->torque_limit > 0) t = t > d->torque_limit ? d->torque_limit : (t < -d->torque_limit ? -d->torque_limit : t);
+    return t;
+}
+
+static int contact_force_sphere(const orc_dyn_params* d, const double pos[3], const double vel[3], double radius, double f[3])
 {
     int active = 0;
     f[0] = f[1] = f[2] = 0.0;
-    if (d->ground_z == d->ground_z) {                      /* plane z = ground_z, normal +z, pointer centre */
-        double depth = d->ground_z - pos[2];
+    if (d->ground_z == d->ground_z) {                      /* plane z = ground_z, normal +z; the POINTER touches with its
+                                                            * centre (r01 form, kept), a link sample with its surface */
+        double depth = d->ground_z - pos[2] + (d->link_contacts ? radius : 0.0);
         if (depth > 0) {
             double fz = d->contact_kp * depth - d->contact_kd * vel[2];
             if (fz > 0) { f[2] += fz; active = 1; }
@@ -264,7 +354,7 @@ int orc_dyn_contact_force(const orc_dyn_params* d, const double pos[3], const do
             sdf = qmax;                                    /* inside: push out through the nearest face */
             n[kmax] = dd[kmax] < 0 ? -1.0 : 1.0;
         }
-        double depth = d->pointer_radius - sdf;
+        double depth = radius - sdf;
         if (depth > 0) {
             double vn = vel[0] * n[0] + vel[1] * n[1] + vel[2] * n[2];
             double fn = d->contact_kp * depth - d->contact_kd * vn;
@@ -288,29 +378,24 @@ void orc_dyn_params_default(orc_dyn_params* d)
     d->obstacle_position[0] = 10.0; d->obstacle_position[1] = 5.0; d->obstacle_position[2] = 0.0;   /* pioneer_knm_env.py:253 */
     d->obstacle_half_extents[0] = d->obstacle_half_extents[1] = d->obstacle_half_extents[2] = 0.0;  /* disabled */
     d->pointer_radius = 0.2;                                                                          /* urdf:193 */
+    d->control_mode = 0; d->link_contacts = 0; d->max_velocity = 0.0;
 }
 
 void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state* s,
                      const double r_ref[ORC_DOF], const double v_ref[ORC_DOF])
 {
-    double tau[ORC_DOF], qdd[ORC_DOF], ftip[3] = {0, 0, 0};
-    const double* fext = NULL;
+    double tau[ORC_DOF], qdd[ORC_DOF], fext[ORC_DOF][6];
+    int have_ext = 0;
     for (int i = 0; i < ORC_DOF; i++) {
         double t = 0.0;
-        if (!d->teleport) {
-            t = d->kp * (r_ref[i] - s->q[i]) + d->kd * (v_ref[i] - s->qd[i]);
-            if (d->torque_limit > 0) t = t > d->torque_limit ? d->torque_limit : (t < -d->torque_limit ? -d->torque_limit : t);
-        }
+        if (!d->teleport) t = orc_dyn_motor_torque(d, r_ref[i], v_ref[i], s->q[i], s->qd[i]);
         t -= s->damping[i] * s->qd[i];
         t -= s->friction[i] * s->qd[i] / sqrt(s->qd[i] * s->qd[i] + FRICTION_EPS * FRICTION_EPS);
         tau[i] = t;
     }
-    if (d->ground_z == d->ground_z || d->obstacle_half_extents[0] > 0) {
-        double pos[3], vel[3];
-        orc_dyn_tip(s, pos, vel);
-        if (orc_dyn_contact_force(d, pos, vel, ftip)) fext = ftip;
-    }
-    orc_dyn_aba(s, tau, d->gravity, fext, qdd);
+    if (d->ground_z == d->ground_z || d->obstacle_half_extents[0] > 0)
+        have_ext = orc_dyn_contact_wrenches(d, s, fext);
+    orc_dyn_aba_ext(s, tau, d->gravity, have_ext ? (const double (*)[6])fext : NULL, qdd);
     for (int i = 0; i < ORC_DOF; i++) {          /* semi-implicit Euler + inelastic joint limits */
         s->qd[i] += qdd[i] * d->timestep;
         s->q[i] += s->qd[i] * d->timestep;

@@ -43,7 +43,18 @@ typedef struct orc_dyn_params {
     double contact_kp, contact_kd;
     double obstacle_position[3], obstacle_half_extents[3];   /* half extent <= 0: no box */
     double pointer_radius;
+    /* the rest of the reference's motor surface (bullet_scene.py:123-155) */
+    int32_t control_mode;     /* 0: POSITION_CONTROL (Joint.control_position), 1: VELOCITY_CONTROL (Joint.control_velocity: the
+                                 motor tracks the commanded velocity only, torque_limit is its `force`) */
+    int32_t link_contacts;    /* 0: only the pointer sphere collides; 1: sample spheres along every moving link too
+                                 (capsules fitted to the URDF's visual boxes, which carry no <collision> of their own) */
+    double max_velocity;      /* control_position's maxVelocity: cap on the velocity the motor asks for; <= 0 = none */
 } orc_dyn_params;
+
+#define ORC_CONTACT_SAMPLES 23
+/* the contact sample spheres: body (0-based moving body), position in that body's frame, radius (< 0: pointer_radius) */
+typedef struct orc_contact_sample { int32_t body; double c[3]; double radius; } orc_contact_sample;
+int orc_dyn_contact_samples(const orc_dyn_params* d, orc_contact_sample* out);   /* returns the number active (1 or 23) */
 
 typedef struct orc_dyn_state {
     double q[ORC_DOF], qd[ORC_DOF];
@@ -57,6 +68,16 @@ void orc_dyn_params_default(orc_dyn_params* d);
  * external force on the pointer (world frame, applied at the pointer origin) */
 void orc_dyn_aba(const orc_dyn_state* s, const double tau[ORC_DOF], double gravity,
                  const double f_tip_world[3], double qdd[ORC_DOF]);
+
+/* the same with an external spatial force on every body (body coordinates at the body origin, [n; f]) or NULL */
+void orc_dyn_aba_ext(const orc_dyn_state* s, const double tau[ORC_DOF], double gravity,
+                     const double fext[ORC_DOF][6], double qdd[ORC_DOF]);
+
+/* the motor torque of one joint (PD / velocity servo with the maxVelocity and force caps), before damping and friction */
+double orc_dyn_motor_torque(const orc_dyn_params* d, double r_ref, double v_ref, double q, double qd);
+
+/* penalty contact forces of all active sample spheres as per-body spatial forces; returns 1 if any contact is active */
+int orc_dyn_contact_wrenches(const orc_dyn_params* d, const orc_dyn_state* s, double fext[ORC_DOF][6]);
 
 /* kinetic energy and gravitational potential energy (for conservation tests) */
 void orc_dyn_energy(const orc_dyn_state* s, double gravity, double* kinetic, double* potential);

@@ -23,6 +23,7 @@ DYN_STATE_WORDS = 36
 PNR_OK = 0
 ENV_MAJOR, FEATURE_MAJOR = 0, 1
 MODE_KINEMATIC, MODE_DYNAMIC = 0, 1
+CONTROL_POSITION, CONTROL_VELOCITY = 0, 1
 
 
 class PnrError(RuntimeError):
@@ -51,6 +52,7 @@ class PnrConfig(C.Structure):
         ("ground_z", C.c_double), ("contact_kp", C.c_double), ("contact_kd", C.c_double),
         ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
         ("pointer_radius", C.c_double),
+        ("control_mode", C.c_int32), ("link_contacts", C.c_int32), ("max_velocity", C.c_double),
     ]
 
 

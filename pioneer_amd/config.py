@@ -87,10 +87,17 @@ class EngineConfig:
     obstacle_position: Tuple[float, float, float] = (10.0, 5.0, 0.0)
     obstacle_half_extents: Tuple[float, float, float] = (0.0, 0.0, 0.0)
     pointer_radius: float = 0.2
+    # the rest of the reference's motor surface (Joint.control_position / control_velocity, bullet_scene.py:123-155)
+    control_mode: str = "position"      # "position" (POSITION_CONTROL) | "velocity" (VELOCITY_CONTROL: tracks the commanded velocity)
+    max_velocity: float = 0.0           # control_position's maxVelocity: cap on the velocity the motor asks for; <= 0 = none
+    # contacts of the LINKS with the plane / box: sample spheres along capsules fitted to the URDF's visual boxes (the
+    # reference URDF carries no <collision> elements, so without this only the pointer sphere collides)
+    link_contacts: bool = False
 
 
 _LAYOUTS = {"env_major": _lib.ENV_MAJOR, "feature_major": _lib.FEATURE_MAJOR}
 _MODES = {"kinematic": _lib.MODE_KINEMATIC, "dynamic": _lib.MODE_DYNAMIC}
+_CONTROLS = {"position": _lib.CONTROL_POSITION, "velocity": _lib.CONTROL_VELOCITY}
 
 
 def to_c_config(pioneer: PioneerKinematicConfig, sim: SimulationConfig, engine: EngineConfig) -> _lib.PnrConfig:
@@ -130,4 +137,16 @@ def to_c_config(pioneer: PioneerKinematicConfig, sim: SimulationConfig, engine: 
         c.obstacle_position[k] = float(engine.obstacle_position[k])
         c.obstacle_half_extents[k] = float(engine.obstacle_half_extents[k])
     c.pointer_radius = float(engine.pointer_radius)
+    if engine.control_mode not in _CONTROLS:
+        raise AssertionError(f"control_mode must be one of {sorted(_CONTROLS)}")
+    c.control_mode = _CONTROLS[engine.control_mode]
+    c.max_velocity = float(engine.max_velocity)
+    c.link_contacts = int(bool(engine.link_contacts))
+    # SimulationConfig.self_collision / collision_parent (bullet_env.py:43-58) select pybullet's URDF_USE_SELF_COLLISION load
+    # flags.  The reference URDF has no <collision> elements, so in the reference they change nothing — and here they
+    # are accepted with that same meaning.  What is NOT modelled is self-collision between the build-defined link
+    # capsules: asking for both is refused rather than silently ignored.
+    if sim.self_collision and engine.link_contacts:
+        raise AssertionError("self_collision between the link capsules (EngineConfig.link_contacts) is not modelled; the "
+                             "reference's own URDF has no collision shapes, so self_collision alone is a no-op there and here")
     return c

@@ -294,7 +294,7 @@ __device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParam
 
 // Leading scalar arguments as in step_kernel: preloaded into SGPRs, they repeat P.state / D.dyn / P.actions /
 // P.n / P.dt / P.eps and carry max_v_to_r.
-template <bool OBS_EM, bool ACT_EM, bool RAND>
+template <bool OBS_EM, bool ACT_EM, bool RAND, bool CONTACT>
 __global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
                                                          const float* __restrict__ actions_, const long long n_,
                                                          const double dt_, const double eps_, const float max_v_to_r_,
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restric
         float4 k0[2] = {z4, z4}, k1[2] = {z4, z4}, k2[2] = {z4, z4};
         float q[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qd[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
-        if (e < n) dyn_substeps_lane<ACT_EM, RAND>(lead, D, e, k0, k1, k2, q, qd);
+        if (e < n) dyn_substeps_lane<ACT_EM, RAND, CONTACT>(lead, D, e, k0, k1, k2, q, qd);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             hrec[2 * lane + p] = k0[p];
@@ -505,7 +505,7 @@ __device__ __forceinline__ void dyn_rollout_tile(const KParams& P, const DynPara
 // The obs stores of step t drain under the sub-steps of step t + 1.  The hand-off has its own 9 KB here (the
 // kernel runs one wave per SIMD anyway), so a tile's values are read right before that tile is finished and
 // nothing of phase B is live during the sub-steps.
-template <bool OBS_EM, bool ACT_EM, bool RAND>
+template <bool OBS_EM, bool ACT_EM, bool RAND, bool CONTACT>
 __global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
                                                          const float* __restrict__ actions_, const long long n_,
                                                          const double dt_, const double eps_, const float max_v_to_r_,
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __rest
     const int T = P.T;
     for (int t = 0; t < T; ++t) {
         // ---- phase A: one env per lane
-        if (liveA) dyn_lane_advance<ACT_EM, RAND>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L);
+        if (liveA) dyn_lane_advance<ACT_EM, RAND, CONTACT>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L);
         dyn_write_handoff(hand, lane, L);
         rst[lane] = 0.f;                                // no reset noted yet (episode counters are >= 1)
         wave_lds_sync();
@@ -787,6 +787,7 @@ int pnr_config_default(pnr_config* c)
     c->obstacle_position[0] = 10.0; c->obstacle_position[1] = 5.0; c->obstacle_position[2] = 0.0;  // pioneer_knm_env.py:253
     c->obstacle_half_extents[0] = c->obstacle_half_extents[1] = c->obstacle_half_extents[2] = 0.0; // disabled
     c->pointer_radius = 0.2;
+    c->control_mode = PNR_CONTROL_POSITION; c->max_velocity = 0.0; c->link_contacts = 0;
     return PNR_OK;
 }
 
@@ -805,6 +806,10 @@ static int check_config(const pnr_config* c)
     if (c->mode != PNR_MODE_KINEMATIC && c->mode != PNR_MODE_DYNAMIC)
         return fail(nullptr, PNR_ERR_INVALID, "bad mode %d", c->mode);
     if (c->max_episode_steps < 0) return fail(nullptr, PNR_ERR_INVALID, "max_episode_steps < 0");
+    if (c->control_mode != PNR_CONTROL_POSITION && c->control_mode != PNR_CONTROL_VELOCITY)
+        return fail(nullptr, PNR_ERR_INVALID, "bad control_mode %d", c->control_mode);
+    if (c->max_velocity > 0 && !(c->pd_kd > 0))
+        return fail(nullptr, PNR_ERR_INVALID, "max_velocity needs pd_kd > 0 (the cap acts on the velocity the motor asks for)");
     for (int k = 0; k < 3; ++k)
         if (!(c->target_hi[k] >= c->target_lo[k]))
             return fail(nullptr, PNR_ERR_INVALID, "target_hi[%d] < target_lo[%d]", k, k);
@@ -856,6 +861,14 @@ static void fill_base(pnr_handle h)
     D.has_box = (c.obstacle_half_extents[0] > 0 && c.obstacle_half_extents[1] > 0 && c.obstacle_half_extents[2] > 0) ? 1 : 0;
     for (int k = 0; k < 3; ++k) { D.box_c[k] = (float)c.obstacle_position[k]; D.box_h[k] = (float)c.obstacle_half_extents[k]; }
     D.ptr_radius = (float)c.pointer_radius;
+    {   // the one motor law of pnr_dyn.h (oracle: orc_dyn_motor_torque)
+        const bool capped = c.max_velocity > 0;
+        const bool velocity = c.control_mode == PNR_CONTROL_VELOCITY;
+        D.kp_eff = (velocity || capped) ? 0.f : (float)c.pd_kp;
+        D.c_pos = (!velocity && capped) ? (float)(c.pd_kp / c.pd_kd) : 0.f;
+        D.v_cap = capped ? (float)c.max_velocity : INFINITY;
+    }
+    D.link_contacts = c.link_contacts ? 1 : 0;
     D.joint_damping = (float)c.joint_damping; D.joint_friction = (float)c.joint_friction;
     D.mass_lo = c.rand_mass_lo; D.mass_span = c.rand_mass_hi - c.rand_mass_lo;
     D.fric_lo = c.rand_friction_lo; D.fric_span = c.rand_friction_hi - c.rand_friction_lo;
@@ -1039,11 +1052,13 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
             const KParams& Pt = P;
             // T > 1: dyn_rollout_kernel loops over the steps inside the launch (state in registers, stores of step t
             // under the sub-steps of t + 1); T == 1: the lean single-step kernel
-#define PNR_DYN_LAUNCH(O, A, R) do { \
-        if (T > 1) hipLaunchKernelGGL((dyn_rollout_kernel<O, A, R>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
+#define PNR_DYN_LAUNCH2(O, A, R, C) do { \
+        if (T > 1) hipLaunchKernelGGL((dyn_rollout_kernel<O, A, R, C>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                       Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); \
-        else hipLaunchKernelGGL((dyn_step_kernel<O, A, R>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
+        else hipLaunchKernelGGL((dyn_step_kernel<O, A, R, C>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                 Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); } while (0)
+            // contact-free handles run instantiations without any contact code
+#define PNR_DYN_LAUNCH(O, A, R) do { if (D.has_ground || D.has_box) PNR_DYN_LAUNCH2(O, A, R, true); else PNR_DYN_LAUNCH2(O, A, R, false); } while (0)
             if (oem) {
                 if (aem) { if (rnd) PNR_DYN_LAUNCH(true, true, true); else PNR_DYN_LAUNCH(true, true, false); }
                 else { if (rnd) PNR_DYN_LAUNCH(true, false, true); else PNR_DYN_LAUNCH(true, false, false); }
@@ -1051,6 +1066,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
                 if (aem) { if (rnd) PNR_DYN_LAUNCH(false, true, true); else PNR_DYN_LAUNCH(false, true, false); }
                 else { if (rnd) PNR_DYN_LAUNCH(false, false, true); else PNR_DYN_LAUNCH(false, false, false); }
             }
+#undef PNR_DYN_LAUNCH2
 #undef PNR_DYN_LAUNCH
         }
         HIP_TRY(h, hipGetLastError());

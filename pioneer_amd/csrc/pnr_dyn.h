@@ -45,6 +45,10 @@ struct DynParams {
     float box_c[3], box_h[3], ptr_radius;   // static box obstacle for the pointer sphere
     float joint_damping, joint_friction;
     double mass_lo, mass_span, fric_lo, fric_span, damp_lo, damp_span;
+    // motor law (bullet_scene.py:123-155), one form for POSITION_CONTROL, its maxVelocity cap and VELOCITY_CONTROL:
+    //   tau = clip(kp_eff (r - q) + kd (clamp(v + c_pos (r - q), +-v_cap) - qd), +-tau_max)
+    float kp_eff, c_pos, v_cap;
+    int link_contacts;          // 1: the link capsules' sample spheres collide too (pnr_model.h kCapsules)
 };
 
 constexpr float kFrictionEps = 0.05f;   // smooth sign(qd) = qd / sqrt(qd^2 + eps^2)
@@ -458,31 +462,24 @@ __device__ __forceinline__ void pose_outward(const M3& Rp, V3 pp, float c, float
     R = {rot<AXJ>(Rp.r0, c, -s), rot<AXJ>(Rp.r1, c, -s), rot<AXJ>(Rp.r2, c, -s)};
 }
 
-// penalty contacts of the pointer sphere with the ground plane and the static box (the reference demo's
-// scene extras, pioneer_knm_env.py:249-261): the external spatial force on body 6, in body coordinates
-__device__ __forceinline__ P3 contact_force(const DynParams& D, const float (&c)[kDof], const float (&s)[kDof], const P3& v5)
+// Penalty contact of ONE sample sphere (centre c in the frame of the body whose world pose is R, p and whose spatial
+// velocity in body coordinates is vb) with the ground plane and the static axis-aligned box (the reference demo's scene
+// extras, pioneer_knm_env.py:249-261; create_body_plane / create_body_box, bullet_scene.py:206-228): the contact force
+// is added to the body's external spatial force in body coordinates.
+__device__ __forceinline__ void sample_contact(const DynParams& D, const M3& R, V3 p, const P3& vb, V3 c, float radius, P3& fext)
 {
-    M3 R = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, Rn;
-    V3 p = {0.f, 0.f, 0.f}, pn;
-    pose_outward<0>(R, p, c[0], s[0], Rn, pn); R = Rn; p = pn;
-    pose_outward<1>(R, p, c[1], s[1], Rn, pn); R = Rn; p = pn;
-    pose_outward<2>(R, p, c[2], s[2], Rn, pn); R = Rn; p = pn;
-    pose_outward<3>(R, p, c[3], s[3], Rn, pn); R = Rn; p = pn;
-    pose_outward<4>(R, p, c[4], s[4], Rn, pn); R = Rn; p = pn;
-    pose_outward<5>(R, p, c[5], s[5], Rn, pn); R = Rn; p = pn;
-    const V3 t = {(float)kTipX, (float)kTipY, (float)kTipZ};
-    const V3 tip = p + mul(R, t);                         // world position of the pointer
-    const V3 vb = lin(v5) + cross(ang(v5), t);
-    const V3 vw = mul(R, vb);                             // world velocity of the pointer
+    const V3 pos = p + mul(R, c);                           // world position of the sphere centre
+    const V3 vw = mul(R, lin(vb) + cross(ang(vb), c));      // its world velocity
     V3 F = {0.f, 0.f, 0.f};
     if (D.has_ground) {
-        const float depth = D.ground_z - tip.z;
+        // the pointer alone touches with its centre (the r01 form); with link contacts every sphere with its surface
+        const float depth = D.ground_z - pos.z + (D.link_contacts ? radius : 0.f);
         const float fz = D.ckp * depth - D.ckd * vw.z;
         if (depth > 0.f && fz > 0.f) F.z += fz;
     }
     if (D.has_box) {
-        // signed distance of the pointer centre to the axis-aligned box and its outward normal
-        const V3 dd = {tip.x - D.box_c[0], tip.y - D.box_c[1], tip.z - D.box_c[2]};
+        // signed distance of the centre to the axis-aligned box and its outward normal
+        const V3 dd = {pos.x - D.box_c[0], pos.y - D.box_c[1], pos.z - D.box_c[2]};
         const V3 q = {fabsf(dd.x) - D.box_h[0], fabsf(dd.y) - D.box_h[1], fabsf(dd.z) - D.box_h[2]};
         const V3 o = {fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f)};
         const float out2 = dot(o, o);
@@ -497,15 +494,51 @@ __device__ __forceinline__ P3 contact_force(const DynParams& D, const float (&c)
             nrm = {km == 0 ? (dd.x < 0.f ? -1.f : 1.f) : 0.f, km == 1 ? (dd.y < 0.f ? -1.f : 1.f) : 0.f,
                    km == 2 ? (dd.z < 0.f ? -1.f : 1.f) : 0.f};
         }
-        const float depth = D.ptr_radius - sdf;
+        const float depth = radius - sdf;
         const float fn = D.ckp * depth - D.ckd * dot(vw, nrm);
         if (depth > 0.f && fn > 0.f) F = F + fn * nrm;
     }
     const V3 fb = mulT(R, F);                             // R^T F
-    return pack(cross(t, fb), fb);
+    fext = fext + pack(cross(c, fb), fb);
 }
 
-// qdd = ABA(q, qd, tau); optional contacts on the pointer
+// every sample sphere of moving body BODY (compile-time table kCapsules); without link contacts only the pointer
+template <int BODY>
+__device__ __forceinline__ void body_contacts(const DynParams& D, const M3& R, V3 p, const P3& vb, P3& fext)
+{
+    static_for<kNumCapsules>([&](auto ci_) {
+        constexpr int ci = decltype(ci_)::value;
+        if constexpr (kCapsules[ci].body == BODY) {
+            static_for<kCapsules[ci].n>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                constexpr CapsuleDef K = kCapsules[ci];
+                constexpr float t = K.n > 1 ? (float)((double)i / (double)(K.n - 1)) : 0.f;
+                constexpr bool tip = (ci == kNumCapsules - 1) && (i == K.n - 1);
+                const V3 c = tip ? V3{(float)kTipX, (float)kTipY, (float)kTipZ}
+                                 : V3{K.ax + t * (K.bx - K.ax), K.ay + t * (K.by - K.ay), K.az + t * (K.bz - K.az)};
+                if (tip || D.link_contacts) sample_contact(D, R, p, vb, c, K.radius < 0.f ? D.ptr_radius : K.radius, fext);
+            });
+        }
+    });
+}
+
+// the external spatial force of all active contacts on every body, in body coordinates
+__device__ __forceinline__ void contact_wrenches(const DynParams& D, const float (&c)[kDof], const float (&s)[kDof],
+                                                 const P3 (&v)[kDof], P3 (&fext)[kDof])
+{
+    M3 R = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}, Rn;
+    V3 p = {0.f, 0.f, 0.f}, pn;
+    pose_outward<0>(R, p, c[0], s[0], Rn, pn); R = Rn; p = pn;          // body 0 (rotator1 + hinge1) carries no samples
+    pose_outward<1>(R, p, c[1], s[1], Rn, pn); R = Rn; p = pn; body_contacts<1>(D, R, p, v[1], fext[1]);
+    pose_outward<2>(R, p, c[2], s[2], Rn, pn); R = Rn; p = pn; body_contacts<2>(D, R, p, v[2], fext[2]);
+    pose_outward<3>(R, p, c[3], s[3], Rn, pn); R = Rn; p = pn; body_contacts<3>(D, R, p, v[3], fext[3]);
+    pose_outward<4>(R, p, c[4], s[4], Rn, pn); R = Rn; p = pn; body_contacts<4>(D, R, p, v[4], fext[4]);
+    pose_outward<5>(R, p, c[5], s[5], Rn, pn); R = Rn; p = pn; body_contacts<5>(D, R, p, v[5], fext[5]);
+}
+
+// qdd = ABA(q, qd, tau).  CONTACT: the penalty contacts' external forces are subtracted from the bodies' bias forces
+// (a separate instantiation: the contact-free kernels carry none of that code or its registers)
+template <bool CONTACT>
 __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const float (&q)[kDof], const float (&qd)[kDof],
                                     const float (&tau)[kDof], float (&qdd)[kDof])
 {
@@ -523,18 +556,29 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
     vel_outward<4>(v[3], c[4], s[4], qd[4], v[4]);
     vel_outward<5>(v[4], c[5], s[5], qd[5], v[5]);
 
+    P3 fext[kDof];
+    if (CONTACT) {
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) fext[i] = v0;
+        contact_wrenches(D, c, s, v, fext);
+    }
+
     // pass 2: tip -> base
     DynBody B[kDof];
     SIp IA, IP; P3 pA, pP;
     rigid_body<5>(M, v[5], IA, pA);
-    if (D.has_ground || D.has_box) pA = pA - contact_force(D, c, s, v[5]);
+    if (CONTACT) pA = pA - fext[5];
     rigid_body<4>(M, v[4], IP, pP);
+    if (CONTACT) pP = pP - fext[4];
     aba_inward<5>(IA, pA, v[5], qd[5], tau[5], c[5], s[5], B[5], IP, pP);
     IA = IP; pA = pP; rigid_body<3>(M, v[3], IP, pP);
+    if (CONTACT) pP = pP - fext[3];
     aba_inward<4>(IA, pA, v[4], qd[4], tau[4], c[4], s[4], B[4], IP, pP);
     IA = IP; pA = pP; rigid_body<2>(M, v[2], IP, pP);
+    if (CONTACT) pP = pP - fext[2];
     aba_inward<3>(IA, pA, v[3], qd[3], tau[3], c[3], s[3], B[3], IP, pP);
     IA = IP; pA = pP; rigid_body<1>(M, v[1], IP, pP);
+    if (CONTACT) pP = pP - fext[1];
     aba_inward<2>(IA, pA, v[2], qd[2], tau[2], c[2], s[2], B[2], IP, pP);
     IA = IP; pA = pP; rigid_body<0>(M, v[0], IP, pP);
     aba_inward<1>(IA, pA, v[1], qd[1], tau[1], c[1], s[1], B[1], IP, pP);
@@ -638,6 +682,7 @@ __device__ __forceinline__ void dyn_lane_load(const DynLead& in, long long base,
 // ---------------------------------------------------------------------------------
 // The arithmetic of phase A, shared by the single-step and the rollout kernels (one text, so that both produce
 // the same bits): command integration with the action latched for the next step, then nsub sub-steps of ABA + PD.
+template <bool CONTACT>
 __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, float (&a)[kDof], float (&v)[kDof],
                                          float (&r)[kDof], float (&q)[kDof], float (&qd)[kDof], const float (&sc)[kNumLinks],
                                          const float (&fric)[kDof], const float (&damp)[kDof], const float (&act)[kDof])
@@ -658,19 +703,22 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
     }
     // wave-uniform options folded into the arithmetic once, so the sub-step loop carries no branches:
     // teleport = no motor torque (gains 0), no torque cap = cap at +inf
-    const float kp = D.teleport ? 0.f : D.kp, kd = D.teleport ? 0.f : D.kd;
+    const float kp = D.teleport ? 0.f : D.kp_eff, kd = D.teleport ? 0.f : D.kd;
+    const float cpos = D.c_pos, vcap = D.v_cap;            // 0 and +inf for the plain PD motor: v_ask == v[i] exactly
     const float tcap = D.tau_max > 0.f ? D.tau_max : __builtin_inff();
     for (int k = 0; k < D.nsub; ++k) {
         float tau[kDof], qdd[kDof];
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {
-            float tq = kp * (r[i] - q[i]) + kd * (v[i] - qd[i]);
+            const float dq = r[i] - q[i];
+            const float v_ask = fminf(fmaxf(v[i] + cpos * dq, -vcap), vcap);
+            float tq = kp * dq + kd * (v_ask - qd[i]);
             tq = fminf(fmaxf(tq, -tcap), tcap);
             tq -= damp[i] * qd[i];
             tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
             tau[i] = tq;
         }
-        aba(D, M, q, qd, tau, qdd);
+        aba<CONTACT>(D, M, q, qd, tau, qdd);
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits (selects, no branches)
             const float hi = limit_hi(i), lo = limit_lo(i);
@@ -683,7 +731,7 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
     }
 }
 
-template <bool ACT_EM, bool RAND>
+template <bool ACT_EM, bool RAND, bool CONTACT>
 __device__ __forceinline__ void dyn_lane_advance(const DynLead& in, const DynParams& D, long long base, int lane,
                                                  const float* __restrict__ next_actions, DynLane& L)
 {
@@ -692,7 +740,7 @@ __device__ __forceinline__ void dyn_lane_advance(const DynLead& in, const DynPar
     for (int i = 0; i < kDof; ++i) act[i] = L.act[i];
     // the action after this one is requested now: it arrives under the sub-steps (next_actions: null on the last step)
     if (next_actions) dyn_load_action<ACT_EM>(next_actions, in.n, base, lane, L.act);
-    dyn_core(in, D, L.a, L.v, L.r, L.q, L.qd, L.sc, L.fric, L.damp, act);
+    dyn_core<CONTACT>(in, D, L.a, L.v, L.r, L.q, L.qd, L.sc, L.fric, L.damp, act);
 }
 
 // The per-env parameter draws of a reset: Philox blocks 3..8 of the env's counter (the joints and the target
@@ -727,7 +775,7 @@ __device__ __forceinline__ void dyn_draw_params(const KParams& P, const DynParam
 // the single-step kernel (A/B inside one library: 32.15 vs 32.85 us per 65 536-env step; SQ_WAIT_INST_ANY +40 %).
 // In: nothing but the env index.  Out: the env's two state records as they lie in HBM (a, v, r updated), q, qd.
 // ---------------------------------------------------------------------------------
-template <bool ACT_EM, bool RAND>
+template <bool ACT_EM, bool RAND, bool CONTACT>
 __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynParams& D, long long e,
                                                   float4 (&k0)[2], float4 (&k1)[2], float4 (&k2)[2],
                                                   float (&q)[kDof], float (&qd)[kDof])
@@ -764,7 +812,7 @@ __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynPa
 #pragma unroll
         for (int i = 0; i < kDof; ++i) act[i] = in.actions[(long long)i * n + e];
     }
-    dyn_core(in, D, a, v, r, q, qd, sc, fric, damp, act);
+    dyn_core<CONTACT>(in, D, a, v, r, q, qd, sc, fric, damp, act);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         k0[p] = make_float4(a[3 * p], a[3 * p + 1], a[3 * p + 2], v[3 * p]);

@@ -66,4 +66,19 @@ constexpr int kLinkBody[kNumLinks] = {-1, 0, 0, 1, 2, 3, 3, 4, 5, 5, 5};
 constexpr double kLinkMass = 1.0;
 constexpr double kLinkInertia = 1.0;
 
+// Contact sample spheres of dynamics mode.  The reference URDF has <visual> but no <collision> elements, so only the
+// pointer's sphere (urdf:190-196) is the reference's own; the link samples are capsules fitted to the visual boxes
+// (arm1 urdf:78-90, arm2 :92-104, rotator2 + hinge2 :106-132, arm3 :134-153, effector :169-188): n spheres of the
+// given radius from a to b in the frame of moving body `body` (0-based).  radius < 0 = pointer_radius; the last
+// sample of the last capsule IS the pointer sphere.  Spacing <= sphere diameter + the demo obstacle's width.
+struct CapsuleDef { int body; float ax, ay, az, bx, by, bz; int n; float radius; };
+constexpr int kNumCapsules = 5;
+constexpr CapsuleDef kCapsules[kNumCapsules] = {
+    {1, 0.f, 0.f, 0.f, 0.f, 0.f, 11.f, 8, 0.7f},
+    {2, -1.f, 1.f, 0.f, 9.f, 1.f, 0.f, 7, 0.7f},
+    {3, 9.f, 0.f, 0.f, 11.f, 0.f, 0.f, 2, 0.7f},
+    {4, -0.5f, 0.f, 0.f, 2.5f, 0.f, 0.f, 3, 0.6f},
+    {5, 3.6f, 0.f, -0.75f, 3.6f, 0.f, 1.9f, 3, -1.0f},
+};
+
 }  // namespace pnr

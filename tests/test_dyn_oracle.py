@@ -211,3 +211,133 @@ def test_box_contact_force_geometry(oracle_built):
     k = 0.1 / np.sqrt(2)
     act, f = force((10.5 + k, 5.5 + k, 1.0))                                   # off an edge: normal along the diagonal
     assert act == 1 and abs(f[0] - f[1]) < 1e-9 and f[2] == 0 and abs(np.linalg.norm(f) - 2000.0 * 0.1) < 1e-6
+
+
+# ---- the rest of the reference's motor surface (bullet_scene.py:123-155) and link contacts (r02) -----------------------
+def body_point_world(q, body, c):
+    """World position of point c (body frame) of moving body `body` (0-based, fixed joints merged): the body frame is
+    the frame right behind revolute joint `body`."""
+    frames, joints = link_frames(q)
+    R, p = frames[joints[body][2]]
+    return p + R @ np.asarray(c, dtype=float)
+
+
+def test_motor_law_forms(oracle_built):
+    pd = DynOracle(1, dyn=dict(kp=4000.0, kd=400.0))
+    assert pd.motor_torque(0.3, 1.0, 0.1, -0.5) == 4000.0 * (0.3 - 0.1) + 400.0 * (1.0 - -0.5)     # plain PD, r01 arithmetic
+    lim = DynOracle(1, dyn=dict(kp=4000.0, kd=400.0, torque_limit=500.0))
+    assert lim.motor_torque(0.3, 1.0, 0.1, -0.5) == 500.0 and lim.motor_torque(-0.3, 0.0, 0.1, 0.0) == -500.0
+    cap = DynOracle(1, dyn=dict(kp=4000.0, kd=400.0, max_velocity=1e9))
+    assert abs(cap.motor_torque(0.3, 1.0, 0.1, -0.5) - pd.motor_torque(0.3, 1.0, 0.1, -0.5)) < 1e-9  # inactive cap == the PD
+    cap = DynOracle(1, dyn=dict(kp=4000.0, kd=400.0, max_velocity=0.5))
+    # asked-for velocity 1.0 + 10 * 0.2 = 3.0 -> capped at 0.5: tau = kd (0.5 - qd)
+    assert abs(cap.motor_torque(0.3, 1.0, 0.1, -0.5) - 400.0 * (0.5 - -0.5)) < 1e-12
+    vel = DynOracle(1, dyn=dict(kp=4000.0, kd=400.0, control_mode=1))
+    assert vel.motor_torque(123.0, 1.0, 0.1, -0.5) == 400.0 * (1.0 - -0.5)                          # the position target is ignored
+
+
+def test_max_velocity_caps_the_joint_speed(oracle_built):
+    """A 2 rad position step on the wrist joint: the PD motor overshoots 4 rad/s on the way, the capped one never asks
+    for more than 1 rad/s and still arrives."""
+    peak = {}
+    for name, vmax in (("pd", 0.0), ("capped", 1.0)):
+        o = DynOracle(1, dyn=dict(kp=4000.0, kd=400.0, max_velocity=vmax))
+        set_state(o, np.zeros(6), np.zeros(6))
+        r = np.zeros(6); r[5] = 2.0
+        speeds = []
+        for _ in range(1200):
+            o.substep(r, np.zeros(6))
+            speeds.append(abs(o.dstate["qd"][0][5]))
+        peak[name] = max(speeds)
+        assert abs(o.dstate["q"][0][5] - 2.0) < 2e-2
+    assert peak["pd"] > 4.0 and peak["capped"] <= 1.0 + 1e-3     # the motor never ASKS for more; coupling adds a hair
+
+
+def test_velocity_control_tracks_the_commanded_velocity(oracle_built):
+    o = DynOracle(1, dyn=dict(kp=4000.0, kd=400.0, control_mode=1))
+    set_state(o, np.zeros(6), np.zeros(6))
+    v = np.array([0.2, 0.0, 0.0, 0.5, 0.0, -0.7])
+    for _ in range(480):                                     # 2 s (before the wrist joints reach their limits)
+        o.substep(np.full(6, 99.0), v)                       # r is ignored in this mode
+    err = np.abs(o.dstate["qd"][0] - v)
+    assert err[1:].max() < 2e-2 and err[0] < 8e-2            # the heavy base joint's time constant I / kd is ~1 s
+
+
+def test_contact_samples_cover_the_links(oracle_built):
+    o = DynOracle(1, dyn=dict(link_contacts=1))
+    smp = o.contact_samples()
+    assert len(smp) == 23 and sorted({b for b, _, _ in smp}) == [1, 2, 3, 4, 5]
+    assert np.allclose(smp[-1][1], [3.6, 0.0, 1.9]) and smp[-1][2] < 0          # the last sample is the pointer sphere
+    # neighbours on one link are never further apart than their diameter + the demo obstacle's width (no tunnelling)
+    for (b0, c0, r0), (b1, c1, r1) in zip(smp[:-1], smp[1:]):
+        if b0 == b1:
+            assert np.linalg.norm(c1 - c0) <= 2 * abs(r0 if r0 > 0 else 0.2) + 1.0 + 1e-9
+    assert len(DynOracle(1).contact_samples()) == 1                              # default: the pointer alone
+
+
+def test_link_contact_wrenches_equal_generalised_forces(oracle_built):
+    """ABA with the per-body contact wrenches == ABA with tau + sum_k J_k^T F_k (Jacobians of the sample points by
+    finite differences of an independent FK): the force transformation into body coordinates is right."""
+    rng = np.random.RandomState(5)
+    o = DynOracle(1, dyn=dict(link_contacts=1, ground_z=9.0, contact_kp=2000.0, contact_kd=50.0, gravity=9.81,
+                              obstacle_position=(8.0, 1.0, 6.0), obstacle_half_extents=(2.0, 2.0, 2.0)))
+    hits = 0
+    for trial in range(40):
+        q = rng.uniform(-1.0, 1.0, 6); qd = rng.uniform(-1.0, 1.0, 6); tau = rng.uniform(-50, 50, 6)
+        set_state(o, q, qd)
+        active, fext = o.contact_wrenches()
+        if not active:
+            continue
+        hits += 1
+        # generalised force of the same contacts: world forces recomputed here from the oracle's own force law per sample
+        import ctypes as C
+        Q = np.zeros(6)
+        for b, c, rad in o.contact_samples():
+            pos = body_point_world(q, b, c)
+            J = np.zeros((3, 6))
+            for k in range(6):
+                e = np.zeros(6); e[k] = 1e-6
+                J[:, k] = (body_point_world(q + e, b, c) - body_point_world(q - e, b, c)) / 2e-6
+            vel = J @ qd
+            f = np.zeros(3)
+            radius = o.d.pointer_radius if rad < 0 else rad
+            # plane
+            depth = 9.0 - pos[2] + radius
+            if depth > 0:
+                fz = 2000.0 * depth - 50.0 * vel[2]
+                if fz > 0:
+                    f[2] += fz
+            # box (outside or inside)
+            dd = pos - np.array([8.0, 1.0, 6.0]); qq = np.abs(dd) - 2.0; oo = np.maximum(qq, 0)
+            if (oo > 0).any():
+                sdf = np.linalg.norm(oo); nrm = np.sign(dd) * oo / sdf
+            else:
+                km = int(np.argmax(qq)); sdf = qq[km]; nrm = np.zeros(3); nrm[km] = 1.0 if dd[km] >= 0 else -1.0
+            dep = radius - sdf
+            if dep > 0:
+                fn = 2000.0 * dep - 50.0 * float(vel @ nrm)
+                if fn > 0:
+                    f += fn * nrm
+            Q += J.T @ f
+        a = o.aba_ext(tau, 9.81, fext)
+        b_ = o.aba_ext(tau + Q, 9.81, None)
+        assert np.allclose(a, b_, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(b_).max())), (trial, a, b_)
+    assert hits >= 10
+
+
+def test_an_arm_link_rests_on_the_ground_plane(oracle_built):
+    """Released horizontally above a plane that only the LINK samples can reach first (the pointer ends higher): without
+    link contacts arm2 sinks through, with them it is held."""
+    z = np.zeros(6)
+    low = {}
+    for name, links in (("pointer_only", 0), ("links", 1)):
+        o = DynOracle(1, dyn=dict(teleport=1, gravity=9.81, ground_z=12.5, contact_kp=4000.0, contact_kd=100.0, link_contacts=links))
+        q0 = np.zeros(6); q0[4] = -1.2                       # wrist pitched up: the pointer sits well above arm2
+        set_state(o, q0, np.zeros(6))
+        zmin = 1e9
+        for _ in range(1500):
+            o.substep(z, z)
+            zmin = min(zmin, body_point_world(o.dstate["q"][0], 2, [9.0, 1.0, 0.0])[2])      # far end of arm2
+        low[name] = zmin
+    assert low["links"] > 12.5 - 0.7 - 0.6                   # held near the plane (sphere radius 0.7 + bounded penetration)
+    assert low["pointer_only"] < low["links"] - 1.0
