@@ -21,7 +21,8 @@ def main():
     cols = lambda t: [r[1] for r in c.execute(f"pragma table_info({t})")]   # noqa: E731
     pecols, picols = cols(pe), cols(pi)
     name_col = "name" if "name" in picols else [x for x in picols if "name" in x][0]
-    q = (f"select s.kernel_name, p.{name_col}, count(*), sum(e.value), avg(d.end - d.start) from {pe} e "
+    # a dispatch has one row per counter INSTANCE (XCD / shader engine): sum them, then average over dispatches
+    q = (f"select s.kernel_name, p.{name_col}, count(distinct d.id), sum(e.value), avg(d.end - d.start) from {pe} e "
          f"join {pi} p on e.pmc_id = p.id join {kd} d on d.event_id = e.event_id join {ks} s on d.kernel_id = s.id "
          f"group by s.kernel_name, p.{name_col}")
     out = {}
