@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libpioneer_amd.so")
+# PNR_LIB_PATH: load another build of the library (A/B experiments such as tools/build_variant.py's); default in-tree
+LIB_PATH = os.environ.get("PNR_LIB_PATH") or os.path.join(CSRC, "libpioneer_amd.so")
 SOURCES = ["pnr_api.hip", "pnr_device.h", "pnr_dyn.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pioneer_amd.h")
 
@@ -126,8 +127,11 @@ def _stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> pioneer_amd/csrc/libpioneer_amd.so (in-tree)."""
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None) -> str:
+    """hipcc --offload-arch=gfx950 -> pioneer_amd/csrc/libpioneer_amd.so (in-tree).  extra_flags / out_path build a
+    variant next to it (e.g. -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B)."""
+    if out_path is not None:
+        force = True
     if not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -136,12 +140,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-slp-vectorize",
            "-mllvm", "-amdgpu-kernarg-preload-count=16",     # leading scalar kernel args arrive preloaded in SGPRs
-           "-Wall", "-Wno-unused-function",
-           "-o", LIB_PATH, os.path.join(CSRC, "pnr_api.hip")]
+           "-Wall", "-Wno-unused-function", *extra_flags,
+           "-o", out_path or LIB_PATH, os.path.join(CSRC, "pnr_api.hip")]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB_PATH
+    return out_path or LIB_PATH
 
 
 _lib = None

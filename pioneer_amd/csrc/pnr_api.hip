@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restric
         float4 k0[2] = {z4, z4}, k1[2] = {z4, z4}, k2[2] = {z4, z4};
         float q[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qd[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
-        if (e < n) dyn_substeps_lane<ACT_EM, RAND, CONTACT>(lead, D, e, k0, k1, k2, q, qd);
+        if (e < n) dyn_substeps_lane<ACT_EM, RAND, CONTACT>(lead, D, e, k0, k1, k2, q, qd, tile);   // tile: free during phase A
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             hrec[2 * lane + p] = k0[p];
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __rest
                                                          const double dt_, const double eps_, const float max_v_to_r_,
                                                          const KParams P, const DynParams D)
 {
-    __shared__ __attribute__((aligned(16))) float lds[kTileFloats + kComFloats + kRstFloats + kHandFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kTileFloats + kComFloats + kRstFloats + kHandFloats + (PNR_DYN_LDS_MODEL ? kDynStageWords * 64 : 0)];
     float* tile = lds;
     float4* com = reinterpret_cast<float4*>(lds + kTileFloats);   // [2][64] common words between steps, index tile * 64 + lane
     float* rst = lds + kTileFloats + kComFloats;                  // [7][64] reset notes, phase B -> phase A
@@ -543,7 +543,8 @@ __global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __rest
     const int T = P.T;
     for (int t = 0; t < T; ++t) {
         // ---- phase A: one env per lane
-        if (liveA) dyn_lane_advance<ACT_EM, RAND, CONTACT>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L);
+        if (liveA) dyn_lane_advance<ACT_EM, RAND, CONTACT>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L,
+                                                           lds + kTileFloats + kComFloats + kRstFloats + kHandFloats);
         dyn_write_handoff(hand, lane, L);
         rst[lane] = 0.f;                                // no reset noted yet (episode counters are >= 1)
         wave_lds_sync();
@@ -1130,10 +1131,13 @@ int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, co
 }
 
 // ---- the host driver's MLPs (pnr_mlp.h) ------------------------------------------------------------------------
+// 32 slices x 4 roles x 2 nets = 256 workgroups = one per CU, one round; 64 slices (two rounds) wrote and re-read twice the
+// slab bytes for the same time in the multiply loop
+constexpr long long kMaxSlices = 32;
 static inline void mlp_slicing(long long B, long long* slices, long long* slice_rows)
 {
     long long want = (B + kWgChunk - 1) / kWgChunk;          // at most one slice per 64-sample chunk ...
-    if (want > 64) want = 64;                                // ... and at most 64 slices (slab traffic)
+    if (want > kMaxSlices) want = kMaxSlices;                // ... and few enough that slices x 4 roles x 2 nets fill the CUs ONCE
     if (want < 1) want = 1;
     long long rows = (B + want - 1) / want;
     rows = (rows + kWgChunk - 1) / kWgChunk * kWgChunk;
@@ -1209,7 +1213,7 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     MlpWgradParams Wp;
     Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
     Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, 4, kMlpNets), dim3(kMlpThreads), 0, st, Wp);
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kMlpThreads), 0, st, Wp);
     MlpReduceParams Rp;
     Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate; Rp.scale = scale;
     for (int n = 0; n < kMlpNets; ++n) {
@@ -1299,7 +1303,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     MlpWgradParams Wp;
     Wp.g_head = s->g_head; Wp.xs = F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
     Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, 4, kMlpNets), thr, 0, st, Wp);
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), thr, 0, st, Wp);
     if (s->flat_grad)
         hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((kMlpNets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad);
     else

@@ -682,10 +682,20 @@ __device__ __forceinline__ void dyn_lane_load(const DynLead& in, long long base,
 // ---------------------------------------------------------------------------------
 // The arithmetic of phase A, shared by the single-step and the rollout kernels (one text, so that both produce
 // the same bits): command integration with the action latched for the next step, then nsub sub-steps of ABA + PD.
+// PNR_DYN_LDS_MODEL=1 (a build-time A/B, north_star's "per-link spatial inertias staged in LDS"): the env's rigid-body model
+// (6 masses, first moment and 6 inertia entries of body 6) and its 12 friction / damping coefficients are written to a
+// per-lane LDS slice [kDynStageWords][64] once per step and re-read at the top of every sub-step instead of living in
+// ~33 registers across the loop.  Default 0: everything in registers (the measured winner).
+#ifndef PNR_DYN_LDS_MODEL
+#define PNR_DYN_LDS_MODEL 0
+#endif
+constexpr int kDynStageWords = 33;
+
 template <bool CONTACT>
 __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, float (&a)[kDof], float (&v)[kDof],
                                          float (&r)[kDof], float (&q)[kDof], float (&qd)[kDof], const float (&sc)[kNumLinks],
-                                         const float (&fric)[kDof], const float (&damp)[kDof], const float (&act)[kDof])
+                                         const float (&fric_)[kDof], const float (&damp_)[kDof], const float (&act)[kDof],
+                                         float* stage = nullptr)
 {
 #pragma unroll
     for (int i = 0; i < kDof; ++i) {
@@ -696,6 +706,19 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
 
     DynModel M;
     build_model(sc, M);
+    float fric[kDof], damp[kDof];
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { fric[i] = fric_[i]; damp[i] = damp_[i]; }
+#if PNR_DYN_LDS_MODEL
+    {
+        float* w = stage + (threadIdx.x & 63);
+#pragma unroll
+        for (int i = 0; i < kDof; ++i) { w[i * 64] = M.m[i]; w[(6 + i) * 64] = fric[i]; w[(12 + i) * 64] = damp[i]; }
+        w[18 * 64] = M.h6.x; w[19 * 64] = M.h6.y; w[20 * 64] = M.h6.z;
+        w[21 * 64] = M.I6.r0.x; w[22 * 64] = M.I6.r0.y; w[23 * 64] = M.I6.r0.z;
+        w[24 * 64] = M.I6.r1.y; w[25 * 64] = M.I6.r1.z; w[26 * 64] = M.I6.r2.z;
+    }
+#endif
 
     if (D.teleport) {   // resetJointState semantics: pioneer_knm_env.py:148, bullet_scene.py:157-165
 #pragma unroll
@@ -708,6 +731,18 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
     const float tcap = D.tau_max > 0.f ? D.tau_max : __builtin_inff();
     for (int k = 0; k < D.nsub; ++k) {
         float tau[kDof], qdd[kDof];
+#if PNR_DYN_LDS_MODEL
+        {   // re-read the staged model: the offset is opaque per iteration, so nothing is hoisted out of the loop
+            int off = threadIdx.x & 63;
+            asm volatile("" : "+v"(off));
+            const float* w = stage + off;
+#pragma unroll
+            for (int i = 0; i < kDof; ++i) { M.m[i] = w[i * 64]; fric[i] = w[(6 + i) * 64]; damp[i] = w[(12 + i) * 64]; }
+            M.h6 = {w[18 * 64], w[19 * 64], w[20 * 64]};
+            const float i01 = w[22 * 64], i02 = w[23 * 64], i12 = w[25 * 64];
+            M.I6 = {{w[21 * 64], i01, i02}, {i01, w[24 * 64], i12}, {i02, i12, w[26 * 64]}};
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {
             const float dq = r[i] - q[i];
@@ -733,14 +768,14 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
 
 template <bool ACT_EM, bool RAND, bool CONTACT>
 __device__ __forceinline__ void dyn_lane_advance(const DynLead& in, const DynParams& D, long long base, int lane,
-                                                 const float* __restrict__ next_actions, DynLane& L)
+                                                 const float* __restrict__ next_actions, DynLane& L, float* stage = nullptr)
 {
     float act[kDof];
 #pragma unroll
     for (int i = 0; i < kDof; ++i) act[i] = L.act[i];
     // the action after this one is requested now: it arrives under the sub-steps (next_actions: null on the last step)
     if (next_actions) dyn_load_action<ACT_EM>(next_actions, in.n, base, lane, L.act);
-    dyn_core<CONTACT>(in, D, L.a, L.v, L.r, L.q, L.qd, L.sc, L.fric, L.damp, act);
+    dyn_core<CONTACT>(in, D, L.a, L.v, L.r, L.q, L.qd, L.sc, L.fric, L.damp, act, stage);
 }
 
 // The per-env parameter draws of a reset: Philox blocks 3..8 of the env's counter (the joints and the target
@@ -778,7 +813,7 @@ __device__ __forceinline__ void dyn_draw_params(const KParams& P, const DynParam
 template <bool ACT_EM, bool RAND, bool CONTACT>
 __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynParams& D, long long e,
                                                   float4 (&k0)[2], float4 (&k1)[2], float4 (&k2)[2],
-                                                  float (&q)[kDof], float (&qd)[kDof])
+                                                  float (&q)[kDof], float (&qd)[kDof], float* stage = nullptr)
 {
     const long long n = in.n;
     const long long n2 = 2 * n;
@@ -812,7 +847,7 @@ __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynPa
 #pragma unroll
         for (int i = 0; i < kDof; ++i) act[i] = in.actions[(long long)i * n + e];
     }
-    dyn_core<CONTACT>(in, D, a, v, r, q, qd, sc, fric, damp, act);
+    dyn_core<CONTACT>(in, D, a, v, r, q, qd, sc, fric, damp, act, stage);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         k0[p] = make_float4(a[3 * p], a[3 * p + 1], a[3 * p + 2], v[3 * p]);

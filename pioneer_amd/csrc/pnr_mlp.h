@@ -30,15 +30,29 @@ constexpr int kMlpInPad = 144;    // K of the first layer, padded to a multiple 
 constexpr int kMlpHid = 256;      // fcnet_hiddens [256, 256] (pioneer_knm_train.py:60)
 constexpr int kMlpHead = 16;      // head rows: 12 (6 means + 6 log-stds) or 1 (value), zero-padded to 16
 constexpr int kMlpNets = 2;       // policy, value
-constexpr int kMlpBM = 128;       // samples per workgroup tile (forward / backward-data)
+#ifndef PNR_MLP_BM
+#define PNR_MLP_BM 64
+#endif
+constexpr int kMlpBM = PNR_MLP_BM;   // samples per workgroup tile (forward / backward-data): 64 -> 53 / 71 KB of LDS and <= 256
+                                     // registers, i.e. two workgroups per CU whose phases overlap; 128 -> one (A/B in DESIGN.md)
+constexpr int kMlpCB = kMlpBM / 32;  // 32-sample column blocks per tile
+static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implemented");
+// PNR_MLP_DIAG: timing-only ablations of the forward kernel (results are wrong when set; tools/mlp_ablation.py)
+#ifndef PNR_MLP_DIAG
+#define PNR_MLP_DIAG 0
+#endif
 constexpr int kMlpThreads = 256;  // four waves
 
-// packed bf16 weights of ONE net, element offsets
-constexpr int kOffW1 = 0;                                  // [256][144]
-constexpr int kOffW2 = kOffW1 + kMlpHid * kMlpInPad;       // [256][256]
-constexpr int kOffW3 = kOffW2 + kMlpHid * kMlpHid;         // [16][256]
-constexpr int kOffW2T = kOffW3 + kMlpHead * kMlpHid;       // [256][256]  W2T[i][o] = W2[o][i]
-constexpr int kOffW3T = kOffW2T + kMlpHid * kMlpHid;       // [256][16]   W3T[f][r] = W3[r][f]
+// packed bf16 weights of ONE net, element offsets.  Every matrix is stored FRAGMENT-NATIVE: the 32 x 16 (or 16 x 32) block
+// that one MFMA consumes as its A operand is 1 KiB contiguous in lane order, so a wave's fragment load is one fully
+// coalesced dwordx4 instruction (8 whole 128-byte lines).  Row-major weights made every fragment load touch 32
+// different lines for 32 bytes each: 16.9 M L2 requests per 131 072-sample forward, the kernel's bottleneck
+// (profiles/r02_d_mlp_forward_counters.json); the permutation costs nothing, the packing kernels apply it.
+constexpr int kOffW1 = 0;                                  // [256][144]  as (rows / 32) x 9 blocks
+constexpr int kOffW2 = kOffW1 + kMlpHid * kMlpInPad;       // [256][256]  as 8 x 16 blocks
+constexpr int kOffW3 = kOffW2 + kMlpHid * kMlpHid;         // [16][256]   as 8 blocks of 16 x 32
+constexpr int kOffW2T = kOffW3 + kMlpHead * kMlpHid;       // [256][256]  W2T[i][o] = W2[o][i], 8 x 16 blocks
+constexpr int kOffW3T = kOffW2T + kMlpHid * kMlpHid;       // [256][16]   W3T[f][r] = W3[r][f], 8 x 1 blocks
 constexpr int kPackElems = kOffW3T + kMlpHid * kMlpHead;   // 176 128
 constexpr int kBiasElems = 2 * kMlpHid + kMlpHead;         // b1[256] b2[256] b3[16], float32
 
@@ -50,6 +64,18 @@ constexpr int kGB1 = kGW3 + kMlpHead * kMlpHid;            // [256]
 constexpr int kGB2 = kGB1 + kMlpHid;                       // [256]
 constexpr int kGB3 = kGB2 + kMlpHid;                       // [16]
 constexpr int kGradElems = kGB3 + kMlpHead;                // 107 024
+
+// element offset of A[row][k] inside a matrix packed as 32 x 16 blocks (K = 16 KS): block (row / 32, k / 16), then the
+// mfma_f32_32x32x16_bf16 A-operand lane map: lane = row % 32 + 32 * (k / 8 % 2), element k % 8
+__host__ __device__ constexpr int frag32_off(int row, int k, int KS)
+{
+    return ((((row >> 5) * KS + (k >> 4)) * 64) + (row & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7);
+}
+// the same for a 16-row matrix consumed by mfma_f32_16x16x32_bf16: block k / 32, lane = row + 16 * (k / 8 % 4)
+__host__ __device__ constexpr int frag16_off(int row, int k)
+{
+    return (((k >> 5) * 64) + row + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -68,6 +94,7 @@ constexpr int kTrX = 160;         // [64][160] (80 dwords = 16 mod 64): 144 inpu
 constexpr int kTrHalf = 160;      // [64][128] half-width hidden tile (+32 pad)
 constexpr int kTrG = 32;          // [64][16] head-gradient tile (16 dwords)
 constexpr int kWgChunk = 64;      // samples per weight-gradient chunk
+constexpr int kWgParts = 4;       // weight-gradient workgroup roles (mlp_wgrad_kernel)
 
 struct MlpNetParams {             // float32 master parameters of one net (torch nn.Linear layouts)
     const float* w1; const float* b1;   // [256][137], [256]
@@ -86,13 +113,14 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpPackParams P)
     const int e = blockIdx.x * 256 + threadIdx.x;
     __bf16* wp = P.wpack + (size_t)net * kPackElems;
     if (e < kPackElems) {
-        float v;
-        if (e < kOffW2) { const int o = e / kMlpInPad, k = e % kMlpInPad; v = k < kMlpIn ? N.w1[o * kMlpIn + k] : 0.f; }
-        else if (e < kOffW3) { v = N.w2[e - kOffW2]; }
-        else if (e < kOffW2T) { const int r = (e - kOffW3) / kMlpHid, f = (e - kOffW3) % kMlpHid; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; }
-        else if (e < kOffW3T) { const int i = (e - kOffW2T) / kMlpHid, o = (e - kOffW2T) % kMlpHid; v = N.w2[o * kMlpHid + i]; }
-        else { const int f = (e - kOffW3T) / kMlpHead, r = (e - kOffW3T) % kMlpHead; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; }
-        wp[e] = (__bf16)v;
+        // e walks the SOURCE matrices in row-major order; the destination is the fragment-native position
+        float v; int dst;
+        if (e < kOffW2) { const int o = e / kMlpInPad, k = e % kMlpInPad; v = k < kMlpIn ? N.w1[o * kMlpIn + k] : 0.f; dst = kOffW1 + frag32_off(o, k, kMlpInPad / 16); }
+        else if (e < kOffW3) { const int r = e - kOffW2, o = r / kMlpHid, i = r % kMlpHid; v = N.w2[r]; dst = kOffW2 + frag32_off(o, i, kMlpHid / 16); }
+        else if (e < kOffW2T) { const int r = (e - kOffW3) / kMlpHid, f = (e - kOffW3) % kMlpHid; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3 + frag16_off(r, f); }
+        else if (e < kOffW3T) { const int i = (e - kOffW2T) / kMlpHid, o = (e - kOffW2T) % kMlpHid; v = N.w2[o * kMlpHid + i]; dst = kOffW2T + frag32_off(i, o, kMlpHid / 16); }
+        else { const int f = (e - kOffW3T) / kMlpHead, r = (e - kOffW3T) % kMlpHead; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3T + frag32_off(f, r, 1); }
+        wp[dst] = (__bf16)v;
     } else if (e < kPackElems + kBiasElems) {
         const int b = e - kPackElems;
         float v;
@@ -116,44 +144,45 @@ __device__ __forceinline__ bf16x8 ld_global_bf16x8(const __bf16* p) { return *re
 // acc[rb][cb] += W[64 rows of this wave][K] . tile[128 samples][K]^T.  W: row-major, row stride K (global, L2);
 // tile: LDS, row stride STRIDE.
 template <int K, int STRIDE>
-__device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_rows, const __bf16* tile, f32x16 (&acc)[2][4], int lane)
+__device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_blocks, const __bf16* tile, f32x16 (&acc)[2][kMlpCB], int lane)
 {
+    // w_blocks: the first of this wave's two row-blocks in the fragment-native packing: block (rb, ks) at (rb KS + ks) * 512
     constexpr int KS = K / 16;
     const int r = lane & 31, h = lane >> 5;
-    const __bf16* wa = w_rows + (size_t)r * K + 8 * h;
+    const __bf16* wa = w_blocks + lane * 8;
     const __bf16* tb = tile + r * STRIDE + 8 * h;
     constexpr int D = 5;                      // A fragments run D - 1 k-steps ahead of their use (L2 latency ~ 2-3 k-steps of MFMAs)
     bf16x8 a[D][2];
 #pragma unroll
     for (int p = 0; p < D - 1; ++p) {
         if (p < KS) {
-            a[p][0] = ld_global_bf16x8(wa + 16 * p);
-            a[p][1] = ld_global_bf16x8(wa + 32 * K + 16 * p);
+            a[p][0] = ld_global_bf16x8(wa + 512 * p);
+            a[p][1] = ld_global_bf16x8(wa + 512 * (KS + p));
         }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + D - 1 < KS) {
-            a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 16 * (ks + D - 1));
-            a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 32 * K + 16 * (ks + D - 1));
+            a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
+            a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 512 * (KS + ks + D - 1));
         }
-        bf16x8 b[4];
+        bf16x8 b[kMlpCB];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
+        for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < kMlpCB; ++cb)
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][rb], b[cb], acc[rb][cb], 0, 0, 0);
     }
 }
 
-__device__ __forceinline__ void mlp_zero_acc(f32x16 (&acc)[2][4])
+__device__ __forceinline__ void mlp_zero_acc(f32x16 (&acc)[2][kMlpCB])
 {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 }
@@ -162,7 +191,7 @@ __device__ __forceinline__ void mlp_zero_acc(f32x16 (&acc)[2][4])
 __device__ __forceinline__ void mlp_store_htile(const __bf16* tile, __bf16* __restrict__ dst, long long row0, long long n_rows, int tid)
 {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < kMlpBM / 8; ++i) {
         const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
         if (row0 + row < n_rows)
             *reinterpret_cast<uint4*>(dst + (row0 + row) * kMlpHid + cc * 8) = *reinterpret_cast<const uint4*>(tile + row * kHS + cc * 8);
@@ -171,7 +200,7 @@ __device__ __forceinline__ void mlp_store_htile(const __bf16* tile, __bf16* __re
 __device__ __forceinline__ void mlp_load_htile(__bf16* tile, const __bf16* __restrict__ src, long long row0, long long n_rows, int tid)
 {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < kMlpBM / 8; ++i) {
         const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (row0 + row < n_rows) v = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
@@ -224,25 +253,26 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
         // dependent idx -> row load per iteration this stage was a chain of ~36 memory round trips per thread:
         // 35.8 us of a 16 384-sample launch (rocprof r02_b) against ~3 us of MFMA time.
         {
-            const int row = tid >> 1, half = tid & 1;
+            constexpr int TPR = kMlpThreads / kMlpBM;             // threads per row: 2 (72 columns each) or 4 (36)
+            constexpr int CPT = kMlpInPad / TPR, NV = CPT / 4;    // columns and 16-byte loads per thread
+            const int row = tid / TPR, part = tid % TPR;
             const long long b = row0 + row;
             const bool live = b < P.B;
-            const float* src = P.obs + (live ? (P.idx ? P.idx[b] : b) : 0) * kMlpIn + 72 * half;
+            const float* src = P.obs + (live ? (P.idx ? P.idx[b] : b) : 0) * kMlpIn + CPT * part;
             typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            f32x4 v[18];
+            f32x4 v[NV];
 #pragma unroll
-            for (int j = 0; j < 18; ++j) {
-                const int col = 72 * half + 4 * j;                // compile-time per half: 0..68 | 72..140
+            for (int j = 0; j < NV; ++j) {
+                const int col = CPT * part + 4 * j;
                 v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (live) {
-                    if (half == 0 || j < 16) v[j] = *reinterpret_cast<const f32x4u*>(src + 4 * j);      // cols .. 135
-                    else if (j == 16) v[j][0] = src[64];                                               // col 136
+                if (live && !(PNR_MLP_DIAG & 2)) {
+                    if (col + 3 < kMlpIn) v[j] = *reinterpret_cast<const f32x4u*>(src + 4 * j);         // cols .. 135
+                    else if (col < kMlpIn) v[j][0] = src[4 * j];                                       // col 136 alone
                 }
-                (void)col;
             }
 #pragma unroll
-            for (int j = 0; j < 18; ++j) {
-                const int col = 72 * half + 4 * j;
+            for (int j = 0; j < NV; ++j) {
+                const int col = CPT * part + 4 * j;
                 f32x4 x = v[j];
                 if (P.f_loc) {
                     const f32x4 loc = *reinterpret_cast<const f32x4*>(fv + col), inv = *reinterpret_cast<const f32x4*>(fv + kMlpInPad + col);
@@ -267,7 +297,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
     }
 
     const int c = lane & 31, h = lane >> 5;
-    f32x16 acc[2][4];
+    f32x16 acc[2][kMlpCB];
     // bias + tanh in registers, each register quad = four consecutive features of one sample -> one ds_write_b64
     const auto epilogue = [&](const float* b) {
 #pragma unroll
@@ -276,12 +306,12 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
 #pragma unroll
             for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(b + 64 * w + 32 * rb + 8 * q + 4 * h);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bf16x4 pk;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)tanh_fast(acc[rb][cb][4 * q + j] + bq[q][j]);
+                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)((PNR_MLP_DIAG & 1) ? acc[rb][cb][4 * q + j] + bq[q][j] : tanh_fast(acc[rb][cb][4 * q + j] + bq[q][j]));
                     *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h) = pk;
                 }
         }
@@ -289,37 +319,40 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
     mlp_zero_acc(acc);
-    mlp_gemm_w_xt<kMlpInPad, kXS>(wp + kOffW1 + (size_t)64 * w * kMlpInPad, xt, acc, lane);
-    epilogue(bias);
+    if (!(PNR_MLP_DIAG & 8)) mlp_gemm_w_xt<kMlpInPad, kXS>(wp + kOffW1 + 2 * w * (kMlpInPad / 16) * 512, xt, acc, lane);
+    if (!(PNR_MLP_DIAG & 32)) epilogue(bias);
     __syncthreads();
     if (P.h1) mlp_store_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
 
     // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it
     mlp_zero_acc(acc);
-    mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2 + (size_t)64 * w * kMlpHid, ht, acc, lane);
+    if (!(PNR_MLP_DIAG & 4)) mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2 + 2 * w * (kMlpHid / 16) * 512, ht, acc, lane);
     __syncthreads();
-    epilogue(bias + kMlpHid);
+    if (!(PNR_MLP_DIAG & 32)) epilogue(bias + kMlpHid);
     __syncthreads();
     if (P.h2) mlp_store_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
 
-    // ---- layer 3: head^T [16][samples] = W3 . H2^T + b3 with 16x16x32 MFMAs; wave w owns samples 32w .. 32w+31
-    {
+    // ---- layer 3: head^T [16][samples] = W3 . H2^T + b3 with 16x16x32 MFMAs; wave w owns BM / 4 samples
+    if (!(PNR_MLP_DIAG & 16)) {
         const int r16 = lane & 15, g = lane >> 4;
-        f32x4 a3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const __bf16* w3 = wp + kOffW3 + r16 * kMlpHid + 8 * g;
+        constexpr int SB = kMlpBM / 64;                               // 16-sample blocks per wave
+        f32x4 a3[SB];
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) a3[sb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const __bf16* w3 = wp + kOffW3 + lane * 8;                    // fragment-native: block ks at ks * 512
 #pragma unroll
         for (int ks = 0; ks < kMlpHid / 32; ++ks) {
-            const bf16x8 a = ld_global_bf16x8(w3 + 32 * ks);
+            const bf16x8 a = ld_global_bf16x8(w3 + 512 * ks);
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (32 * w + 16 * sb + r16) * kHS + 32 * ks + 8 * g);
+            for (int sb = 0; sb < SB; ++sb) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (16 * SB * w + 16 * sb + r16) * kHS + 32 * ks + 8 * g);
                 a3[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, a3[sb], 0, 0, 0);
             }
         }
         const f32x4 b3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-            const long long b = row0 + 32 * w + 16 * sb + r16;      // column = sample, rows 4g .. 4g+3 = head entries
+        for (int sb = 0; sb < SB; ++sb) {
+            const long long b = row0 + 16 * SB * w + 16 * sb + r16; // column = sample, rows 4g .. 4g+3 = head entries
             if (b < P.B) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = a3[sb] + b3;
         }
     }
@@ -348,7 +381,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
     const __bf16* wp = P.wpack + (size_t)net * kPackElems;
     const int c = lane & 31, h = lane >> 5;
 
-    {   // head gradients: thread = (row, half): eight floats -> one ds_write_b128
+    if (tid < 2 * kMlpBM) {   // head gradients: thread = (row, half): eight floats -> one ds_write_b128
         const int row = tid >> 1, half = tid & 1;
         bf16x8 pk;
         f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
@@ -363,13 +396,13 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
     mlp_load_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
     __syncthreads();
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][kMlpCB];
     // acc * (1 - h^2) with h from the activation tile, packed into the gradient tile (same quad layout as forward)
     const auto epilogue = [&]() {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int off = (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h;
@@ -384,23 +417,23 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
     // ---- dH2^T = W3^T . G^T: one k-step of 16 (the padded head rows are zero)
     mlp_zero_acc(acc);
     {
-        const __bf16* wa = wp + kOffW3T + (size_t)(64 * w + c) * kMlpHead + 8 * h;
-        bf16x8 a[2] = {ld_global_bf16x8(wa), ld_global_bf16x8(wa + 32 * kMlpHead)};
+        const __bf16* wa = wp + kOffW3T + 2 * w * 512 + lane * 8;     // fragment-native, one k-step per row-block
+        bf16x8 a[2] = {ld_global_bf16x8(wa), ld_global_bf16x8(wa + 512)};
         bf16x8 b[4];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
+        for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
+            for (int cb = 0; cb < kMlpCB; ++cb)
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
     }
     // the H1 tile is requested now (16 x 16 bytes per thread, held in registers) and lands under the epilogue below
-    uint4 h1r[16];
+    uint4 h1r[kMlpBM / 8];
     {
         const __bf16* src = P.h1 + (size_t)net * P.B * kMlpHid;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < kMlpBM / 8; ++i) {
             const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
             h1r[i] = make_uint4(0u, 0u, 0u, 0u);
             if (row0 + row < P.B) h1r[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
@@ -410,7 +443,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
     __syncthreads();                                                               // every wave is done with H2
     mlp_store_htile(dz, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < kMlpBM / 8; ++i) {
         const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
         *reinterpret_cast<uint4*>(ht + row * kHS + cc * 8) = h1r[i];
     }
@@ -418,7 +451,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
 
     // ---- dH1^T = W2^T . dZ2^T
     mlp_zero_acc(acc);
-    mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2T + (size_t)64 * w * kMlpHid, dz, acc, lane);
+    mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2T + 2 * w * (kMlpHid / 16) * 512, dz, acc, lane);
     __syncthreads();                         // all reads of dZ2 done before it is overwritten
     epilogue();
     __syncthreads();
@@ -428,7 +461,9 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
 // ---------------------------------------------------------------------------------------------------------------
 // weight gradients: dW = dZ^T . H over the samples of one batch slice, written to that slice's slab.
 // grid (slices, 4 parts, nets): part 0 / 1 = the two 128-column halves of dW2, part 2 = dW1 and db1 (the input tile
-// carries a column of ones at k = 144), part 3 = dW3, db3 and db2 (16x16x32 MFMAs, a fragment of ones).
+// carries a column of ones at k = 144), part 3 = dW3, db3 and db2 (16x16x32 MFMAs, a fragment of ones).  One workgroup
+// per CU (342 registers); tried and dropped (r02): dW1 as two row-halves for 2 waves per SIMD — five roles x 64 slices
+// x 2 nets = 640 workgroups are 2.5 rounds of the 256 CUs instead of 2, 41 -> 45-50 us.
 // ---------------------------------------------------------------------------------------------------------------
 struct MlpWgradParams {
     const float* g_head;       // [2][B][16]
@@ -748,14 +783,14 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
     int wp0 = -1, wp1 = -1, bp = -1;               // where the bf16 / bias copies of this element go
     if (e < kGW2) {
         const int o = e / kMlpInPad, k = e % kMlpInPad;
-        wp0 = kOffW1 + e;
+        wp0 = kOffW1 + frag32_off(o, k, kMlpInPad / 16);
         if (k < kMlpIn) dst = P.w1[net] + o * kMlpIn + k;
     } else if (e < kGW3) {
         const int r = e - kGW2, o = r / kMlpHid, i = r % kMlpHid;
-        dst = P.w2[net] + r; wp0 = kOffW2 + r; wp1 = kOffW2T + i * kMlpHid + o;
+        dst = P.w2[net] + r; wp0 = kOffW2 + frag32_off(o, i, kMlpHid / 16); wp1 = kOffW2T + frag32_off(i, o, kMlpHid / 16);
     } else if (e < kGB1) {
         const int r = e - kGW3, row = r / kMlpHid, f = r % kMlpHid;
-        wp0 = kOffW3 + r; wp1 = kOffW3T + f * kMlpHead + row;
+        wp0 = kOffW3 + frag16_off(row, f); wp1 = kOffW3T + frag32_off(f, row, 1);
         if (row < P.n3[net]) dst = P.w3[net] + r;
     } else if (e < kGB2) { dst = P.b1[net] + (e - kGB1); bp = e - kGB1; }
     else if (e < kGB3) { dst = P.b2[net] + (e - kGB2); bp = kMlpHid + (e - kGB2); }
