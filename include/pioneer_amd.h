@@ -241,6 +241,23 @@ int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, co
                  float* means, void* stream);
 
 /*
+ * Host-driver helper: after the sampler's T steps, one launch for the log-probabilities of the taken actions (diagonal
+ * Gaussian, actions / mean / log_std [T][n][6]; pass actions NULL to skip) and GAE(lambda) advantages and value targets
+ * [T][n] from reward / values [T][n], last_value [n] (the bootstrap value) and the done / truncated bytes of pnr_step
+ * (terminal = done | truncated, as RLlib 0.8's postprocessing treats the TimeLimit cut; truncated may be NULL).
+ * terminals [T][n] (1.0 / 0.0) is optional.  gamma / lambda: the reference leaves RLlib's defaults (0.99 / 1.0).
+ */
+int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, const float* last_value, const uint8_t* done,
+                const uint8_t* truncated, const float* actions, const float* mean, const float* log_std, double gamma,
+                double lambda, float* logp, float* adv, float* value_target, float* terminals, void* stream);
+
+/*
+ * Host-driver helper: out[0..n) = a pseudo-random permutation of 0..n-1 keyed by (seed, stream_id) — a Feistel network
+ * with cycle walking, one launch and no sort; the SGD epochs' minibatch shuffle (RLlib sgd.py shuffles each epoch).
+ */
+int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, void* stream);
+
+/*
  * Host-driver helpers (not part of the env surface): the two MLPs of the reference's PPO config — 'fcnet_hiddens':
  * [256, 256] (pioneer/launch/pioneer_knm_train.py:59-61), tanh, separate policy (12 outputs: 6 means + 6 log-stds) and
  * value (1 output) nets, RLlib's FullyConnectedNetwork with vf_share_layers False — as bf16 MFMA kernels.
@@ -263,6 +280,16 @@ int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value
 int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const float* f_loc, const float* f_inv,
                     const float* f_lo, const float* f_hi, const void* wpack, const float* bias, float* head,
                     void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, void* stream);
+/*
+ * The sampler's per-step launch: both nets forward on `obs` [batch][137] and, in the policy net's last epilogue, the
+ * action draw of RLlib's DiagGaussian (what the reference's PPO config samples with): log_std = clamp(raw, -20, 2),
+ * actions = mean + exp(log_std) * noise (noise [batch][6] standard-normal draws supplied by the caller), env_actions =
+ * clamp(actions, -a_max, a_max) (a_max [6]; the env's action space, pioneer_knm_env.py:60-61; NULL: no clipping and
+ * env_actions is not written).  mean / log_std / actions / env_actions [batch][6], values [batch]; head [2][batch][16] or NULL.
+ */
+int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
+                const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
+                float* log_std, float* values, float* actions, float* env_actions, void* stream);
 int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
                      void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
                      int32_t n3_value, int32_t accumulate, const float* scale, void* stream);

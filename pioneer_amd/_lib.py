@@ -110,6 +110,9 @@ SIGNATURES = {
     "pnr_mlp_slab_floats": (C.c_int64, [C.c_int64]),
     "pnr_mlp_pack": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     "pnr_mlp_forward": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_int32, C.c_int32, _VP]),
+    "pnr_ppo_gae": (C.c_int, [C.c_int32, C.c_int64] + [_VP] * 8 + [C.c_double, C.c_double] + [_VP] * 5),
+    "pnr_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _VP, _VP]),
+    "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 16),
     "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "pnr_mlp_grad_floats": (C.c_int64, []),
     "pnr_mlp_train_step": (C.c_int, [C.POINTER(PnrMlpStep), _VP]),

@@ -1183,12 +1183,64 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
     if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: the four filter vectors come together or not at all");
     if ((h1 == nullptr) != (h2 == nullptr)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: h1 and h2 come together");
-    MlpFwdParams P;
+    MlpFwdParams P = {};
     P.obs = obs; P.idx = reinterpret_cast<const long long*>(idx); P.f_loc = f_loc; P.f_inv = f_inv; P.f_lo = f_lo; P.f_hi = f_hi;
     P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
     P.xs = static_cast<__bf16*>(xs); P.h1 = static_cast<__bf16*>(h1); P.h2 = static_cast<__bf16*>(h2);
     P.B = batch; P.first_net = first_net; P.n_nets = n_nets;
     hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kMlpThreads), 0,
+                       (hipStream_t)stream, P);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, const float* last_value, const uint8_t* done,
+                const uint8_t* truncated, const float* actions, const float* mean, const float* log_std, double gamma,
+                double lambda, float* logp, float* adv, float* value_target, float* terminals, void* stream)
+{
+    if (T < 1 || n < 1 || !reward || !values || !last_value || !done || !adv || !value_target)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: null argument or empty rollout");
+    if (actions && (!mean || !log_std || !logp)) return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: actions need mean, log_std and logp");
+    GaeParams P;
+    P.reward = reward; P.values = values; P.last_value = last_value; P.done = done; P.trunc = truncated;
+    P.actions = actions; P.mean = mean; P.log_std = log_std; P.logp = logp; P.adv = adv; P.vtarg = value_target;
+    P.terminals = terminals; P.N = n; P.T = T;
+    P.gamma = (float)gamma; P.gamma_lam = (float)(gamma * lambda);      // the host formula's Python-float product, then float32
+    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
+{
+    if (n < 1 || !out) return fail(nullptr, PNR_ERR_INVALID, "pnr_permutation: null argument or n < 1");
+    if (n > (1ll << 40)) return fail(nullptr, PNR_ERR_INVALID, "pnr_permutation: n above 2^40");
+    int bits = 1;
+    while ((1ll << bits) < n) ++bits;                   // 2^bits >= n
+    const int half = (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
+    hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<long long*>(out), (long long)n, half, (unsigned long long)seed, (unsigned long long)stream_id);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
+                const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
+                float* log_std, float* values, float* actions, float* env_actions, void* stream)
+{
+    if (batch < 1 || !obs || !wpack || !bias || !noise || !mean || !log_std || !values || !actions)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: null argument or empty batch");
+    if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: the four filter vectors come together or not at all");
+    if (a_max && (!env_actions || env_actions == actions))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: clipping (a_max) needs its own env_actions buffer");
+    MlpFwdParams P = {};
+    P.obs = obs; P.f_loc = f_loc; P.f_inv = f_inv; P.f_lo = f_lo; P.f_hi = f_hi;
+    P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
+    P.B = batch; P.first_net = 0; P.n_nets = kMlpNets;
+    P.noise = noise; P.a_max = a_max; P.mean = mean; P.log_std = log_std; P.values = values; P.actions = actions;
+    P.env_actions = a_max ? env_actions : actions;
+    hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0,
                        (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
@@ -1280,7 +1332,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     hipStream_t st = (hipStream_t)stream;
     const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), kMlpNets), thr(kMlpThreads);
 
-    MlpFwdParams F;
+    MlpFwdParams F = {};
     F.obs = s->obs; F.idx = reinterpret_cast<const long long*>(s->idx); F.f_loc = s->f_loc; F.f_inv = s->f_inv; F.f_lo = s->f_lo; F.f_hi = s->f_hi;
     F.wpack = static_cast<const __bf16*>(s->wpack); F.bias = s->bias; F.head = s->head;
     F.xs = static_cast<__bf16*>(s->xs); F.h1 = static_cast<__bf16*>(s->h1); F.h2 = static_cast<__bf16*>(s->h2);

@@ -28,6 +28,7 @@ namespace pnr {
 constexpr int kMlpIn = 137;       // observation entries (pioneer_knm_env.py:194-211)
 constexpr int kMlpInPad = 144;    // K of the first layer, padded to a multiple of 16 (zero columns)
 constexpr int kMlpHid = 256;      // fcnet_hiddens [256, 256] (pioneer_knm_train.py:60)
+constexpr int kMlpAct = 6;        // action dimensions (means 0..5, log-stds 6..11 of the policy head)
 constexpr int kMlpHead = 16;      // head rows: 12 (6 means + 6 log-stds) or 1 (value), zero-padded to 16
 constexpr int kMlpNets = 2;       // policy, value
 #ifndef PNR_MLP_BM
@@ -223,6 +224,16 @@ struct MlpFwdParams {
     __bf16* h2;                // [2][B][256]
     long long B;
     int first_net, n_nets;     // blockIdx.y + first_net = net
+    // the sampler's action draw, fused into the layer-3 epilogue (all null in the learner): a = mean + exp(log_std) * noise
+    // with log_std = clamp(raw, -20, 2) (RLlib DiagGaussian's sample(); SquashedGaussian is not the reference's choice),
+    // the env's action = clamp(a, -a_max, a_max) when a_max is given (RLlib clip_actions, the reference's default)
+    const float* noise;        // [B][6] standard-normal draws
+    const float* a_max;        // [6] or null
+    float* mean;               // [B][6]
+    float* log_std;            // [B][6] clamped
+    float* actions;            // [B][6] the sampled (unclipped) action: what the log-prob is taken of
+    float* env_actions;        // [B][6] what pnr_step is given (may equal `actions` when a_max is null)
+    float* values;             // [B] value head
 };
 
 // Forward pass of one 128-sample tile through one net: grid (ceil(B / 128), nets), 256 threads.
@@ -353,7 +364,44 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb) {
             const long long b = row0 + 16 * SB * w + 16 * sb + r16; // column = sample, rows 4g .. 4g+3 = head entries
-            if (b < P.B) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = a3[sb] + b3;
+            const f32x4 h = a3[sb] + b3;
+            if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = h;
+            if (!P.noise) continue;
+            if (net == 1) {
+                if (b < P.B && g == 0) P.values[b] = h[0];
+                continue;
+            }
+            // policy rows: g = 0 holds means 0..3, g = 1 means 4, 5 and raw log-stds 0, 1, g = 2 raw log-stds 2..5.
+            // Six cross-lane reads put each mean next to its log-std (executed by all lanes: no divergence around them).
+            const auto ls = [](float x) { return fminf(fmaxf(x, -20.f), 2.f); };
+            const float l0 = ls(__shfl(h[2], r16 + 16)), l1 = ls(__shfl(h[3], r16 + 16));
+            const float l2 = ls(__shfl(h[0], r16 + 32)), l3 = ls(__shfl(h[1], r16 + 32));
+            const float l4 = ls(__shfl(h[2], r16 + 32)), l5 = ls(__shfl(h[3], r16 + 32));
+            if (b >= P.B || g > 2) continue;
+            const size_t o = (size_t)b * kMlpAct;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const auto st2 = [](float* dst, float x, float y) { *reinterpret_cast<f32x2*>(dst) = (f32x2){x, y}; };
+            const auto draw = [&](int j, float m, float l, float& a, float& e) {
+                a = fmaf(expf(l), P.noise[o + j], m);
+                e = P.a_max ? fminf(fmaxf(a, -P.a_max[j]), P.a_max[j]) : a;
+            };
+            if (g == 0) {
+                float a[4], e[4];
+                draw(0, h[0], l0, a[0], e[0]); draw(1, h[1], l1, a[1], e[1]);
+                draw(2, h[2], l2, a[2], e[2]); draw(3, h[3], l3, a[3], e[3]);
+                st2(P.mean + o, h[0], h[1]); st2(P.mean + o + 2, h[2], h[3]);
+                st2(P.actions + o, a[0], a[1]); st2(P.actions + o + 2, a[2], a[3]);
+                if (P.env_actions != P.actions) { st2(P.env_actions + o, e[0], e[1]); st2(P.env_actions + o + 2, e[2], e[3]); }
+            } else if (g == 1) {
+                float a[2], e[2];
+                draw(4, h[0], l4, a[0], e[0]); draw(5, h[1], l5, a[1], e[1]);
+                st2(P.mean + o + 4, h[0], h[1]);
+                st2(P.actions + o + 4, a[0], a[1]);
+                if (P.env_actions != P.actions) st2(P.env_actions + o + 4, e[0], e[1]);
+                st2(P.log_std + o, ls(h[2]), ls(h[3]));
+            } else {
+                st2(P.log_std + o + 2, ls(h[0]), ls(h[1])); st2(P.log_std + o + 4, ls(h[2]), ls(h[3]));
+            }
         }
     }
 }

@@ -151,4 +151,111 @@ __global__ __launch_bounds__(64) void ppo_loss_finish_kernel(const float* __rest
     if (threadIdx.x < kPpoSums) means[k] = s / (float)B;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// After the sampler's T steps: log-probabilities of the taken actions and GAE(lambda) advantages, one thread per env
+// walking its T records backwards (the scan is serial in t, parallel in n; all accesses coalesced over n).  Replaces
+// ~7 element-wise launches per step of the host loop with one launch per rollout.  Every product and sum is a
+// separate rounded float32 operation in the order of the host formula (ppo.py compute_gae / gaussian_logp), so the
+// advantages are bit-identical to it; RLlib of the reference's era (0.8.x postprocessing.compute_advantages) treats the
+// TimeLimit cut as terminal, hence terminal = done | truncated.
+// ---------------------------------------------------------------------------------------------------------------
+struct GaeParams {
+    const float* reward;       // [T][N]
+    const float* values;       // [T][N]
+    const float* last_value;   // [N] value of the state after the last step
+    const unsigned char* done; // [T][N]
+    const unsigned char* trunc;// [T][N] or null
+    const float* actions;      // [T][N][6] or null (then no log-probs)
+    const float* mean;         // [T][N][6]
+    const float* log_std;      // [T][N][6]
+    float* logp;               // [T][N]
+    float* adv;                // [T][N]
+    float* vtarg;              // [T][N]
+    float* terminals;          // [T][N] 1.0 / 0.0, or null
+    long long N;
+    int T;
+    float gamma, gamma_lam;
+};
+
+__global__ __launch_bounds__(256) void gae_logp_kernel(const GaeParams P)
+{
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= P.N) return;
+    float nxt_v = P.last_value[n], nxt_a = 0.f;
+    const float gl = P.gamma_lam;
+    for (int t = P.T - 1; t >= 0; --t) {
+        const long long i = (long long)t * P.N + n;
+        const bool term = P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0);
+        const float live = term ? 0.f : 1.f;
+        const float v = P.values[i];
+        // delta = r + gamma * nxt_v * live - v ; adv = delta + gamma * lam * live * nxt_a
+        const float delta = __fsub_rn(__fadd_rn(P.reward[i], __fmul_rn(__fmul_rn(P.gamma, nxt_v), live)), v);
+        nxt_a = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, live), nxt_a));
+        nxt_v = v;
+        P.adv[i] = nxt_a;
+        P.vtarg[i] = __fadd_rn(nxt_a, v);
+        if (P.terminals) P.terminals[i] = term ? 1.f : 0.f;
+        if (P.actions) {
+            const float* a = P.actions + i * 6;
+            const float* m = P.mean + i * 6;
+            const float* l = P.log_std + i * 6;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float z = __fmul_rn(__fsub_rn(a[j], m[j]), expf(-l[j]));
+                // (-0.5 z) z - log_std - 0.5 log(2 pi), summed over j in order
+                const float term_j = __fsub_rn(__fsub_rn(__fmul_rn(__fmul_rn(-0.5f, z), z), l[j]), 0.91893853320467274178f);
+                s = __fadd_rn(s, term_j);
+            }
+            P.logp[i] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A pseudo-random permutation of 0 .. n-1 without a sort: a 6-round Feistel network over the next even-bit-width
+// power of two, keyed by (seed, stream), with cycle walking (re-encrypt until the value is below n; fewer than four
+// rounds expected, since the domain is < 4n).  A bijection of [0, 2^k) restricted by cycle walking is a bijection of
+// [0, n): every index appears exactly once, which is all minibatch shuffling needs (RLlib's sgd.py shuffles with
+// np.random.permutation; the draws differ, the property "each sample once per epoch" is the same).  One launch of n
+// threads instead of torch.randperm's radix sort + merge passes (~170 us at n = 524 288).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int perm_round(unsigned int x, unsigned int key)
+{
+    x = (x ^ key) * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA77u;
+    x ^= x >> 13; x *= 0xC2B2AE3Du;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void permutation_kernel(long long* __restrict__ out, long long n, int half_bits,
+                                                         unsigned long long seed, unsigned long long stream)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int mask = (1u << half_bits) - 1u;
+    unsigned int keys[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {                         // splitmix64 of (seed, stream, round)
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (stream * 6ull + (unsigned long long)r + 1ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        keys[r] = (unsigned int)(z ^ (z >> 31));
+    }
+    unsigned long long x = (unsigned long long)i;
+    do {                                                  // terminates: the walk of a bijection returns to i < n at the latest
+        unsigned int L = (unsigned int)(x >> half_bits) & mask, R = (unsigned int)x & mask;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const unsigned int f = perm_round(R, keys[r]) & mask;
+            const unsigned int nl = R;
+            R = L ^ f;
+            L = nl;
+        }
+        x = ((unsigned long long)L << half_bits) | R;
+    } while ((long long)x >= n);
+    out[i] = (long long)x;
+}
+
 }  // namespace pnr

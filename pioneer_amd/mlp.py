@@ -113,6 +113,26 @@ class HipMLP:
         self._launch_forward(B, obs, idx, filt, head, save=False)
         return head
 
+    @torch.no_grad()
+    def act(self, obs: torch.Tensor, filt, noise: torch.Tensor, a_max: Optional[torch.Tensor], *, mean: torch.Tensor,
+            log_std: torch.Tensor, values: torch.Tensor, actions: torch.Tensor, env_actions: Optional[torch.Tensor] = None,
+            head: Optional[torch.Tensor] = None) -> None:
+        """One sampler step in ONE launch (pnr_mlp_act): both nets on ``obs`` [B, 137] and the DiagGaussian draw
+        ``actions = mean + exp(clamp(log_std, -20, 2)) * noise`` in the policy net's epilogue; ``env_actions`` =
+        ``actions`` clipped to +-``a_max`` (what the env is stepped with) when ``a_max`` is given."""
+        self._check_inputs(obs, None, filt, self.device)
+        B = int(obs.numel() // 137)
+        f = filt if filt is not None else (None, None, None, None)
+        for name, x, shape in (("noise", noise, (B, 6)), ("mean", mean, (B, 6)), ("log_std", log_std, (B, 6)), ("values", values, (B,)),
+                               ("actions", actions, (B, 6)), ("env_actions", env_actions, (B, 6)), ("head", head, (2, B, HEAD)),
+                               ("a_max", a_max, (6,))):
+            if x is not None:
+                assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == shape and x.device == self.device, name
+        assert (a_max is None) or (env_actions is not None and env_actions.data_ptr() != actions.data_ptr())
+        _lib.check(self.lib.pnr_mlp_act(B, _p(obs), _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(self.wpack), _p(self.bias), _p(noise),
+                                        _p(a_max), _p(head), _p(mean), _p(log_std), _p(values), _p(actions), _p(env_actions),
+                                        self._stream()))
+
     # -- the learner path -------------------------------------------------------------------------------------
     def apply(self, obs: torch.Tensor, idx: Optional[torch.Tensor] = None, filt=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """(head_policy [B, 16], head_value [B, 16]) with autograd through the HIP backward kernels.  Packs the

@@ -417,6 +417,36 @@ def compute_gae(rewards, values, last_value, terminals, gamma, lam):
     return adv, adv + values
 
 
+def _dp(t):
+    import ctypes
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def hip_gae_logp(reward, values, last_value, done, trunc, actions, mean, log_std, gamma, lam, *, logp, adv, vtarg, terminals=None):
+    """compute_gae + gaussian_logp of a [T, N] rollout in ONE launch (pnr_ppo_gae) on the current stream; outputs are
+    written in place.  Advantages bit-identical to compute_gae (same float32 operations in the same order)."""
+    import ctypes
+    from . import _lib
+    T, N = reward.shape
+    f32 = [reward, values, last_value, actions, mean, log_std, logp, adv, vtarg] + ([terminals] if terminals is not None else [])
+    assert all(x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda for x in f32)
+    assert done.dtype == torch.uint8 and done.is_contiguous() and (trunc is None or (trunc.dtype == torch.uint8 and trunc.is_contiguous()))
+    assert values.shape == (T, N) and last_value.shape == (N,) and actions.shape == (T, N, 6) and adv.shape == (T, N)
+    _lib.check(_lib.load_library().pnr_ppo_gae(T, N, _dp(reward), _dp(values), _dp(last_value), _dp(done), _dp(trunc), _dp(actions),
+                                                _dp(mean), _dp(log_std), float(gamma), float(lam), _dp(logp), _dp(adv), _dp(vtarg),
+                                                _dp(terminals), ctypes.c_void_p(torch.cuda.current_stream(reward.device).cuda_stream)))
+
+
+def hip_permutation(n: int, seed: int, stream_id: int, out: torch.Tensor) -> torch.Tensor:
+    """out[:n] = a pseudo-random permutation of 0..n-1 keyed by (seed, stream_id): pnr_permutation, one launch, no sort."""
+    import ctypes
+    from . import _lib
+    assert out.dtype == torch.int64 and out.is_contiguous() and out.numel() >= n and out.is_cuda
+    _lib.check(_lib.load_library().pnr_permutation(n, seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1), _dp(out),
+                                                   ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
+    return out[:n]
+
+
 class EpisodeStats:
     """episode_reward_{max,min,mean}, episode_len_mean, episodes_total (cli.py:32-38), on device.
 
@@ -530,6 +560,8 @@ class PPOLearner:
         self.hip = (self.fused_loss and bool(cfg.amp_bf16) and cfg.obs_dim == 137 and tuple(cfg.fcnet_hiddens) == (256, 256))
         self._mlp = None            # HipMLP with a workspace for one minibatch
         self._means = None          # [minibatches, 8] per-update loss means (HIP path)
+        self._perm = None           # the epoch's minibatch shuffle (HIP path)
+        self._epochs = 0            # SGD epochs so far: the shuffle's stream id (saved with the optimiser state)
         self._hip_dirty = True      # the packed bf16 weights are stale (construction, restore)
 
     def drop_graphs(self) -> None:
@@ -654,7 +686,7 @@ class PPOLearner:
         (padded gradient layout) and its update count."""
         if self.hip and self._mlp is not None:
             m, v, step = self._mlp.adam_state()
-            return {"hip_adam": {"m": m, "v": v, "step": step}}
+            return {"hip_adam": {"m": m, "v": v, "step": step, "epochs": self._epochs}}
         return self.opt.state_dict()
 
     def load_optimizer_state(self, sd) -> None:
@@ -664,6 +696,7 @@ class PPOLearner:
             mlp = self.hip_mlp(max(1, min(self.cfg.sgd_minibatch_size, 1 << 20)))
             for dst, k in zip(mlp.adam_state(), ("m", "v", "step")):
                 dst.copy_(sd["hip_adam"][k])
+            self._epochs = int(sd["hip_adam"].get("epochs", 0))
         elif not (self.hip and not sd.get("state")):
             self.opt.load_state_dict(sd)
         self._hip_dirty = True           # the master weights changed behind the packed bf16 copies
@@ -699,9 +732,13 @@ class PPOLearner:
         world = pdist.dist.get_world_size() if multi else 1
         if multi and self._flat_grad is None:
             self._flat_grad = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), dtype=torch.float32, device=dev)
+        if self._perm is None or self._perm.numel() != B:
+            self._perm = torch.empty(B, dtype=torch.int64, device=dev)
         k = 0
         for _ in range(cfg.num_sgd_iter):
-            perm = torch.randperm(B, device=dev, generator=generator)
+            # each epoch's shuffle: pnr_permutation keyed by (seed, rank, epoch counter) — one launch, no sort
+            perm = hip_permutation(B, cfg.seed * 1000003 + (pdist.dist.get_rank() if multi else 0), self._epochs, self._perm)
+            self._epochs += 1
             for s in range(0, B - mbs + 1, mbs):
                 mlp.train_step(rec["obs"], perm[s:s + mbs], filt, rec, self._kl_c, self._ent_c, cfg.clip_param, cfg.vf_clip_param,
                                cfg.vf_loss_coeff, self._means[k], cfg.lr, flat_grad=self._flat_grad if multi else None)
@@ -800,8 +837,8 @@ class PPOTrainer:
         if self.hip:
             from .mlp import HipMLP
             self.sample_mlp = HipMLP(self.learner.model, N, self.device)   # packed weights for the rollout's T forwards
-            self.buf["heads"] = torch.empty((T, 2, N, 16), **f32)      # raw head rows of both nets
             self._last_heads = torch.empty((2, N, 16), **f32)
+            self._last_v = torch.empty((N,), **f32)
         else:
             self.buf["obs"] = torch.empty((T, N, D), **f32)            # filtered, what the nets saw
 
@@ -821,6 +858,11 @@ class PPOTrainer:
 
     def _finish_rollout(self, last_v: torch.Tensor) -> None:
         cfg, buf = self.cfg, self.buf
+        if self.hip:
+            hip_gae_logp(buf["reward"], buf["values"], last_v.contiguous(), buf["done"], buf["trunc"], buf["actions"], buf["mean"],
+                         buf["log_std"], cfg.gamma, cfg.lambda_, logp=buf["logp"], adv=buf["adv"], vtarg=buf["vtarg"],
+                         terminals=buf["terminals"])
+            return
         buf["logp"].copy_(gaussian_logp(buf["actions"], buf["mean"], buf["log_std"]))
         torch.bitwise_or(buf["done"], buf["trunc"], out=buf["term_u8"])
         buf["terminals"].copy_(buf["term_u8"])
@@ -844,18 +886,20 @@ class PPOTrainer:
         self.filter.prepare()
         noise = self._noise()
         if self.hip:
-            # per step: ONE launch for both nets on the raw observation (filter applied on load), the action draw, pnr_step
+            # per step TWO launches: pnr_mlp_act (both nets on the raw observation, filter applied on load, action draw and
+            # clip in the policy net's epilogue) and pnr_step
             mlp, filt = self.sample_mlp, self._filt()
             mlp.pack()
+            clip = self.cfg.clip_actions
             for t in range(T):
-                heads = mlp.forward_nograd(self.raw_in[t], None, filt, out=buf["heads"][t])
-                buf["mean"][t].copy_(heads[0, :, :A])
-                log_std = torch.clamp(heads[0, :, A:2 * A], -20.0, 2.0, out=buf["log_std"][t])
-                buf["values"][t].copy_(heads[1, :, 0])
-                act = torch.addcmul(buf["mean"][t], torch.exp(log_std), noise[t], out=buf["actions"][t])
-                self._env_step(t, act)
+                mlp.act(self.raw_in[t], filt, noise[t], self.a_max if clip else None, mean=buf["mean"][t], log_std=buf["log_std"][t],
+                        values=buf["values"][t], actions=buf["actions"][t], env_actions=self._env_act if clip else None)
+                self.env.vector_step(self._env_act if clip else buf["actions"][t],
+                                     out={"obs": self.raw_in[t + 1], "reward": buf["reward"][t], "done": buf["done"][t],
+                                          "truncated": buf["trunc"][t]})
             last = mlp.forward_nograd(self.raw_in[T], None, filt, out=self._last_heads)
-            self._finish_rollout(last[1, :, 0])          # bootstrap value of the state after the last step
+            self._last_v.copy_(last[1, :, 0])           # bootstrap value of the state after the last step
+            self._finish_rollout(self._last_v)
             return
         model.refresh_inference_cache(cfg.amp_bf16)
         cdt = model._icache["dtype"]

@@ -119,6 +119,38 @@ def test_nograd_forward_equals_training_forward_and_respects_bounds():
     assert bool((guard[2 * B * 16:] == 7.0).all())
 
 
+@pytest.mark.parametrize("B,clip", [(1, True), (4099, True), (16384, False)])
+def test_act_equals_the_torch_glue_on_the_same_heads(B, clip):
+    """pnr_mlp_act = forward_nograd + the sampler's torch glue (mean / clamp(log_std) / value slices, mean + exp(log_std)
+    * noise, clip to the action space): heads bit for bit, the draw to float32 rounding of exp (torch.exp vs expf)."""
+    model, mlp, obs, _, filt = make(B, 21, with_filter=True)
+    dev = obs.device
+    mlp.pack()
+    heads = mlp.forward_nograd(obs, None, filt)
+    g = torch.Generator(device=dev).manual_seed(3)
+    noise = torch.randn(B, 6, generator=g, device=dev)
+    a_max = torch.rand(6, generator=g, device=dev) * 2.0 + 0.5
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {k: torch.full((B, 6), float("nan"), **f32) for k in ("mean", "log_std", "actions", "env_actions")}
+    values = torch.full((B,), float("nan"), **f32)
+    head2 = torch.full((2, B, 16), float("nan"), **f32)
+    mlp.act(obs, filt, noise, a_max if clip else None, mean=out["mean"], log_std=out["log_std"], values=values,
+            actions=out["actions"], env_actions=out["env_actions"] if clip else None, head=head2)
+    torch.cuda.synchronize()
+    assert torch.equal(head2, heads)
+    mean, log_std = heads[0, :, :6], torch.clamp(heads[0, :, 6:12], -20.0, 2.0)
+    assert torch.equal(out["mean"], mean) and torch.equal(out["log_std"], log_std) and torch.equal(values, heads[1, :, 0])
+    act = torch.addcmul(mean, torch.exp(log_std), noise)
+    # |d act| <= 2 ulp of exp(log_std) * |noise| + 1 ulp of the sum
+    bound = 2.4e-7 * (torch.exp(log_std) * noise.abs()) + 1.2e-7 * act.abs() + 1e-30
+    assert bool(((out["actions"] - act).abs() <= bound).all()), float((out["actions"] - act).abs().max())
+    if clip:
+        assert torch.equal(out["env_actions"], torch.minimum(torch.maximum(out["actions"], -a_max), a_max))
+        assert bool((out["env_actions"].abs() <= a_max).all()) and bool((out["actions"].abs() > a_max).any())
+    else:
+        assert bool(torch.isnan(out["env_actions"]).all())           # not written without a_max
+
+
 def test_graph_replay_of_the_learner_kernels_is_exact():
     """Captured once, replayed on fresh inputs: bit-identical heads and gradients to eager launches, replay after
     replay (no semaphores, no atomics, no library workspaces in these kernels; fixed-order slab reduction)."""

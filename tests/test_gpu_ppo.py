@@ -251,3 +251,53 @@ def test_evaluate_checkpoint_and_record_gif(tmp_path):
     # the stochastic policy runs too, and in dynamics mode
     res2 = evaluate(ck, episodes=1, max_episode_steps=5, mode="dynamic", deterministic=False)
     assert res2["episode_lengths"] == [5] or res2["successes"][0]
+
+
+def test_gae_logp_kernel_equals_the_host_formulas():
+    """pnr_ppo_gae against compute_gae (bit for bit: same float32 operations in the same order) and gaussian_logp (to
+    the rounding of exp), ragged N, with terminals of both kinds and lambda < 1."""
+    from pioneer_amd.ppo import compute_gae, gaussian_logp, hip_gae_logp
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(4)
+    T, N = 32, 4099
+    r = torch.randn(T, N, generator=g, device=dev)
+    v = torch.randn(T, N, generator=g, device=dev) * 3
+    last = torch.randn(N, generator=g, device=dev)
+    done = (torch.rand(T, N, generator=g, device=dev) < 0.05).to(torch.uint8)
+    trunc = ((torch.rand(T, N, generator=g, device=dev) < 0.05) & (done == 0)).to(torch.uint8)
+    mean = torch.randn(T, N, 6, generator=g, device=dev)
+    log_std = torch.rand(T, N, 6, generator=g, device=dev) * 4 - 3
+    act = mean + torch.exp(log_std) * torch.randn(T, N, 6, generator=g, device=dev)
+    for gamma, lam in ((0.99, 1.0), (0.97, 0.9)):
+        out = {k: torch.full((T, N), float("nan"), device=dev) for k in ("logp", "adv", "vtarg", "terminals")}
+        hip_gae_logp(r, v, last, done, trunc, act, mean, log_std, gamma, lam, **out)
+        term = (done | trunc).float()
+        adv, vt = compute_gae(r, v, last, term, gamma, lam)
+        assert torch.equal(out["terminals"], term)
+        assert torch.equal(out["adv"], adv) and torch.equal(out["vtarg"], vt)
+        lp = gaussian_logp(act, mean, log_std)
+        assert float((out["logp"] - lp).abs().max()) <= 2e-5 * float(lp.abs().max())
+        assert float(((out["logp"] - lp).abs() / (lp.abs() + 1)).max()) < 5e-6
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 4099, 32768, 524288, 1000003])
+def test_permutation_kernel_is_a_permutation(n):
+    from pioneer_amd.ppo import hip_permutation
+    dev = torch.device("cuda", 0)
+    out = torch.full((n + 3,), -7, dtype=torch.int64, device=dev)
+    p0 = hip_permutation(n, 11, 0, out).clone()
+    assert bool((out[n:] == -7).all())
+    assert torch.equal(torch.sort(p0).values, torch.arange(n, device=dev))
+    p1 = hip_permutation(n, 11, 1, out).clone()
+    p0b = hip_permutation(n, 11, 0, out).clone()
+    assert torch.equal(p0, p0b)                                  # a function of (seed, stream id)
+    if n >= 4099:
+        assert not torch.equal(p0, p1)
+        # no visible structure: few fixed points, first-difference sign changes like a random sequence (2/3 of the positions)
+        assert int((p0 == torch.arange(n, device=dev)).sum()) < 12
+        d = torch.sign(p0[1:] - p0[:-1])
+        turns = float((d[1:] != d[:-1]).float().mean())
+        assert abs(turns - 2.0 / 3.0) < 0.03, turns
+        # each quarter of the output draws evenly from the input range
+        q = p0[: n // 4].double().mean() / n
+        assert abs(float(q) - 0.5) < 0.02
