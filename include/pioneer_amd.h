@@ -63,6 +63,22 @@ enum pnr_mode {
 };
 
 /*
+ * A static body of the scene: what World/Scene.create_body_plane / create_body_box / create_body_sphere make with mass 0
+ * and a collision shape (bullet_scene.py:193-246).  Dynamics mode only: every contact sample sphere of the arm (the
+ * pointer; with link_contacts the 22 link samples too) collides with it, surface to surface, by the penalty law of
+ * contact_kp / contact_kd.  orientation is Bullet's quaternion (x, y, z, w).
+ */
+#define PNR_MAX_SCENE 8
+enum pnr_shape { PNR_SHAPE_NONE = 0, PNR_SHAPE_PLANE = 1, PNR_SHAPE_BOX = 2, PNR_SHAPE_SPHERE = 3 };
+typedef struct pnr_scene_body {
+    int32_t shape;                /* enum pnr_shape */
+    int32_t reserved;
+    double position[3];           /* basePosition */
+    double orientation[4];        /* baseOrientation (x, y, z, w) */
+    double size[3];               /* plane: planeNormal in the body frame; box: halfExtents; sphere: radius in size[0] */
+} pnr_scene_body;
+
+/*
  * Tunables.  Field names and defaults follow PioneerKinematicConfig
  * (pioneer_knm_env.py:19-34) and SimulationConfig (bullet_env.py:36-44);
  * max_episode_steps is gym.wrappers.TimeLimit's argument
@@ -121,6 +137,9 @@ typedef struct pnr_config {
                                    * fitted to the URDF's visual boxes; the URDF itself has no <collision>) */
     double max_velocity;          /* control_position's maxVelocity (bullet_scene.py:126,136): cap on the velocity the
                                    * motor asks for, rad/s; <= 0 = none */
+    int32_t n_scene;              /* static scene bodies in use, 0 .. PNR_MAX_SCENE */
+    int32_t reserved0;
+    pnr_scene_body scene[PNR_MAX_SCENE];
 } pnr_config;
 
 typedef struct pnr_env_s* pnr_handle;

@@ -179,6 +179,15 @@ class COracle:
 LINKS = 11
 
 
+ORC_MAX_SCENE = 8
+SHAPES = {"plane": 1, "box": 2, "sphere": 3}
+
+
+class OrcSceneBody(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("pad", C.c_int32), ("position", C.c_double * 3), ("orientation", C.c_double * 4),
+                ("size", C.c_double * 3)]
+
+
 class OrcDynParams(C.Structure):
     _fields_ = [
         ("kp", C.c_double), ("kd", C.c_double), ("torque_limit", C.c_double), ("gravity", C.c_double),
@@ -192,6 +201,7 @@ class OrcDynParams(C.Structure):
         ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
         ("pointer_radius", C.c_double),
         ("control_mode", C.c_int32), ("link_contacts", C.c_int32), ("max_velocity", C.c_double),
+        ("n_scene", C.c_int32), ("pad2", C.c_int32), ("scene", OrcSceneBody * ORC_MAX_SCENE),
     ]
 
 
@@ -223,6 +233,17 @@ class DynOracle(COracle):
             if k in ("obstacle_position", "obstacle_half_extents"):
                 for i in range(3):
                     getattr(self.d, k)[i] = float(v[i])
+            elif k == "scene":
+                # [(shape, position, orientation xyzw, size3)], the static bodies of create_body_plane / _box / _sphere
+                assert len(v) <= ORC_MAX_SCENE
+                self.d.n_scene = len(v)
+                for i, (shape, pos, quat, size) in enumerate(v):
+                    b = self.d.scene[i]
+                    b.shape = SHAPES[shape]
+                    for j in range(3):
+                        b.position[j] = float(pos[j]); b.size[j] = float(size[j])
+                    for j in range(4):
+                        b.orientation[j] = float(quat[j])
             else:
                 setattr(self.d, k, v)
         self.dstate = np.zeros(self.n, dtype=DYN_STATE_DTYPE)

@@ -242,6 +242,17 @@ void orc_dyn_tip(const orc_dyn_state* s, double pos[3], double vel[3])
     }
 }
 
+/* rotation matrix of Bullet's quaternion (x, y, z, w), normalised first */
+static void quat_to_matrix(const double qq[4], double R[3][3])
+{
+    double n = sqrt(qq[0] * qq[0] + qq[1] * qq[1] + qq[2] * qq[2] + qq[3] * qq[3]);
+    double x = 0, y = 0, z = 0, w = 1;
+    if (n > 0) { x = qq[0] / n; y = qq[1] / n; z = qq[2] / n; w = qq[3] / n; }
+    R[0][0] = 1 - 2 * (y * y + z * z); R[0][1] = 2 * (x * y - z * w);     R[0][2] = 2 * (x * z + y * w);
+    R[1][0] = 2 * (x * y + z * w);     R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (y * z - x * w);
+    R[2][0] = 2 * (x * z - y * w);     R[2][1] = 2 * (y * z + x * w);     R[2][2] = 1 - 2 * (x * x + y * y);
+}
+
 static int contact_force_sphere(const orc_dyn_params* d, const double pos[3], const double vel[3], double radius, double f[3]);
 
 int orc_dyn_contact_force(const orc_dyn_params* d, const double pos[3], const double vel[3], double f[3])
@@ -361,6 +372,47 @@ static int contact_force_sphere(const orc_dyn_params* d, const double pos[3], co
             if (fn > 0) { for (int k = 0; k < 3; k++) f[k] += fn * n[k]; active = 1; }
         }
     }
+    for (int b = 0; b < d->n_scene && b < ORC_MAX_SCENE; b++) {
+        /* static scene bodies (create_body_plane / _box / _sphere, bullet_scene.py:193-228): signed distance of the sample's
+         * centre to the shape and its outward normal n in the world frame; the sample touches with its surface */
+        const orc_scene_body* B = &d->scene[b];
+        double R[3][3], dd[3], n[3] = {0, 0, 0}, sdf;
+        quat_to_matrix(B->orientation, R);
+        for (int k = 0; k < 3; k++) dd[k] = pos[k] - B->position[k];
+        if (B->shape == ORC_SHAPE_PLANE) {
+            double nl = sqrt(B->size[0] * B->size[0] + B->size[1] * B->size[1] + B->size[2] * B->size[2]);
+            for (int k = 0; k < 3; k++) n[k] = (R[k][0] * B->size[0] + R[k][1] * B->size[1] + R[k][2] * B->size[2]) / nl;
+            sdf = n[0] * dd[0] + n[1] * dd[1] + n[2] * dd[2];
+        } else if (B->shape == ORC_SHAPE_SPHERE) {
+            double len = sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]);
+            sdf = len - B->size[0];
+            if (len > 0) { for (int k = 0; k < 3; k++) n[k] = dd[k] / len; } else n[2] = 1.0;
+        } else if (B->shape == ORC_SHAPE_BOX) {
+            double l[3], q[3], o[3], nl[3] = {0, 0, 0}, out2 = 0, qmax = -1e300; int kmax = 0;
+            for (int k = 0; k < 3; k++) l[k] = R[0][k] * dd[0] + R[1][k] * dd[1] + R[2][k] * dd[2];     /* R^T dd */
+            for (int k = 0; k < 3; k++) {
+                q[k] = fabs(l[k]) - B->size[k];
+                o[k] = q[k] > 0 ? q[k] : 0.0;
+                out2 += o[k] * o[k];
+                if (q[k] > qmax) { qmax = q[k]; kmax = k; }
+            }
+            if (out2 > 0) {
+                double len = sqrt(out2);
+                sdf = len;
+                for (int k = 0; k < 3; k++) nl[k] = (l[k] < 0 ? -o[k] : o[k]) / len;
+            } else {
+                sdf = qmax;
+                nl[kmax] = l[kmax] < 0 ? -1.0 : 1.0;
+            }
+            for (int k = 0; k < 3; k++) n[k] = R[k][0] * nl[0] + R[k][1] * nl[1] + R[k][2] * nl[2];
+        } else continue;
+        double depth = radius - sdf;
+        if (depth > 0) {
+            double vn = vel[0] * n[0] + vel[1] * n[1] + vel[2] * n[2];
+            double fn = d->contact_kp * depth - d->contact_kd * vn;
+            if (fn > 0) { for (int k = 0; k < 3; k++) f[k] += fn * n[k]; active = 1; }
+        }
+    }
     return active;
 }
 
@@ -393,7 +445,7 @@ void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state
         t -= s->friction[i] * s->qd[i] / sqrt(s->qd[i] * s->qd[i] + FRICTION_EPS * FRICTION_EPS);
         tau[i] = t;
     }
-    if (d->ground_z == d->ground_z || d->obstacle_half_extents[0] > 0)
+    if (d->ground_z == d->ground_z || d->obstacle_half_extents[0] > 0 || d->n_scene > 0)
         have_ext = orc_dyn_contact_wrenches(d, s, fext);
     orc_dyn_aba_ext(s, tau, d->gravity, have_ext ? (const double (*)[6])fext : NULL, qdd);
     for (int i = 0; i < ORC_DOF; i++) {          /* semi-implicit Euler + inelastic joint limits */

@@ -26,6 +26,18 @@ extern "C" {
 
 #define ORC_LINKS 11
 
+/* a static body of the scene: World/Scene.create_body_plane / create_body_box / create_body_sphere with mass 0 and a
+ * collision shape (bullet_scene.py:193-246); orientation is Bullet's quaternion (x, y, z, w) */
+#define ORC_MAX_SCENE 8
+enum { ORC_SHAPE_NONE = 0, ORC_SHAPE_PLANE = 1, ORC_SHAPE_BOX = 2, ORC_SHAPE_SPHERE = 3 };
+typedef struct orc_scene_body {
+    int32_t shape;
+    int32_t pad;
+    double position[3];
+    double orientation[4];
+    double size[3];           /* plane: planeNormal in the body frame; box: halfExtents; sphere: radius in size[0] */
+} orc_scene_body;
+
 typedef struct orc_dyn_params {
     double kp, kd;            /* PD gains on (r - q), (v - qd): Joint.control_position's positionGain/velocityGain role, bullet_scene.py:123-142 */
     double torque_limit;      /* `force` cap; <= 0 = unlimited */
@@ -49,6 +61,9 @@ typedef struct orc_dyn_params {
     int32_t link_contacts;    /* 0: only the pointer sphere collides; 1: sample spheres along every moving link too
                                  (capsules fitted to the URDF's visual boxes, which carry no <collision> of their own) */
     double max_velocity;      /* control_position's maxVelocity: cap on the velocity the motor asks for; <= 0 = none */
+    int32_t n_scene;          /* static scene bodies every contact sample sphere collides with (surface to surface) */
+    int32_t pad2;
+    orc_scene_body scene[ORC_MAX_SCENE];
 } orc_dyn_params;
 
 #define ORC_CONTACT_SAMPLES 23

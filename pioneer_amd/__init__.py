@@ -5,10 +5,12 @@ Drop-in for the hot path of xdralex/pioneer's ``pioneer.envs``: the per-env
 ``csrc/libpioneer_amd.so`` behind the C ABI of ``include/pioneer_amd.h``; this
 package is the host-side mirror of the reference's Python interface.
 """
-from .config import EngineConfig, PioneerKinematicConfig, RenderConfig, SimulationConfig  # noqa: F401
+from .config import (EngineConfig, PioneerKinematicConfig, RenderConfig, SceneBody, SimulationConfig,  # noqa: F401
+                     scene_box, scene_plane, scene_sphere)
 from ._lib import PnrError, build_library, load_library  # noqa: F401
 
-__all__ = ["EngineConfig", "PioneerKinematicConfig", "RenderConfig", "SimulationConfig",
+__all__ = ["EngineConfig", "PioneerKinematicConfig", "RenderConfig", "SimulationConfig", "SceneBody", "scene_box", "scene_plane",
+           "scene_sphere",
            "PioneerVectorEnv", "PioneerKinematicEnv", "TimeLimit", "make_env",
            "PnrError", "build_library", "load_library"]
 

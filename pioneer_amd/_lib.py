@@ -33,6 +33,15 @@ class PnrError(RuntimeError):
         self.code = code
 
 
+MAX_SCENE = 8
+SHAPE_PLANE, SHAPE_BOX, SHAPE_SPHERE = 1, 2, 3
+
+
+class PnrSceneBody(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("reserved", C.c_int32), ("position", C.c_double * 3), ("orientation", C.c_double * 4),
+                ("size", C.c_double * 3)]
+
+
 class PnrConfig(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
@@ -54,6 +63,7 @@ class PnrConfig(C.Structure):
         ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
         ("pointer_radius", C.c_double),
         ("control_mode", C.c_int32), ("link_contacts", C.c_int32), ("max_velocity", C.c_double),
+        ("n_scene", C.c_int32), ("reserved0", C.c_int32), ("scene", PnrSceneBody * MAX_SCENE),
     ]
 
 

@@ -60,6 +60,32 @@ class RenderConfig:
     projection_far: float = 200.0
 
 
+@dataclass(frozen=True)
+class SceneBody:
+    """A static body of the scene (mass 0, with a collision shape): what Scene.create_body_plane / create_body_box /
+    create_body_sphere (bullet_scene.py:193-228) add to the world.  Dynamics mode only; every contact sample of the arm
+    collides with it.  Build with scene_plane / scene_box / scene_sphere, whose arguments are the reference's."""
+    shape: str                                              # "plane" | "box" | "sphere"
+    position: Tuple[float, float, float]
+    orientation: Tuple[float, float, float, float] = (0.0, 0.0, 0.0, 1.0)   # Bullet quaternion (x, y, z, w)
+    size: Tuple[float, float, float] = (0.0, 0.0, 0.0)     # plane normal | box half extents | (radius, 0, 0)
+
+
+def scene_plane(normal, position=(0.0, 0.0, 0.0), orientation=(0.0, 0.0, 0.0, 1.0)) -> SceneBody:
+    """create_body_plane(name, mass=0, normal, position, orientation), bullet_scene.py:219-227."""
+    return SceneBody("plane", tuple(map(float, position)), tuple(map(float, orientation)), tuple(map(float, normal)))
+
+
+def scene_box(half_extents, position, orientation=(0.0, 0.0, 0.0, 1.0)) -> SceneBody:
+    """create_body_box(name, collision=True, mass=0, half_extents, position, orientation, rgba), bullet_scene.py:206-217."""
+    return SceneBody("box", tuple(map(float, position)), tuple(map(float, orientation)), tuple(map(float, half_extents)))
+
+
+def scene_sphere(radius, position, orientation=(0.0, 0.0, 0.0, 1.0)) -> SceneBody:
+    """create_body_sphere(name, collision=True, mass=0, radius, position, orientation, rgba), bullet_scene.py:193-204."""
+    return SceneBody("sphere", tuple(map(float, position)), tuple(map(float, orientation)), (float(radius), 0.0, 0.0))
+
+
 @dataclass
 class EngineConfig:
     """Options without a reference counterpart."""
@@ -93,6 +119,8 @@ class EngineConfig:
     # contacts of the LINKS with the plane / box: sample spheres along capsules fitted to the URDF's visual boxes (the
     # reference URDF carries no <collision> elements, so without this only the pointer sphere collides)
     link_contacts: bool = False
+    # further static bodies (up to 8): planes of any normal, oriented boxes, spheres — see SceneBody
+    scene: Tuple[SceneBody, ...] = ()
 
 
 _LAYOUTS = {"env_major": _lib.ENV_MAJOR, "feature_major": _lib.FEATURE_MAJOR}
@@ -142,6 +170,18 @@ def to_c_config(pioneer: PioneerKinematicConfig, sim: SimulationConfig, engine: 
     c.control_mode = _CONTROLS[engine.control_mode]
     c.max_velocity = float(engine.max_velocity)
     c.link_contacts = int(bool(engine.link_contacts))
+    shapes = {"plane": _lib.SHAPE_PLANE, "box": _lib.SHAPE_BOX, "sphere": _lib.SHAPE_SPHERE}
+    if len(engine.scene) > _lib.MAX_SCENE:
+        raise AssertionError(f"at most {_lib.MAX_SCENE} scene bodies")
+    c.n_scene = len(engine.scene)
+    for i, b in enumerate(engine.scene):
+        if b.shape not in shapes:
+            raise AssertionError(f"scene body {i}: shape must be one of {sorted(shapes)}")
+        c.scene[i].shape = shapes[b.shape]
+        for k in range(3):
+            c.scene[i].position[k] = float(b.position[k]); c.scene[i].size[k] = float(b.size[k])
+        for k in range(4):
+            c.scene[i].orientation[k] = float(b.orientation[k])
     # SimulationConfig.self_collision / collision_parent (bullet_env.py:43-58) select pybullet's URDF_USE_SELF_COLLISION load
     # flags.  The reference URDF has no <collision> elements, so in the reference they change nothing — and here they
     # are accepted with that same meaning.  What is NOT modelled is self-collision between the build-defined link

@@ -719,6 +719,7 @@ struct pnr_env_s {
     int device;
     float4* state;
     float* dyn;          // dynamics-mode planar words [36][n] or null
+    SceneBody* scene;    // dynamics-mode static scene bodies [kMaxScene] or null
     int diag;            // PNR_DIAG env var at create time (timing-only ablations; 0 in production)
     bool ready;          // a full reset has happened, or the state was set explicitly
     bool kin_set, dyn_set;  // pnr_set_state / pnr_set_dyn_state seen (both needed in dynamics mode)
@@ -789,6 +790,7 @@ int pnr_config_default(pnr_config* c)
     c->obstacle_half_extents[0] = c->obstacle_half_extents[1] = c->obstacle_half_extents[2] = 0.0; // disabled
     c->pointer_radius = 0.2;
     c->control_mode = PNR_CONTROL_POSITION; c->max_velocity = 0.0; c->link_contacts = 0;
+    c->n_scene = 0;                                         // scene[] zeroed by the memset above
     return PNR_OK;
 }
 
@@ -814,6 +816,25 @@ static int check_config(const pnr_config* c)
     for (int k = 0; k < 3; ++k)
         if (!(c->target_hi[k] >= c->target_lo[k]))
             return fail(nullptr, PNR_ERR_INVALID, "target_hi[%d] < target_lo[%d]", k, k);
+    if (c->n_scene < 0 || c->n_scene > PNR_MAX_SCENE)
+        return fail(nullptr, PNR_ERR_INVALID, "n_scene %d outside 0..%d", c->n_scene, PNR_MAX_SCENE);
+    if (c->n_scene > 0 && c->mode != PNR_MODE_DYNAMIC)
+        return fail(nullptr, PNR_ERR_INVALID, "scene bodies collide in dynamics mode only (the kinematic arm passes through everything, as the reference's does)");
+    for (int b = 0; b < c->n_scene; ++b) {
+        const pnr_scene_body& S = c->scene[b];
+        const double qn = S.orientation[0] * S.orientation[0] + S.orientation[1] * S.orientation[1] +
+                          S.orientation[2] * S.orientation[2] + S.orientation[3] * S.orientation[3];
+        if (!(qn > 0)) return fail(nullptr, PNR_ERR_INVALID, "scene body %d: zero orientation quaternion", b);
+        if (S.shape == PNR_SHAPE_PLANE) {
+            if (!(S.size[0] * S.size[0] + S.size[1] * S.size[1] + S.size[2] * S.size[2] > 0))
+                return fail(nullptr, PNR_ERR_INVALID, "scene body %d: zero plane normal", b);
+        } else if (S.shape == PNR_SHAPE_BOX) {
+            if (!(S.size[0] > 0 && S.size[1] > 0 && S.size[2] > 0))
+                return fail(nullptr, PNR_ERR_INVALID, "scene body %d: box half extents must be > 0", b);
+        } else if (S.shape == PNR_SHAPE_SPHERE) {
+            if (!(S.size[0] > 0)) return fail(nullptr, PNR_ERR_INVALID, "scene body %d: sphere radius must be > 0", b);
+        } else return fail(nullptr, PNR_ERR_INVALID, "scene body %d: bad shape %d", b, S.shape);
+    }
     return PNR_OK;
 }
 
@@ -870,6 +891,30 @@ static void fill_base(pnr_handle h)
         D.v_cap = capped ? (float)c.max_velocity : INFINITY;
     }
     D.link_contacts = c.link_contacts ? 1 : 0;
+    D.n_scene = h->scene ? c.n_scene : 0;
+    D.scene = h->scene;
+    SceneBody host_scene[kMaxScene];
+    for (int b = 0; b < kMaxScene; ++b) {
+        SceneBody& S = host_scene[b];
+        S = SceneBody{};
+        if (b >= c.n_scene) continue;
+        const pnr_scene_body& B = c.scene[b];
+        const double qn = std::sqrt(B.orientation[0] * B.orientation[0] + B.orientation[1] * B.orientation[1] +
+                                    B.orientation[2] * B.orientation[2] + B.orientation[3] * B.orientation[3]);
+        const double x = B.orientation[0] / qn, y = B.orientation[1] / qn, z = B.orientation[2] / qn, w = B.orientation[3] / qn;
+        const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+        S.shape = B.shape;
+        for (int k = 0; k < 3; ++k) { S.pos[k] = (float)B.position[k]; S.size[k] = (float)B.size[k]; }
+        if (B.shape == PNR_SHAPE_PLANE) {               // unit world normal = R n / |n|
+            const double nl = std::sqrt(B.size[0] * B.size[0] + B.size[1] * B.size[1] + B.size[2] * B.size[2]);
+            for (int k = 0; k < 3; ++k) S.rot[k] = (float)((R[3 * k] * B.size[0] + R[3 * k + 1] * B.size[1] + R[3 * k + 2] * B.size[2]) / nl);
+        } else {
+            for (int k = 0; k < 9; ++k) S.rot[k] = (float)R[k];
+        }
+    }
+    if (h->scene) (void)hipMemcpy(h->scene, host_scene, sizeof(host_scene), hipMemcpyHostToDevice);
     D.joint_damping = (float)c.joint_damping; D.joint_friction = (float)c.joint_friction;
     D.mass_lo = c.rand_mass_lo; D.mass_span = c.rand_mass_hi - c.rand_mass_lo;
     D.fric_lo = c.rand_friction_lo; D.fric_span = c.rand_friction_hi - c.rand_friction_lo;
@@ -926,6 +971,10 @@ int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, i
         e = hipMalloc((void**)&h->dyn, bytes);
         if (e != hipSuccess) { (void)hipFree(h->state); delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(dyn) failed: %s", hipGetErrorString(e)); }
         (void)hipMemset(h->dyn, 0, bytes);
+        if (cfg->n_scene > 0) {
+            e = hipMalloc((void**)&h->scene, sizeof(SceneBody) * kMaxScene);
+            if (e != hipSuccess) { (void)hipFree(h->dyn); (void)hipFree(h->state); delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(scene) failed: %s", hipGetErrorString(e)); }
+        }
     }
     { const char* e_ = getenv("PNR_DIAG"); h->diag = e_ ? atoi(e_) : 0; }
     fill_base(h);
@@ -940,6 +989,7 @@ int pnr_destroy(pnr_handle h)
     DeviceGuard g(h->device);
     if (h->state) (void)hipFree(h->state);
     if (h->dyn) (void)hipFree(h->dyn);
+    if (h->scene) (void)hipFree(h->scene);
     delete h;
     return PNR_OK;
 }
@@ -1059,7 +1109,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
         else hipLaunchKernelGGL((dyn_step_kernel<O, A, R, C>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                 Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); } while (0)
             // contact-free handles run instantiations without any contact code
-#define PNR_DYN_LAUNCH(O, A, R) do { if (D.has_ground || D.has_box) PNR_DYN_LAUNCH2(O, A, R, true); else PNR_DYN_LAUNCH2(O, A, R, false); } while (0)
+#define PNR_DYN_LAUNCH(O, A, R) do { if (D.has_ground || D.has_box || D.n_scene > 0) PNR_DYN_LAUNCH2(O, A, R, true); else PNR_DYN_LAUNCH2(O, A, R, false); } while (0)
             if (oem) {
                 if (aem) { if (rnd) PNR_DYN_LAUNCH(true, true, true); else PNR_DYN_LAUNCH(true, true, false); }
                 else { if (rnd) PNR_DYN_LAUNCH(true, false, true); else PNR_DYN_LAUNCH(true, false, false); }

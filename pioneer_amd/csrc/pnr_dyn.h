@@ -31,6 +31,11 @@
 
 namespace pnr {
 
+// a static scene body as the kernels want it: world position, rotation matrix (row-major; a plane keeps its unit world
+// normal in rot[0..2]), size (box half extents | sphere radius in size[0])
+constexpr int kMaxScene = 8;
+struct SceneBody { int shape; float pos[3]; float rot[9]; float size[3]; };
+
 struct DynParams {
     float* dyn;                 // [36][n]
     float kp, kd, tau_max;      // PD gains, torque cap (<= 0: none)
@@ -49,6 +54,8 @@ struct DynParams {
     //   tau = clip(kp_eff (r - q) + kd (clamp(v + c_pos (r - q), +-v_cap) - qd), +-tau_max)
     float kp_eff, c_pos, v_cap;
     int link_contacts;          // 1: the link capsules' sample spheres collide too (pnr_model.h kCapsules)
+    int n_scene;                // static bodies of create_body_plane / _box / _sphere (bullet_scene.py:193-228)
+    const SceneBody* scene;     // [n_scene] in device memory (a by-value array indexed by the loop counter went to scratch)
 };
 
 constexpr float kFrictionEps = 0.05f;   // smooth sign(qd) = qd / sqrt(qd^2 + eps^2)
@@ -493,6 +500,43 @@ __device__ __forceinline__ void sample_contact(const DynParams& D, const M3& R, 
             sdf = comp(q, km);
             nrm = {km == 0 ? (dd.x < 0.f ? -1.f : 1.f) : 0.f, km == 1 ? (dd.y < 0.f ? -1.f : 1.f) : 0.f,
                    km == 2 ? (dd.z < 0.f ? -1.f : 1.f) : 0.f};
+        }
+        const float depth = radius - sdf;
+        const float fn = D.ckp * depth - D.ckd * dot(vw, nrm);
+        if (depth > 0.f && fn > 0.f) F = F + fn * nrm;
+    }
+    // the scene's static bodies: wave-uniform loop over a small device array, the sample touches with its surface.  Same signed-distance forms as the oracle's contact_force_sphere.
+#pragma unroll 1
+    for (int b = 0; b < D.n_scene; ++b) {
+        const SceneBody S = D.scene[b];
+        const V3 dd = {pos.x - S.pos[0], pos.y - S.pos[1], pos.z - S.pos[2]};
+        V3 nrm; float sdf;
+        if (S.shape == 1) {                                // plane: unit world normal in rot[0..2]
+            nrm = {S.rot[0], S.rot[1], S.rot[2]};
+            sdf = dot(nrm, dd);
+        } else if (S.shape == 3) {                         // sphere
+            const float len = sqrtf(dot(dd, dd));
+            sdf = len - S.size[0];
+            nrm = len > 0.f ? (1.f / len) * dd : V3{0.f, 0.f, 1.f};
+        } else {                                           // oriented box: into its frame, out again with the normal
+            const V3 l = {S.rot[0] * dd.x + S.rot[3] * dd.y + S.rot[6] * dd.z, S.rot[1] * dd.x + S.rot[4] * dd.y + S.rot[7] * dd.z,
+                          S.rot[2] * dd.x + S.rot[5] * dd.y + S.rot[8] * dd.z};
+            const V3 q = {fabsf(l.x) - S.size[0], fabsf(l.y) - S.size[1], fabsf(l.z) - S.size[2]};
+            const V3 o = {fmaxf(q.x, 0.f), fmaxf(q.y, 0.f), fmaxf(q.z, 0.f)};
+            const float out2 = dot(o, o);
+            V3 nl;
+            if (out2 > 0.f) {
+                const float len = sqrtf(out2);
+                sdf = len;
+                nl = {(l.x < 0.f ? -o.x : o.x) / len, (l.y < 0.f ? -o.y : o.y) / len, (l.z < 0.f ? -o.z : o.z) / len};
+            } else {
+                const int km = (q.x >= q.y && q.x >= q.z) ? 0 : (q.y >= q.z ? 1 : 2);
+                sdf = comp(q, km);
+                nl = {km == 0 ? (l.x < 0.f ? -1.f : 1.f) : 0.f, km == 1 ? (l.y < 0.f ? -1.f : 1.f) : 0.f,
+                      km == 2 ? (l.z < 0.f ? -1.f : 1.f) : 0.f};
+            }
+            nrm = {S.rot[0] * nl.x + S.rot[1] * nl.y + S.rot[2] * nl.z, S.rot[3] * nl.x + S.rot[4] * nl.y + S.rot[5] * nl.z,
+                   S.rot[6] * nl.x + S.rot[7] * nl.y + S.rot[8] * nl.z};
         }
         const float depth = radius - sdf;
         const float fn = D.ckp * depth - D.ckd * dot(vw, nrm);

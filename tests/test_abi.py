@@ -88,6 +88,22 @@ def test_bad_config_is_rejected(hip_lib):
     assert hip_lib.pnr_get_constants(c, k) == -1
     hip_lib.pnr_config_default(c); c.timestep = 0.0
     assert hip_lib.pnr_get_constants(c, k) == -1
+    # static scene bodies (create_body_plane / _box / _sphere): dynamics mode only, sane shapes and sizes
+    from pioneer_amd.config import EngineConfig, PioneerKinematicConfig, SimulationConfig, scene_box, scene_plane, scene_sphere, to_c_config
+    good = (scene_plane((0, 0, 1), (0, 0, 2)), scene_box((1, 2, 3), (10, 0, 0), (0, 0, 0.5, 0.5)), scene_sphere(2.0, (15, 5, 5)))
+    c = to_c_config(PioneerKinematicConfig(), SimulationConfig(), EngineConfig(mode="dynamic", scene=good))
+    assert c.n_scene == 3 and hip_lib.pnr_get_constants(c, k) == 0
+    c.mode = _lib.MODE_KINEMATIC
+    assert hip_lib.pnr_get_constants(c, k) == -1 and b"dynamics mode only" in hip_lib.pnr_last_error(None)
+    for bad, msg in ((scene_box((1, 0, 3), (0, 0, 0)), b"half extents"), (scene_sphere(0.0, (0, 0, 0)), b"radius"),
+                     (scene_plane((0, 0, 0)), b"plane normal"), (scene_sphere(1.0, (0, 0, 0), (0, 0, 0, 0)), b"quaternion")):
+        c = to_c_config(PioneerKinematicConfig(), SimulationConfig(), EngineConfig(mode="dynamic", scene=(bad,)))
+        assert hip_lib.pnr_get_constants(c, k) == -1 and msg in hip_lib.pnr_last_error(None)
+    c.n_scene = 9
+    assert hip_lib.pnr_get_constants(c, k) == -1
+    import pytest
+    with pytest.raises(AssertionError):
+        to_c_config(PioneerKinematicConfig(), SimulationConfig(), EngineConfig(mode="dynamic", scene=good * 3))
 
 
 def test_create_fails_loudly_without_gpu(hip_lib):

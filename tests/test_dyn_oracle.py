@@ -6,6 +6,8 @@ Jacobians -> mass matrix M(q); Coriolis and gravity terms by numerical different
 M(q) and of the potential energy.  Plus energy conservation, contact, limits, and the
 reduction to the kinematic (reference) semantics under teleport.
 """
+import math
+
 import numpy as np
 import pytest
 
@@ -341,3 +343,59 @@ def test_an_arm_link_rests_on_the_ground_plane(oracle_built):
         low[name] = zmin
     assert low["links"] > 12.5 - 0.7 - 0.6                   # held near the plane (sphere radius 0.7 + bounded penetration)
     assert low["pointer_only"] < low["links"] - 1.0
+
+
+def _wrench(dyn, q, qd=None):
+    o = DynOracle(1, seed=0, dyn=dyn)
+    o.reset(joint_pos=np.asarray(q, float)[None])
+    o.dstate["q"][0] = q
+    o.dstate["qd"][0] = 0.0 if qd is None else qd
+    return o.contact_wrenches(0)
+
+
+def test_scene_bodies_reduce_to_the_legacy_plane_and_box_and_rotate_consistently():
+    """The static scene bodies (create_body_plane / _box / _sphere, bullet_scene.py:193-228) against what is already
+    validated: a z-normal plane and an identity-orientation box ARE the legacy ground / obstacle (same wrenches);
+    turning a box by 90 degrees about z equals swapping its x / y half extents; a plane given by a rotated body-frame
+    normal equals the plane given by the rotated normal directly."""
+    rng = np.random.RandomState(3)
+    h = math.sqrt(0.5)
+    for _ in range(20):
+        q = rng.uniform(-1.2, 1.2, 6)
+        qd = rng.uniform(-1, 1, 6)
+        # plane (with link contacts the legacy ground also touches with the surface)
+        a = _wrench(dict(ground_z=6.0, link_contacts=1), q, qd)
+        b = _wrench(dict(link_contacts=1, scene=[("plane", (3.0, -2.0, 6.0), (0, 0, 0, 1), (0, 0, 5.0))]), q, qd)
+        assert a[0] == b[0] and np.allclose(a[1], b[1], rtol=1e-12, atol=1e-12)
+        # box
+        box = dict(obstacle_position=(12.0, 0.0, 4.0), obstacle_half_extents=(4.0, 6.0, 3.0))
+        a = _wrench(dict(link_contacts=1, **box), q, qd)
+        b = _wrench(dict(link_contacts=1, scene=[("box", (12.0, 0.0, 4.0), (0, 0, 0, 1), (4.0, 6.0, 3.0))]), q, qd)
+        c = _wrench(dict(link_contacts=1, scene=[("box", (12.0, 0.0, 4.0), (0, 0, h, h), (6.0, 4.0, 3.0))]), q, qd)
+        assert a[0] == b[0] == c[0]
+        assert np.allclose(a[1], b[1], rtol=1e-12, atol=1e-12) and np.allclose(a[1], c[1], rtol=1e-9, atol=1e-9)
+        # a plane's normal lives in the body frame: normal x turned 90 degrees about y -> -z ... check with +z from -x
+        a = _wrench(dict(link_contacts=1, scene=[("plane", (0, 0, 6.0), (0, 0, 0, 1), (0, 0, 1.0))]), q, qd)
+        b = _wrench(dict(link_contacts=1, scene=[("plane", (0, 0, 6.0), (0, h, 0, h), (-1.0, 0, 0))]), q, qd)   # R_y(90) (-x) = +z
+        assert a[0] == b[0] and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-9)
+
+
+def test_scene_sphere_pushes_the_pointer_radially():
+    """A static sphere around the resting pointer: force on body 6 = kp * depth along (pointer - centre), zero torque about
+    the pointer; outside reach nothing happens."""
+    q = np.zeros(6)
+    o = DynOracle(1, seed=0, dyn=dict())
+    o.reset(joint_pos=q[None])
+    tip = o.observe()[0, 126:129].copy() if hasattr(o, "observe") else None
+    assert tip is not None
+    centre = tip + np.array([0.3, -0.2, 0.1])
+    R, r = 1.0, 0.2
+    any_, f = _wrench(dict(scene=[("sphere", tuple(centre), (0, 0, 0, 1), (R, 0, 0))]), q)
+    assert any_
+    d = tip - centre
+    depth = r + R - np.linalg.norm(d)
+    want = 2000.0 * depth * d / np.linalg.norm(d)
+    # the wrench is in body 6's frame; at q = 0 every body frame is parallel to the world's
+    assert np.allclose(f[5, 3:6], want, rtol=1e-9, atol=1e-9)
+    any_, f = _wrench(dict(scene=[("sphere", tuple(tip + 10.0), (0, 0, 0, 1), (R, 0, 0))]), q)
+    assert not any_ and not f.any()

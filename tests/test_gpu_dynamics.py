@@ -14,6 +14,8 @@ articulated inertia) are integrated open-loop over the ten sub-steps; per-env li
 accelerations the same way.  r01 first set 2e-5 from the pd / gravity scenarios alone and torque_limited missed it
 by 5 % (2.098e-5); 5e-5 is 2.4x the worst measured value, QD_TOL = 2e-3 is 1.7x.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -25,9 +27,16 @@ pytestmark = pytest.mark.gpu
 
 Q_TOL, QD_TOL = 5e-5, 2e-3
 
+_c, _s = math.cos(0.35), math.sin(0.35)
+_ax = np.array([1.0, 2.0, 0.5]) / np.linalg.norm([1.0, 2.0, 0.5])
+SCENE = (("plane", (0.0, 0.0, 1.0), (0.0, math.sin(0.1), 0.0, math.cos(0.1)), (0.0, 0.0, 2.0)),        # tilted 0.2 rad about y
+         ("box", (9.0, -7.0, 12.0), tuple(_ax * _s) + (_c,), (6.0, 7.0, 5.0)),                          # turned 0.7 rad about a skew axis
+         ("sphere", (-7.0, 8.0, 14.0), (0.0, 0.0, 0.0, 1.0), (8.0, 0.0, 0.0)))                          # inside the arm's reach
+
 
 def make(n, seed=0, auto_reset=False, max_steps=0, layout="env_major", gravity=0.0, **dyn):
     from pioneer_amd import PioneerVectorEnv, EngineConfig, SimulationConfig
+    from pioneer_amd.config import SceneBody
     ek = dict(dyn)
     eng = EngineConfig(mode="dynamic", auto_reset=auto_reset, max_episode_steps=max_steps, obs_layout=layout,
                        pd_kp=ek.pop("kp", 4000.0), pd_kd=ek.pop("kd", 400.0), torque_limit=ek.pop("torque_limit", 0.0),
@@ -39,7 +48,8 @@ def make(n, seed=0, auto_reset=False, max_steps=0, layout="env_major", gravity=0
                        obstacle_half_extents=ek.pop("obstacle_half_extents", (0.0, 0.0, 0.0)),
                        pointer_radius=ek.pop("pointer_radius", 0.2),
                        control_mode={0: "position", 1: "velocity"}[ek.pop("control_mode", 0)],
-                       max_velocity=ek.pop("max_velocity", 0.0), link_contacts=bool(ek.pop("link_contacts", 0)))
+                       max_velocity=ek.pop("max_velocity", 0.0), link_contacts=bool(ek.pop("link_contacts", 0)),
+                       scene=tuple(SceneBody(sh, tuple(p), tuple(q), tuple(sz)) for sh, p, q, sz in ek.pop("scene", ())))
     assert not ek
     env = PioneerVectorEnv(n, device="cuda:0", seed=seed, simulation_config=SimulationConfig(gravity=gravity),
                            engine_config=eng)
@@ -73,7 +83,8 @@ def test_teleport_zero_gravity_equals_kinematic_kernel():
 
 
 @pytest.mark.parametrize("scenario", ["pd", "gravity_friction", "randomized", "ground", "torque_limited", "box", "box_and_ground",
-                                      "velocity_control", "max_velocity", "links_ground", "box_links"])
+                                      "velocity_control", "max_velocity", "links_ground", "box_links", "scene_pointer",
+                                      "scene_links"])
 def test_single_step_parity_resynced(scenario):
     cfg = {
         "pd": dict(),
@@ -92,6 +103,10 @@ def test_single_step_parity_resynced(scenario):
         # of the random poses, and the large block of the "box" scenario
         "links_ground": dict(gravity=9.81, ground_z=6.0, link_contacts=1),
         "box_links": dict(gravity=9.81, link_contacts=1, obstacle_position=(12.0, 0.0, 4.0), obstacle_half_extents=(4.0, 6.0, 4.0)),
+        # static scene bodies (create_body_plane / _box / _sphere, bullet_scene.py:193-228): a tilted plane, a box turned
+        # about a skew axis and a large sphere, all inside the arm's reach; first the pointer alone, then all 23 samples
+        "scene_pointer": dict(gravity=9.81, pointer_radius=1.0, scene=SCENE),
+        "scene_links": dict(gravity=9.81, link_contacts=1, scene=SCENE),
     }[scenario]
     n = 2048
     env, orc = make(n, seed=5, **cfg)
@@ -108,10 +123,10 @@ def test_single_step_parity_resynced(scenario):
         w = env.get_dyn_state().cpu().numpy().astype(np.float64)
         eq = np.abs(w[0:6].T - orc.dstate["q"]).max(1); eqd = np.abs(w[6:12].T - orc.dstate["qd"]).max(1)
         o = obs.double().cpu().numpy()
-        loose = scenario.startswith("box") or scenario == "links_ground"
+        loose = scenario.startswith("box") or scenario == "links_ground" or scenario.startswith("scene")
         worst_q = max(worst_q, float(np.quantile(eq, 0.995) if loose else eq.max()))
         worst_qd = max(worst_qd, float(np.quantile(eqd, 0.995) if loose else eqd.max()))
-        if scenario.startswith("box") or scenario == "links_ground":
+        if loose:
             # (links_ground: 23 one-sided springs per env switch on at depth 0, same argument)
             # the nearest-face normal of a box is discontinuous on its medial axis and the penalty force
             # switches on at depth 0: an env sitting within float32 noise of either may legitimately take
@@ -128,6 +143,16 @@ def test_single_step_parity_resynced(scenario):
         assert np.array_equal(env.get_state().cpu().numpy().view(np.uint32)[:21], orc.state_words()[:21])
     st = env.get_dyn_state().cpu().numpy()
     assert np.all(st[0:6].T <= env.r_hi) and np.all(st[0:6].T >= env.r_lo)
+    if scenario.startswith("scene"):
+        # the comparison above means something only if the bodies are touched: every one of the three shapes, alone, is in
+        # contact in a visible share of the final states (oracle's own contact test on the states both sides agree on)
+        for body in SCENE:
+            one = dict(cfg); one["scene"] = (body,)
+            probe = DynOracle(n, seed=5, precision=ORC_DEV, nthreads=8, dyn=dict(one, gravity=cfg["gravity"]))
+            probe.reset()
+            probe.load_state_words(orc.state_words()); probe.load_dyn_words(orc.dyn_words())
+            share = np.mean([probe.contact_wrenches(e)[0] for e in range(0, n, 4)])
+            assert share > 0.01, (body[0], share)     # 5-35 % at reset; the penalty springs push most samples out again
     env.close()
     _record_margin(scenario, worst_q, worst_qd)
 
