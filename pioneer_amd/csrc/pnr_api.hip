@@ -1238,7 +1238,7 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
     P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
     P.xs = static_cast<__bf16*>(xs); P.h1 = static_cast<__bf16*>(h1); P.h2 = static_cast<__bf16*>(h2);
     P.B = batch; P.first_net = first_net; P.n_nets = n_nets;
-    hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kMlpThreads), 0,
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kMlpThreads), 0,
                        (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
@@ -1290,7 +1290,7 @@ int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float
     P.B = batch; P.first_net = 0; P.n_nets = kMlpNets;
     P.noise = noise; P.a_max = a_max; P.mean = mean; P.log_std = log_std; P.values = values; P.actions = actions;
     P.env_actions = a_max ? env_actions : actions;
-    hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0,
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0,
                        (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
@@ -1377,33 +1377,30 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     if (s->slab_floats < slices * kMlpNets * kGradElems)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: slabs hold %lld floats, the launch needs %lld",
                     (long long)s->slab_floats, slices * kMlpNets * kGradElems);
-    const long long blocks = (B + kPpoBlock - 1) / kPpoBlock;
-    if (s->partial_rows < blocks) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: partials too small");
     hipStream_t st = (hipStream_t)stream;
     const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), kMlpNets), thr(kMlpThreads);
+    const long long prow = (long long)tiles.x * kMlpNets;       // one row of loss sums per workgroup of the fused kernel
+    if (s->partial_rows < prow)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: partials hold %lld rows, the launch needs %lld",
+                    (long long)s->partial_rows, prow);
 
+    // forward + loss + backward-data of each 64-sample tile in ONE launch (mlp_forward_kernel<true>), then the means
     MlpFwdParams F = {};
     F.obs = s->obs; F.idx = reinterpret_cast<const long long*>(s->idx); F.f_loc = s->f_loc; F.f_inv = s->f_inv; F.f_lo = s->f_lo; F.f_hi = s->f_hi;
-    F.wpack = static_cast<const __bf16*>(s->wpack); F.bias = s->bias; F.head = s->head;
+    F.wpack = static_cast<const __bf16*>(s->wpack); F.bias = s->bias; F.head = nullptr;
     F.xs = static_cast<__bf16*>(s->xs); F.h1 = static_cast<__bf16*>(s->h1); F.h2 = static_cast<__bf16*>(s->h2);
     F.B = B; F.first_net = 0; F.n_nets = kMlpNets;
-    hipLaunchKernelGGL(mlp_forward_kernel, tiles, thr, 0, st, F);
-
-    PpoLossParams L;
-    L.head_p = s->head; L.head_v = s->head + (size_t)B * kMlpHead; L.actions = s->actions; L.logp_old = s->logp_old;
-    L.mean_old = s->mean_old; L.ls_old = s->log_std_old; L.adv = s->adv; L.vtarg = s->value_target; L.v_old = s->value_old;
-    L.idx = F.idx; L.kl_coeff = s->kl_coeff; L.ent_coeff = s->entropy_coeff;
-    L.g_head_p = s->g_head; L.g_head_v = s->g_head + (size_t)B * kMlpHead; L.partials = s->partials;
-    L.B = B; L.clip = s->clip_param; L.vf_clip = s->vf_clip_param; L.vf_coeff = s->vf_loss_coeff;
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)blocks), dim3(kPpoBlock), 0, st, L);
-    hipLaunchKernelGGL(ppo_loss_finish_kernel, dim3(1), dim3(64), 0, st, s->partials, blocks, B, s->means, s->adam_step);
-
-    MlpBwdParams Bp;
-    Bp.g_head = s->g_head; Bp.wpack = F.wpack; Bp.h1 = F.h1; Bp.h2 = F.h2;
-    Bp.dz1 = static_cast<__bf16*>(s->dz1); Bp.dz2 = static_cast<__bf16*>(s->dz2); Bp.B = B;
-    hipLaunchKernelGGL(mlp_backward_data_kernel, tiles, thr, 0, st, Bp);
+    F.rec_actions = s->actions; F.rec_logp = s->logp_old; F.rec_mean = s->mean_old; F.rec_log_std = s->log_std_old;
+    F.rec_adv = s->adv; F.rec_vtarg = s->value_target; F.rec_values = s->value_old;
+    F.kl_coeff = s->kl_coeff; F.ent_coeff = s->entropy_coeff;
+    F.clip = s->clip_param; F.vf_clip = s->vf_clip_param; F.vf_coeff = s->vf_loss_coeff;
+    F.g_head = s->g_head; F.partials = s->partials;
+    F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, thr, 0, st, F);
+    hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(512), 0, st, s->partials, prow, B, s->means, s->adam_step,
+                       s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
     MlpWgradParams Wp;
-    Wp.g_head = s->g_head; Wp.xs = F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
+    Wp.g_head = s->g_head; Wp.xs = F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
     Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows;
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), thr, 0, st, Wp);
     if (s->flat_grad)

@@ -234,10 +234,26 @@ struct MlpFwdParams {
     float* actions;            // [B][6] the sampled (unclipped) action: what the log-prob is taken of
     float* env_actions;        // [B][6] what pnr_step is given (may equal `actions` when a_max is null)
     float* values;             // [B] value head
+    // FUSED instantiation (pnr_mlp_train_step): the loss and the backward-data pass of the same tile follow in the same
+    // launch.  Rollout record as in PpoLossParams (rows gathered by idx); each net's workgroup differentiates its own
+    // half of the loss (the policy and the value terms share nothing but the sample)
+    const float* rec_actions; const float* rec_logp; const float* rec_mean; const float* rec_log_std;
+    const float* rec_adv; const float* rec_vtarg; const float* rec_values;
+    const float* kl_coeff; const float* ent_coeff;
+    float clip, vf_clip, vf_coeff;
+    float* g_head;             // [2][B][16] d loss / d head (float32; the weight-gradient kernel reads it)
+    float* partials;           // [tiles * nets][8] per-workgroup sums: policy rows (-surr, 0, kl, entropy), value rows (0, vf)
+    __bf16* dz1;               // [2][B][256]
+    __bf16* dz2;
 };
 
-// Forward pass of one 128-sample tile through one net: grid (ceil(B / 128), nets), 256 threads.
-__global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdParams P)
+// Forward pass of one 64-sample tile through one net: grid (ceil(B / 64), nets), 256 threads.
+// FUSED: followed, in the same workgroup, by the tile's loss (one wave, a thread per sample) and its backward-data
+// pass — the activations are written once (for the weight-gradient kernel) and never read back, except H1, which
+// returns from L2 while dZ2 is being multiplied.  One 256-column LDS tile serves H1, H2, dZ2 (in place over H2), H1
+// again and dZ1 (in place), the dead input tile holds the head rows and their gradients: 53 KB as in the plain forward.
+template <bool FUSED>
+__global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel(const MlpFwdParams P)
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[kMlpBM * kXS + kMlpBM * kHS];
     __bf16* xt = lds;
@@ -366,6 +382,10 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
             const long long b = row0 + 16 * SB * w + 16 * sb + r16; // column = sample, rows 4g .. 4g+3 = head entries
             const f32x4 h = a3[sb] + b3;
             if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = h;
+            if constexpr (FUSED) {                                    // head rows of the tile, float32 [64][16], in the dead input tile
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(xt) + (16 * SB * w + 16 * sb + r16) * kMlpHead + 4 * g) = h;
+                continue;
+            }
             if (!P.noise) continue;
             if (net == 1) {
                 if (b < P.B && g == 0) P.values[b] = h[0];
@@ -403,6 +423,135 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_forward_kernel(const MlpFwdPa
                 st2(P.log_std + o + 2, ls(h[0]), ls(h[1])); st2(P.log_std + o + 4, ls(h[2]), ls(h[3]));
             }
         }
+    }
+
+    if constexpr (FUSED) {
+        float* hd = reinterpret_cast<float*>(xt);                         // [64][16] float32 head rows (written above)
+        __bf16* gt = xt + kMlpBM * kMlpHead * 2;                          // [64][kGS] bf16 head gradients, behind them
+        __syncthreads();
+        // ---- the tile's loss: wave 0, thread = sample (pnr_ppo.h: the per-sample halves ppo_loss_kernel is made of)
+        if (w == 0) {
+            const long long b = row0 + lane;
+            const bool live = b < P.B;
+            const float invB = 1.0f / (float)P.B;
+            // the sample's rollout record (behind the idx gather), loaded here rather than prefetched: 22 registers live
+            // across the three products cost the third workgroup per CU, which hides this round trip anyway
+            float rec_a[6], rec_m0[6], rec_l0[6], rec_adv = 0.f, rec_lp0 = 0.f, rec_vt = 0.f, rec_v0 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { rec_a[j] = 0.f; rec_m0[j] = 0.f; rec_l0[j] = 0.f; }
+            if (live) {
+                const long long r = P.idx ? P.idx[b] : b;
+                if (net == 0) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { rec_a[j] = P.rec_actions[r * 6 + j]; rec_m0[j] = P.rec_mean[r * 6 + j]; rec_l0[j] = P.rec_log_std[r * 6 + j]; }
+                    rec_adv = P.rec_adv[r]; rec_lp0 = P.rec_logp[r];
+                } else {
+                    rec_vt = P.rec_vtarg[r]; rec_v0 = P.rec_values[r];
+                }
+            }
+            float g[kMlpHead];
+#pragma unroll
+            for (int j = 0; j < kMlpHead; ++j) g[j] = 0.f;
+            float sums[4] = {0.f, 0.f, 0.f, 0.f};                          // -surr, vf, kl, entropy
+            if (live) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(hd + lane * kMlpHead), q1 = *reinterpret_cast<const f32x4*>(hd + lane * kMlpHead + 4),
+                            q2 = *reinterpret_cast<const f32x4*>(hd + lane * kMlpHead + 8);
+                if (net == 0) {
+                    const float m[6] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1]};
+                    const float raw[6] = {q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
+                    float gm[6], gl[6];
+                    ppo_policy_sample(m, raw, rec_a, rec_m0, rec_l0, rec_adv, rec_lp0, P.clip, *P.kl_coeff, *P.ent_coeff, invB, gm, gl,
+                                      sums[0], sums[2], sums[3]);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { g[j] = gm[j]; g[6 + j] = gl[j]; }
+                } else {
+                    float dvf;
+                    ppo_value_sample(q0[0], rec_vt, rec_v0, P.vf_clip, sums[1], dvf);
+                    g[0] = P.vf_coeff * dvf * invB;
+                }
+                f32x4* gp = reinterpret_cast<f32x4*>(P.g_head + ((size_t)net * P.B + b) * kMlpHead);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gp[q] = (f32x4){g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
+            }
+            bf16x8 p0, p1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { p0[j] = (__bf16)g[j]; p1[j] = (__bf16)g[8 + j]; }
+            *reinterpret_cast<bf16x8*>(gt + lane * kGS) = p0;
+            *reinterpret_cast<bf16x8*>(gt + lane * kGS + 8) = p1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x = sums[k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+                sums[k] = x;
+            }
+            if (lane == 0) {
+                float* pr = P.partials + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * 8;
+                *reinterpret_cast<f32x4*>(pr) = (f32x4){sums[0], sums[1], sums[2], sums[3]};
+                *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+
+        // acc * (1 - h^2) with h read from the tile at this lane's own quads and the product written over it
+        const auto bwd_epilogue = [&]() {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        __bf16* at = ht + (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h;
+                        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at);
+                        bf16x4 pk;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const float hf = (float)hv[j]; pk[j] = (__bf16)(acc[rb][cb][4 * q + j] * (1.0f - hf * hf)); }
+                        *reinterpret_cast<bf16x4*>(at) = pk;
+                    }
+        };
+        // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
+        mlp_zero_acc(acc);
+        {
+            const __bf16* wa = wp + kOffW3T + 2 * w * 512 + lane * 8;
+            const bf16x8 a[2] = {ld_global_bf16x8(wa), ld_global_bf16x8(wa + 512)};
+            bf16x8 b[kMlpCB];
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < kMlpCB; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+        }
+        bwd_epilogue();
+        __syncthreads();
+        mlp_store_htile(ht, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+
+        // ---- dH1^T = W2^T . dZ2^T, then H1 into the tile and dZ1 in place over it
+        mlp_zero_acc(acc);
+        mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2T + 2 * w * (kMlpHid / 16) * 512, ht, acc, lane);
+        // H1 comes back (this workgroup wrote it a moment ago: L2) as 16-byte row pieces; requested only now, so that the
+        // 32 registers are not live across the product (three workgroups per CU hide the round trip)
+        uint4 h1r[kMlpBM / 8];
+        {
+            const __bf16* src = P.h1 + (size_t)net * P.B * kMlpHid;
+#pragma unroll
+            for (int i = 0; i < kMlpBM / 8; ++i) {
+                const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
+                h1r[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (row0 + row < P.B) h1r[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
+            }
+        }
+        __syncthreads();                         // every read of dZ2 (the product and the store above) is done
+#pragma unroll
+        for (int i = 0; i < kMlpBM / 8; ++i) {
+            const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
+            *reinterpret_cast<uint4*>(ht + row * kHS + cc * 8) = h1r[i];
+        }
+        __syncthreads();
+        bwd_epilogue();
+        __syncthreads();
+        mlp_store_htile(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
     }
 }
 

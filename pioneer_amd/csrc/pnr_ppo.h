@@ -39,6 +39,65 @@ struct PpoLossParams {
     float clip, vf_clip, vf_coeff;
 };
 
+// The policy half of one sample: head row (means m, raw log-stds) + rollout record -> d loss / d (mean, raw log-std)
+// (already divided by the batch) and the sample's -surrogate, KL and entropy.
+__device__ __forceinline__ void ppo_policy_sample(const float (&m)[6], const float (&raw)[6], const float (&a)[6], const float (&m0)[6],
+                                                  const float (&l0)[6], float adv, float lp0, float clip, float klc, float entc,
+                                                  float invB, float (&gm)[6], float (&gl)[6], float& neg_surr, float& kl_out,
+                                                  float& ent_out)
+{
+    float ls[6], z[6], s[6];
+    bool pass[6];
+    float logp = -0.5f * 6.0f * 1.8378770664093453f;           // -3 log(2 pi)
+    float kl = 0.f, ent = 6.0f * 1.4189385332046727f;          // 6 * 0.5 log(2 pi e)
+    float dkl_m[6], dkl_l[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        pass[j] = raw[j] >= -20.0f && raw[j] <= 2.0f;          // torch.clamp passes the gradient on [min, max]
+        ls[j] = fminf(fmaxf(raw[j], -20.0f), 2.0f);
+        s[j] = expf(-ls[j]);
+        z[j] = (a[j] - m[j]) * s[j];
+        logp += -0.5f * z[j] * z[j] - ls[j];
+        const float ivar = s[j] * s[j];
+        const float d = m0[j] - m[j];
+        const float q = (expf(2.0f * l0[j]) + d * d) * ivar;  // (var0 + (m0 - m)^2) / var
+        kl += ls[j] - l0[j] + 0.5f * q - 0.5f;
+        dkl_m[j] = -d * ivar;
+        dkl_l[j] = 1.0f - q;
+        ent += ls[j];
+    }
+    const float ratio = expf(logp - lp0);
+    const float rc = fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    const float s1 = adv * ratio, s2 = adv * rc;
+    const float surr = fminf(s1, s2);
+    const bool inrange = ratio >= 1.0f - clip && ratio <= 1.0f + clip;
+    // torch.minimum: the smaller argument takes the gradient, a tie splits it; the clipped branch is
+    // constant outside the range
+    float dsurr = 0.f;                                          // d surr / d logp
+    if (s1 < s2) dsurr = s1;
+    else if (s1 == s2) dsurr = 0.5f * s1 + (inrange ? 0.5f * s1 : 0.f);
+    else dsurr = inrange ? s1 : 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        gm[j] = (-dsurr * z[j] * s[j] + klc * dkl_m[j]) * invB;
+        gl[j] = pass[j] ? (-dsurr * (z[j] * z[j] - 1.0f) + klc * dkl_l[j] - entc) * invB : 0.f;
+    }
+    neg_surr = -surr; kl_out = kl; ent_out = ent;
+}
+
+// The value half: clipped value loss (RLlib: max of the plain and the clipped squared error) and d / d v
+__device__ __forceinline__ void ppo_value_sample(float v, float vt, float v0, float vf_clip, float& vf, float& dvf)
+{
+    const float e1 = v - vt;
+    const float dv = v - v0;
+    const bool vin = dv >= -vf_clip && dv <= vf_clip;
+    const float e2 = v0 + fminf(fmaxf(dv, -vf_clip), vf_clip) - vt;
+    const float f1 = e1 * e1, f2 = e2 * e2;
+    vf = fmaxf(f1, f2);
+    const float g1 = 2.0f * e1, g2 = vin ? 2.0f * e2 : 0.f;
+    dvf = f1 > f2 ? g1 : (f1 < f2 ? g2 : 0.5f * (g1 + g2));   // torch.maximum, ties split
+}
+
 __global__ __launch_bounds__(kPpoBlock) void ppo_loss_kernel(const PpoLossParams P)
 {
     __shared__ float red[kPpoSums][kPpoBlock / 64];
@@ -58,53 +117,9 @@ __global__ __launch_bounds__(kPpoBlock) void ppo_loss_kernel(const PpoLossParams
         for (int j = 0; j < 6; ++j) { a[j] = P.actions[r * 6 + j]; m0[j] = P.mean_old[r * 6 + j]; l0[j] = P.ls_old[r * 6 + j]; }
         const float adv = P.adv[r], vt = P.vtarg[r], v0 = P.v_old[r], lp0 = P.logp_old[r];
 
-        float ls[6], z[6], s[6];
-        bool pass[6];
-        float logp = -0.5f * 6.0f * 1.8378770664093453f;           // -3 log(2 pi)
-        float kl = 0.f, ent = 6.0f * 1.4189385332046727f;          // 6 * 0.5 log(2 pi e)
-        float dkl_m[6], dkl_l[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            pass[j] = raw[j] >= -20.0f && raw[j] <= 2.0f;          // torch.clamp passes the gradient on [min, max]
-            ls[j] = fminf(fmaxf(raw[j], -20.0f), 2.0f);
-            s[j] = expf(-ls[j]);
-            z[j] = (a[j] - m[j]) * s[j];
-            logp += -0.5f * z[j] * z[j] - ls[j];
-            const float ivar = s[j] * s[j];
-            const float d = m0[j] - m[j];
-            const float q = (expf(2.0f * l0[j]) + d * d) * ivar;  // (var0 + (m0 - m)^2) / var
-            kl += ls[j] - l0[j] + 0.5f * q - 0.5f;
-            dkl_m[j] = -d * ivar;
-            dkl_l[j] = 1.0f - q;
-            ent += ls[j];
-        }
-        const float ratio = expf(logp - lp0);
-        const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
-        const float s1 = adv * ratio, s2 = adv * rc;
-        const float surr = fminf(s1, s2);
-        const bool inrange = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
-        // torch.minimum: the smaller argument takes the gradient, a tie splits it; the clipped branch is
-        // constant outside the range
-        float dsurr = 0.f;                                          // d surr / d logp
-        if (s1 < s2) dsurr = s1;
-        else if (s1 == s2) dsurr = 0.5f * s1 + (inrange ? 0.5f * s1 : 0.f);
-        else dsurr = inrange ? s1 : 0.f;
-
-        const float e1 = v - vt;
-        const float dv = v - v0;
-        const bool vin = dv >= -P.vf_clip && dv <= P.vf_clip;
-        const float e2 = v0 + fminf(fmaxf(dv, -P.vf_clip), P.vf_clip) - vt;
-        const float f1 = e1 * e1, f2 = e2 * e2;
-        const float vf = fmaxf(f1, f2);
-        const float g1 = 2.0f * e1, g2 = vin ? 2.0f * e2 : 0.f;
-        const float dvf = f1 > f2 ? g1 : (f1 < f2 ? g2 : 0.5f * (g1 + g2));   // torch.maximum, ties split
-
-        float gm[6], gl[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            gm[j] = (-dsurr * z[j] * s[j] + klc * dkl_m[j]) * invB;
-            gl[j] = pass[j] ? (-dsurr * (z[j] * z[j] - 1.0f) + klc * dkl_l[j] - entc) * invB : 0.f;
-        }
+        float gm[6], gl[6], neg_surr, kl, ent, vf, dvf;
+        ppo_policy_sample(m, raw, a, m0, l0, adv, lp0, P.clip, klc, entc, invB, gm, gl, neg_surr, kl, ent);
+        ppo_value_sample(v, vt, v0, P.vf_clip, vf, dvf);
         float4* gp = reinterpret_cast<float4*>(P.g_head_p + i * kPpoHeadStride);
         gp[0] = make_float4(gm[0], gm[1], gm[2], gm[3]);
         gp[1] = make_float4(gm[4], gm[5], gl[0], gl[1]);
@@ -114,8 +129,8 @@ __global__ __launch_bounds__(kPpoBlock) void ppo_loss_kernel(const PpoLossParams
         gv[0] = make_float4(P.vf_coeff * dvf * invB, 0.f, 0.f, 0.f);
         gv[1] = gv[2] = gv[3] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-        acc[0] = -surr; acc[1] = vf; acc[2] = kl; acc[3] = ent;
-        acc[4] = -surr + klc * kl + P.vf_coeff * vf - entc * ent;
+        acc[0] = neg_surr; acc[1] = vf; acc[2] = kl; acc[3] = ent;
+        acc[4] = neg_surr + klc * kl + P.vf_coeff * vf - entc * ent;
     }
     // block sums: wave shuffle, then across the four waves through LDS
 #pragma unroll
@@ -149,6 +164,33 @@ __global__ __launch_bounds__(64) void ppo_loss_finish_kernel(const float* __rest
     s += __shfl_down(s, 16, 64);
     s += __shfl_down(s, 8, 64);
     if (threadIdx.x < kPpoSums) means[k] = s / (float)B;
+}
+
+// The same for the fused forward + loss + backward kernel, whose partial rows come from the policy workgroups
+// (-surrogate, KL, entropy) and the value workgroups (value loss) separately: total = the same combination of the
+// four means that the per-sample form sums (linear, so equal up to float32 summation order).
+__global__ __launch_bounds__(512) void ppo_loss_finish_split_kernel(const float* __restrict__ partials, long long rows, long long B,
+                                                                    float* __restrict__ means, float* __restrict__ step_counter,
+                                                                    const float* __restrict__ kl_coeff, const float* __restrict__ ent_coeff,
+                                                                    float vf_coeff)
+{
+    // 64 walkers per sum slot, rows 64 apart, then a fixed-order sum of the 64 partial sums: deterministic, and short
+    // (a 64-thread block walked 1 024 rows of a 32 768-sample update in 31 us of dependent loads)
+    __shared__ float red[64][kPpoSums];
+    if (step_counter && threadIdx.x == 0) *step_counter += 1.0f;
+    const int k = threadIdx.x & 7, part = threadIdx.x >> 3;
+    float s = 0.f;
+    for (long long r = part; r < rows; r += 64) s += partials[r * kPpoSums + k];
+    red[part][k] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        if (threadIdx.x < kPpoSums)
+            for (int p = 0; p < 64; ++p) t += red[p][threadIdx.x];
+        const float mean = t / (float)B;
+        const float m0 = __shfl(mean, 0, 64), m1 = __shfl(mean, 1, 64), m2 = __shfl(mean, 2, 64), m3 = __shfl(mean, 3, 64);
+        if (threadIdx.x < kPpoSums) means[threadIdx.x] = threadIdx.x == 4 ? m0 + *kl_coeff * m2 + vf_coeff * m1 - *ent_coeff * m3 : mean;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

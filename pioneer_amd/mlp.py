@@ -70,7 +70,7 @@ class HipMLP:
                 "dz1": torch.empty((2, B, HID), **bf), "dz2": torch.empty((2, B, HID), **bf),
                 "slabs": torch.empty(int(self.lib.pnr_mlp_slab_floats(B)), **f32),
                 "head": torch.empty(2 * B * HEAD, **f32), "g": torch.empty(2 * B * HEAD, **f32),
-                "partials": torch.empty(((B + 255) // 256, 8), **f32),
+                "partials": torch.empty((2 * ((B + 63) // 64), 8), **f32),      # one row per (64-sample tile, net)
             }
         return self._train_ws
 
@@ -142,7 +142,7 @@ class HipMLP:
         return out[0], out[1]
 
 
-    # -- the learner path without autograd: one PPO minibatch update = pnr_mlp_train_step (seven launches) ------
+    # -- the learner path without autograd: one PPO minibatch update = pnr_mlp_train_step (four launches) ------
     def adam_state(self):
         """(m, v, step): Adam's moments in the padded gradient layout [pnr_mlp_grad_floats()] and the update count."""
         if not hasattr(self, "_adam"):

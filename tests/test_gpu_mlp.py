@@ -218,7 +218,8 @@ def test_train_step_equals_autograd_plus_torch_adam():
         if it == 0:
             # same weights, same (deterministic) gradient kernels: only the optimiser arithmetic differs.  Adam's first
             # step moves every element by lr * g / (|g| + eps'): compare to a few ulps of the step size
-            assert torch.equal(means[0, :5], m.detach()[:5])
+            # (the fused kernel sums the loss per 64-sample tile and net, the separate loss kernel per 256 samples)
+            assert torch.allclose(means[0, :5], m.detach()[:5], rtol=2e-6, atol=1e-7)
             for a, b in zip(mlp.params, mlp_t.params):
                 assert float((a - b).abs().max()) <= 1e-3 * lr, float((a - b).abs().max())
         # later steps: an element whose gradient is ~0 may take its +-lr step the other way after a last-bit difference,
