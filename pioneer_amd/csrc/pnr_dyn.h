@@ -582,13 +582,11 @@ __device__ __forceinline__ void contact_wrenches(const DynParams& D, const float
 
 // qdd = ABA(q, qd, tau).  CONTACT: the penalty contacts' external forces are subtracted from the bodies' bias forces
 // (a separate instantiation: the contact-free kernels carry none of that code or its registers)
+// c, s: cos / sin of the joint angles (dyn_core carries them across the sub-steps)
 template <bool CONTACT>
-__device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const float (&q)[kDof], const float (&qd)[kDof],
-                                    const float (&tau)[kDof], float (&qdd)[kDof])
+__device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const float (&c)[kDof], const float (&s)[kDof],
+                                    const float (&qd)[kDof], const float (&tau)[kDof], float (&qdd)[kDof])
 {
-    float c[kDof], s[kDof];
-#pragma unroll
-    for (int i = 0; i < kDof; ++i) sincos_bounded(q[i], s[i], c[i]);
 
     // pass 1: body velocities
     P3 v[kDof];
@@ -773,6 +771,15 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
     const float kp = D.teleport ? 0.f : D.kp_eff, kd = D.teleport ? 0.f : D.kd;
     const float cpos = D.c_pos, vcap = D.v_cap;            // 0 and +inf for the plain PD motor: v_ask == v[i] exactly
     const float tcap = D.tau_max > 0.f ? D.tau_max : __builtin_inff();
+    // cos / sin of the joint angles: evaluated once per step and then ROTATED by each sub-step's actual angle change
+    // (|dq| = |qd| / 240 is normally a few hundredths of a radian; sin / cos of it by Taylor polynomials to dq^11 / dq^12:
+    // exact to float32 up to |dq| = 1.3 — the parity suite's wildest transient spins at 265 rad/s = 1.1 rad per sub-step,
+    // and polynomials two terms shorter left 7e-6 there, which that trajectory amplified to 1.4e-3 rad), as (c, s) pairs in
+    // packed registers: ~10 instructions per joint and sub-step instead of the ~35 of a range-reduced sincos.
+    // Ten rotations drift the pair's norm by < 1e-6, and the next step starts from the exact values again.
+    f2 cs[kDof];
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { float sn, cn; sincos_bounded(q[i], sn, cn); cs[i] = (f2){cn, sn}; }
     for (int k = 0; k < D.nsub; ++k) {
         float tau[kDof], qdd[kDof];
 #if PNR_DYN_LDS_MODEL
@@ -797,15 +804,33 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
             tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
             tau[i] = tq;
         }
-        aba<CONTACT>(D, M, q, qd, tau, qdd);
+        {
+            float c[kDof], s[kDof];
+#pragma unroll
+            for (int i = 0; i < kDof; ++i) { c[i] = cs[i].x; s[i] = cs[i].y; }
+            aba<CONTACT>(D, M, c, s, qd, tau, qdd);
+        }
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits (selects, no branches)
             const float hi = limit_hi(i), lo = limit_lo(i);
             const float qdn = qd[i] + qdd[i] * D.dt_sub;
             const float qn = q[i] + qdn * D.dt_sub;
             const bool over = qn > hi, under = qn < lo;
-            q[i] = over ? hi : (under ? lo : qn);
+            const float qnew = over ? hi : (under ? lo : qn);
+            const float dq = qnew - q[i];                          // the angle actually turned (clamps included)
+            q[i] = qnew;
             qd[i] = ((over && qdn > 0.f) || (under && qdn < 0.f)) ? 0.f : qdn;
+            // (cd, sd) = (cos dq, sin dq) as one packed Horner chain in x = dq^2, then (c, s) <- cd (c, s) + sd (-s, c)
+            const float x = dq * dq;
+            f2 p = (f2){1.0f / 479001600.0f, -1.0f / 39916800.0f};
+            p = p * x + (f2){-1.0f / 3628800.0f, 1.0f / 362880.0f};
+            p = p * x + (f2){1.0f / 40320.0f, -1.0f / 5040.0f};
+            p = p * x + (f2){-1.0f / 720.0f, 1.0f / 120.0f};
+            p = p * x + (f2){1.0f / 24.0f, -1.0f / 6.0f};
+            p = p * x + (f2){-0.5f, 1.0f};
+            const float cd = p.x * x + 1.0f, sd = p.y * dq;
+            const f2 rot = (f2){-cs[i].y, cs[i].x};
+            cs[i] = cs[i] * cd + rot * sd;
         }
     }
 }
