@@ -188,13 +188,14 @@ def _record(B, dev, seed=9):
     return {"actions": act, "mean": mean, "log_std": ls, "logp": gaussian_logp(act, mean, ls), "values": R(B), "adv": R(B), "vtarg": R(B)}
 
 
-def test_train_step_equals_autograd_plus_torch_adam():
+@pytest.mark.parametrize("B", [8192, 4099, 1])
+def test_train_step_equals_autograd_plus_torch_adam(B):
     """pnr_mlp_train_step (fused slab reduction + Adam + repacking, update count on the device) against the same HIP
     gradients taken through autograd and applied by torch.optim.Adam, over several updates on changing minibatches; the
     flat-bucket form (reduce -> [all-reduce] -> pnr_mlp_adam) must equal the fused form bit for bit."""
     import copy
     from pioneer_amd.mlp import HipMLP
-    R, B, lr = 20000, 8192, 1e-3
+    R, lr = 20000, 1e-3           # B: full tiles | a ragged last tile and slice (4099 = 64 * 64 + 3) | a single sample
     model, mlp, obs, _, filt = make(B, seed=21, rows=R, with_filter=True)
     dev = obs.device
     rec = _record(R, dev)
@@ -216,6 +217,18 @@ def test_train_step_equals_autograd_plus_torch_adam():
         m[4].backward()
         opt.step()
         if it == 0:
+            # the gradient itself (Adam's first step only shows its sign): the flat bucket of the fused kernel path against
+            # autograd through the separate forward / loss / backward kernels, parameter by parameter
+            E = flat.numel() // 2
+            for n in range(2):
+                f = flat[n * E:(n + 1) * E]
+                n3 = 12 if n == 0 else 1
+                got = [f[:256 * 144].view(256, 144)[:, :137], f[102400 + 4096:102400 + 4096 + 256],
+                       f[36864:36864 + 65536].view(256, 256), f[102400 + 4096 + 256:102400 + 4096 + 512],
+                       f[102400:102400 + 4096].view(16, 256)[:n3], f[102400 + 4096 + 512:102400 + 4096 + 512 + 16][:n3]]
+                for gk, prm in zip(got, mlp_t.params[6 * n:6 * n + 6]):
+                    assert rel(gk, prm.grad) < 2e-3, (n, tuple(prm.shape), rel(gk, prm.grad))
+                assert float(f[:256 * 144].view(256, 144)[:, 137:].abs().max()) == 0.0      # the padded input columns
             # same weights, same (deterministic) gradient kernels: only the optimiser arithmetic differs.  Adam's first
             # step moves every element by lr * g / (|g| + eps'): compare to a few ulps of the step size
             # (the fused kernel sums the loss per 64-sample tile and net, the separate loss kernel per 256 samples)
@@ -229,7 +242,8 @@ def test_train_step_equals_autograd_plus_torch_adam():
     for a, b, c in zip(mlp.params, mlp_t.params, mlp_f.params):
         assert torch.equal(a, c)                                  # fused == flat-bucket form
         d = (a - b).abs()
-        assert float((d <= 1e-2 * lr).float().mean()) > 0.999 and float(d.max()) <= 12 * lr
+        # (small batches: noisier gradients, more elements near a zero crossing take their early +-lr steps differently)
+        assert float((d <= 1e-2 * lr).float().mean()) > (0.999 if B >= 8192 else 0.85) and float(d.max()) <= 12 * lr
     assert float((mlp.params[2] - model.policy[2].weight).abs().max()) == 0.0     # the module's own tensors were updated
     w_now = mlp.wpack.clone(); b_now = mlp.bias.clone()
     mlp.pack()
