@@ -946,8 +946,17 @@ __global__ __launch_bounds__(256) void mlp_reduce_flat_kernel(const float* __res
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kMlpNets * kGradElems) return;
+    constexpr size_t kStride = (size_t)kMlpNets * kGradElems;
     float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * kMlpNets * kGradElems + i];
+    int k = 0;
+    for (; k + 8 <= slices; k += 8) {                       // slice order, eight loads in flight (see mlp_adam_kernel)
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = slabs[(size_t)(k + j) * kStride + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j];
+    }
+    for (; k < slices; ++k) s += slabs[(size_t)k * kStride + i];
     flat[i] = s;
 }
 
@@ -999,7 +1008,18 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
     if (dst) {
         float g = 0.f;
         const float* gp = P.grad + (size_t)net * kGradElems + e;
-        for (int k = 0; k < P.slices; ++k) g += gp[(size_t)k * kMlpNets * kGradElems];
+        // the slices' partial gradients, summed in slice order (the order mlp_reduce_flat_kernel uses: same bits), eight
+        // loads in flight at a time: as a plain loop with a runtime trip count every load waited for the previous add
+        constexpr size_t kStride = (size_t)kMlpNets * kGradElems;
+        int k = 0;
+        for (; k + 8 <= P.slices; k += 8) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = gp[(size_t)(k + j) * kStride];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g += x[j];
+        }
+        for (; k < P.slices; ++k) g += gp[(size_t)k * kStride];
         g *= P.grad_scale;
         const size_t si = (size_t)net * kGradElems + e;
         const float t = *P.step;
