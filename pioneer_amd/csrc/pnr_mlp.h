@@ -23,6 +23,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The TU is compiled -ffp-contract=off for the bit-exact env integrator; nothing here needs that: the epilogues
+// (bias + tanh, (1 - h^2) dz, the filter, Adam) are a quarter of the fused kernel's issue slots and fuse into FMAs.
+#pragma clang fp contract(fast)
+
 namespace pnr {
 
 constexpr int kMlpIn = 137;       // observation entries (pioneer_knm_env.py:194-211)
@@ -1038,3 +1042,5 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
 }
 
 }  // namespace pnr
+
+#pragma clang fp contract(off)
