@@ -43,6 +43,9 @@ constexpr int kMlpBM = PNR_MLP_BM;   // samples per workgroup tile (forward / ba
 constexpr int kMlpCB = kMlpBM / 32;  // 32-sample column blocks per tile
 static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implemented");
 // PNR_MLP_DIAG: timing-only ablations of the forward kernel (results are wrong when set; tools/mlp_ablation.py)
+#ifndef PNR_MLP_RING
+#define PNR_MLP_RING 5            // depth of the weight-fragment prefetch ring (A/B: tools/mlp_variant_ab.py)
+#endif
 #ifndef PNR_MLP_DIAG
 #define PNR_MLP_DIAG 0
 #endif
@@ -156,7 +159,7 @@ __device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_block
     const int r = lane & 31, h = lane >> 5;
     const __bf16* wa = w_blocks + lane * 8;
     const __bf16* tb = tile + r * STRIDE + 8 * h;
-    constexpr int D = 5;                      // A fragments run D - 1 k-steps ahead of their use (L2 latency ~ 2-3 k-steps of MFMAs)
+    constexpr int D = PNR_MLP_RING;           // A fragments run D - 1 k-steps ahead of their use (L2 latency ~ 2-3 k-steps of MFMAs)
     bf16x8 a[D][2];
 #pragma unroll
     for (int p = 0; p < D - 1; ++p) {

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the MLP kernels' tile height: PNR_MLP_BM = 64 (default: two to three workgroups per CU) against 128 (one
-workgroup per CU, half the weight traffic from L2).  Times the sampling forward and one full training step
-(pnr_mlp_train_step) in child processes on both builds.  Writes gpurun_out/mlp_tile_ab.json."""
+"""A/B of build-time variants of the MLP kernels: by default the tile height PNR_MLP_BM = 64 (two to three workgroups
+per CU) against 128 (one workgroup per CU, half the weight traffic from L2); any other set with
+`--variants name:-DX=1,-DY=2 name2:...` (e.g. the prefetch ring depth PNR_MLP_RING).  Times the sampling forward and one
+full training step (pnr_mlp_train_step) in child processes on every build.  Writes gpurun_out/mlp_variant_ab.json."""
 import json
 import os
 import subprocess
@@ -38,14 +39,21 @@ print(json.dumps(res))
 ''' % ROOT
 
 from pioneer_amd import _lib  # noqa: E402
+variants = {"BM64": ["-DPNR_MLP_BM=64"], "BM128": ["-DPNR_MLP_BM=128"]}
+if "--variants" in sys.argv:
+    variants = {}
+    for spec in sys.argv[sys.argv.index("--variants") + 1:]:
+        name, _, flags = spec.partition(":")
+        variants[name] = [f for f in flags.split(",") if f]
 out = {}
-for bm in (64, 128):
-    lib = os.path.join(_lib.CSRC, f"libpioneer_amd_bm{bm}.so")
+for name, flags in variants.items():
+    lib = os.path.join(_lib.CSRC, f"libpioneer_amd_{name}.so")
     if not os.path.exists(lib):
-        _lib.build_library(extra_flags=[f"-DPNR_MLP_BM={bm}"], out_path=lib)
+        _lib.build_library(extra_flags=flags, out_path=lib)
     res = subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, PNR_LIB_PATH=lib), capture_output=True, text=True, timeout=300)
     line = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    out[f"BM{bm}"] = json.loads(line[-1]) if line else {"error": res.stderr[-300:]}
-    print(bm, out[f"BM{bm}"], flush=True)
+    out[name] = json.loads(line[-1]) if line else {"error": res.stderr[-300:]}
+    out[name]["flags"] = flags
+    print(name, out[name], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "mlp_tile_ab.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "mlp_variant_ab.json"), "w"), indent=1)
