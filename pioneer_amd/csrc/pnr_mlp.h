@@ -195,6 +195,22 @@ __device__ __forceinline__ void mlp_zero_acc(f32x16 (&acc)[2][kMlpCB])
             for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 }
 
+// the accumulators START at the bias (row = output feature, the same for every column / sample): the bias loads then
+// travel together with the first weight fragments of the product, instead of costing the epilogue a round trip of its own
+__device__ __forceinline__ void mlp_bias_acc(f32x16 (&acc)[2][kMlpCB], const float* __restrict__ b, int w, int h)
+{
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(b + 64 * w + 32 * rb + 8 * q + 4 * h);
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[rb][cb][4 * q + j] = bq[j];
+        }
+}
+
 // copy a [128][256] bf16 tile between LDS (row stride kHS) and row-major global rows [row0, row0 + 128) of n_rows
 __device__ __forceinline__ void mlp_store_htile(const __bf16* tile, __bf16* __restrict__ dst, long long row0, long long n_rows, int tid)
 {
@@ -332,37 +348,34 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
 
     const int c = lane & 31, h = lane >> 5;
     f32x16 acc[2][kMlpCB];
-    // bias + tanh in registers, each register quad = four consecutive features of one sample -> one ds_write_b64
-    const auto epilogue = [&](const float* b) {
+    // tanh in registers (the bias is what the accumulators started from), each register quad = four consecutive features
+    // of one sample -> one ds_write_b64
+    const auto epilogue = [&]() {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            f32x4 bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(b + 64 * w + 32 * rb + 8 * q + 4 * h);
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bf16x4 pk;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)((PNR_MLP_DIAG & 1) ? acc[rb][cb][4 * q + j] + bq[q][j] : tanh_fast(acc[rb][cb][4 * q + j] + bq[q][j]));
+                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)((PNR_MLP_DIAG & 1) ? acc[rb][cb][4 * q + j] : tanh_fast(acc[rb][cb][4 * q + j]));
                     *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h) = pk;
                 }
-        }
     };
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
-    mlp_zero_acc(acc);
+    mlp_bias_acc(acc, bias, w, h);
     if (!(PNR_MLP_DIAG & 8)) mlp_gemm_w_xt<kMlpInPad, kXS>(wp + kOffW1 + 2 * w * (kMlpInPad / 16) * 512, xt, acc, lane);
-    if (!(PNR_MLP_DIAG & 32)) epilogue(bias);
+    if (!(PNR_MLP_DIAG & 32)) epilogue();
     __syncthreads();
     if (P.h1) mlp_store_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
 
     // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it
-    mlp_zero_acc(acc);
+    mlp_bias_acc(acc, bias + kMlpHid, w, h);
     if (!(PNR_MLP_DIAG & 4)) mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2 + 2 * w * (kMlpHid / 16) * 512, ht, acc, lane);
     __syncthreads();
-    if (!(PNR_MLP_DIAG & 32)) epilogue(bias + kMlpHid);
+    if (!(PNR_MLP_DIAG & 32)) epilogue();
     __syncthreads();
     if (P.h2) mlp_store_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
 
@@ -371,8 +384,9 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
         const int r16 = lane & 15, g = lane >> 4;
         constexpr int SB = kMlpBM / 64;                               // 16-sample blocks per wave
         f32x4 a3[SB];
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);    // rows 4g .. 4g+3: the accumulators' start
 #pragma unroll
-        for (int sb = 0; sb < SB; ++sb) a3[sb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int sb = 0; sb < SB; ++sb) a3[sb] = b3;
         const __bf16* w3 = wp + kOffW3 + lane * 8;                    // fragment-native: block ks at ks * 512
 #pragma unroll
         for (int ks = 0; ks < kMlpHid / 32; ++ks) {
@@ -383,11 +397,10 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
                 a3[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, a3[sb], 0, 0, 0);
             }
         }
-        const f32x4 b3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb) {
             const long long b = row0 + 16 * SB * w + 16 * sb + r16; // column = sample, rows 4g .. 4g+3 = head entries
-            const f32x4 h = a3[sb] + b3;
+            const f32x4 h = a3[sb];
             if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = h;
             if constexpr (FUSED) {                                    // head rows of the tile, float32 [64][16], in the dead input tile
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(xt) + (16 * SB * w + 16 * sb + r16) * kMlpHead + 4 * g) = h;
