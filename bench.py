@@ -454,14 +454,14 @@ def run_rank(args):
         dynamic["value"] = float(total_envs) / (dynamic["ms_per_step"] * 1e-3)
         # the kernel is VALU-issue-bound, not HBM-bound: instructions from the committed SQ-counter pass, time from this run
         try:
-            cnt = json.load(open(os.path.join(ROOT, "profiles", "r02_c_dyn_sq_counters.json")))["kernels"]["dyn_step_kernel<1,1,1,0>"]
+            cnt = json.load(open(os.path.join(ROOT, "profiles", "r02_e_dyn_sq_counters.json")))["kernels"]["dyn_step_kernel<1,1,1,0>"]
             instr = cnt["valu_roofline"]["valu_wave_instructions_per_dispatch"] * (dcnt / 65536.0)
             simds, clock = 256 * 4, 2.4e9
             ach = instr / (dynamic["avg_launch_ms"] * 1e-3)
             dynamic["roofline"] = {"bound": "valu", "achieved": ach / 1e9, "peak": simds * clock / 2 / 1e9, "unit": "G wave-instructions/s",
                                    "frac": ach / (simds * clock / 2),
                                    "frac_of_single_wave_issue": cnt["valu_roofline"]["frac_of_single_wave_issue"],
-                                   "source": "VALU wave-instructions per 65 536-env launch from profiles/r02_c_dyn_sq_counters.json (rocprofv3 --pmc "
+                                   "source": "VALU wave-instructions per 65 536-env launch from profiles/r02_e_dyn_sq_counters.json (rocprofv3 --pmc "
                                              "SQ_INSTS_VALU, not this run), duration = this run's HIP events; peak = one wave64 VALU instruction "
                                              "per 2 cycles per SIMD at 2.4 GHz; one wave per SIMD can issue one per 4"}
         except Exception:
