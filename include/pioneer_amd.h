@@ -271,6 +271,16 @@ int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, 
                 double lambda, float* logp, float* adv, float* value_target, float* terminals, void* stream);
 
 /*
+ * Host-driver helper: the moment pass of the observation filter ('observation_filter': 'ConcurrentMeanStdFilter',
+ * pioneer_knm_train.py:66) over obs [rows][137]: dsum[c] += sum_r (obs[r][c] - pivot[c]), dsq[c] += sum_r (...)^2 (float64
+ * accumulators [137]; float32 partial sums over 512 rows each, added in order), *dn += rows; one read of the buffer.
+ * scratch: pnr_filter_moments_scratch(rows) floats.
+ */
+int64_t pnr_filter_moments_scratch(int64_t rows);
+int pnr_filter_moments(int64_t rows, const float* obs, const float* pivot, float* scratch, int64_t scratch_floats, double* dsum,
+                       double* dsq, double* dn, void* stream);
+
+/*
  * Host-driver helper: out[0..n) = a pseudo-random permutation of 0..n-1 keyed by (seed, stream_id) — a Feistel network
  * with cycle walking, one launch and no sort; the SGD epochs' minibatch shuffle (RLlib sgd.py shuffles each epoch).
  */

@@ -1261,6 +1261,24 @@ int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, 
     return PNR_OK;
 }
 
+int64_t pnr_filter_moments_scratch(int64_t rows) { return rows < 1 ? 0 : ((rows + kFmRows - 1) / kFmRows) * 2 * kFmCols; }
+
+int pnr_filter_moments(int64_t rows, const float* obs, const float* pivot, float* scratch, int64_t scratch_floats, double* dsum,
+                       double* dsq, double* dn, void* stream)
+{
+    if (rows < 1 || !obs || !pivot || !scratch || !dsum || !dsq || !dn)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_filter_moments: null argument or no rows");
+    const long long blocks = (rows + kFmRows - 1) / kFmRows;
+    if (scratch_floats < blocks * 2 * kFmCols)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_filter_moments: scratch holds %lld floats, the launch needs %lld",
+                    (long long)scratch_floats, blocks * 2 * kFmCols);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(filter_moments_kernel, dim3((unsigned)blocks), dim3(kFmThreads), 0, st, obs, (long long)rows, pivot, scratch);
+    hipLaunchKernelGGL(filter_moments_finish_kernel, dim3(1), dim3(kFmThreads), 0, st, scratch, blocks, (long long)rows, dsum, dsq, dn);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
 int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
 {
     if (n < 1 || !out) return fail(nullptr, PNR_ERR_INVALID, "pnr_permutation: null argument or n < 1");

@@ -300,4 +300,56 @@ __global__ __launch_bounds__(256) void permutation_kernel(long long* __restrict_
     out[i] = (long long)x;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MeanStdFilter's moment pass over a rollout's observations (the 'observation_filter' of pioneer_knm_train.py:66):
+// column sums of d = x - pivot and of d^2 over rows x [rows][137], ONE read of the buffer (287 MB per 524 288 rows)
+// instead of the four passes of the element-wise formulation (subtract, sum, square, sum).  Stage 1: a block walks
+// kFmRows consecutive rows, thread = column (a row is 548 contiguous bytes), float32 partial sums (at most 512 terms
+// each); stage 2: one block adds the partials in block order in float64 into the running accumulators.  A constant
+// column has d == 0 exactly, so both of its sums stay exactly 0 (what the shifted-sum filter is built on).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFmCols = 137;
+constexpr int kFmThreads = 160;
+constexpr int kFmRows = 512;
+
+__global__ __launch_bounds__(kFmThreads) void filter_moments_kernel(const float* __restrict__ x, long long rows,
+                                                                   const float* __restrict__ pivot, float* __restrict__ partials)
+{
+    const int c = threadIdx.x;
+    if (c >= kFmCols) return;
+    const long long r0 = (long long)blockIdx.x * kFmRows;
+    long long r1 = r0 + kFmRows;
+    if (r1 > rows) r1 = rows;
+    const float p = pivot[c];
+    float s = 0.f, q = 0.f;
+    const float* xp = x + r0 * kFmCols + c;
+    long long r = r0;
+    for (; r + 8 <= r1; r += 8) {                          // eight rows in flight
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = xp[(long long)j * kFmCols];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = __fsub_rn(v[j], p); s = __fadd_rn(s, d); q = __fadd_rn(q, __fmul_rn(d, d)); }
+        xp += 8 * kFmCols;
+    }
+    for (; r < r1; ++r) { const float d = __fsub_rn(*xp, p); s = __fadd_rn(s, d); q = __fadd_rn(q, __fmul_rn(d, d)); xp += kFmCols; }
+    partials[((size_t)blockIdx.x * 2 + 0) * kFmCols + c] = s;
+    partials[((size_t)blockIdx.x * 2 + 1) * kFmCols + c] = q;
+}
+
+__global__ __launch_bounds__(kFmThreads) void filter_moments_finish_kernel(const float* __restrict__ partials, long long blocks, long long rows,
+                                                                          double* __restrict__ dsum, double* __restrict__ dsq, double* __restrict__ dn)
+{
+    const int c = threadIdx.x;
+    if (c == 0) *dn += (double)rows;
+    if (c >= kFmCols) return;
+    double s = 0.0, q = 0.0;
+    for (long long b = 0; b < blocks; ++b) {
+        s += (double)partials[((size_t)b * 2 + 0) * kFmCols + c];
+        q += (double)partials[((size_t)b * 2 + 1) * kFmCols + c];
+    }
+    dsum[c] += s;
+    dsq[c] += q;
+}
+
 }  // namespace pnr

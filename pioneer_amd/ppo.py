@@ -98,6 +98,17 @@ class MeanStdFilter:
             self._pivot.copy_(x[0])
         self._pending += 1
         m = x.shape[0]
+        if x.is_cuda and x.shape[-1] == 137 and x.dtype == torch.float32 and x.is_contiguous():
+            # one read of the buffer (pnr_filter_moments): float32 partial sums over 512 rows, float64 across them
+            import ctypes
+            from . import _lib
+            lib = _lib.load_library()
+            need = int(lib.pnr_filter_moments_scratch(m))
+            if getattr(self, "_fm_scratch", None) is None or self._fm_scratch.numel() < need:
+                self._fm_scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+            _lib.check(lib.pnr_filter_moments(m, _dp(x), _dp(self._pivot), _dp(self._fm_scratch), self._fm_scratch.numel(), _dp(self._dsum),
+                                              _dp(self._dsq), _dp(self._dn), ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+            return
         chunk = m
         for c in (16384, 8192, 4096, 2048, 1024):
             if m % c == 0:

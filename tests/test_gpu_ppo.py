@@ -301,3 +301,32 @@ def test_permutation_kernel_is_a_permutation(n):
         # each quarter of the output draws evenly from the input range
         q = p0[: n // 4].double().mean() / n
         assert abs(float(q) - 0.5) < 0.02
+
+
+@pytest.mark.parametrize("rows", [1, 511, 4099, 32 * 2048])
+def test_filter_moment_kernel_equals_the_float64_sums(rows):
+    """MeanStdFilter.observe on the GPU (pnr_filter_moments) against float64 column sums of the same deviations: relative
+    error of a float32 partial sum over <= 512 rows; constant columns (36 of the 137 observation entries) exactly 0; two
+    calls accumulate; sync() then gives the float64 mean and variance."""
+    from pioneer_amd.ppo import MeanStdFilter
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(rows)
+    x = torch.randn(rows, 137, generator=g, device=dev) * 3.0 + torch.linspace(-50, 50, 137, device=dev)
+    x[:, 18:54] = torch.linspace(-3.1415927, 3.1415927, 36, device=dev)          # the constant block
+    y = torch.randn(rows, 137, generator=g, device=dev)
+    y[:, 18:54] = x[0, 18:54]
+    f = MeanStdFilter(137, dev)
+    f.observe(x); f.observe(y)
+    piv = x[0].double()
+    d = torch.cat([x, y]).double() - piv
+    assert float(f._dn) == 2 * rows
+    for got, want in ((f._dsum, d.sum(0)), (f._dsq, (d * d).sum(0))):
+        assert bool((got[18:54] == 0).all())
+        scale = d.abs().sum(0) if got is f._dsum else (d * d).sum(0)
+        assert float(((got - want).abs() / (scale + 1e-30)).max()) < 2e-6
+    f.sync()
+    allx = torch.cat([x, y]).double()
+    assert bool(((f.mean - allx.mean(0)).abs() <= 4e-6 * d.abs().mean(0) + 1e-12).all())    # the sums' bound, divided by n
+    if rows > 1:
+        assert torch.allclose(f.std, allx.std(0, unbiased=True), rtol=2e-5, atol=1e-9)
+        assert bool((f.std[18:54] == 0).all())
