@@ -265,10 +265,23 @@ int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, co
  * [T][n] from reward / values [T][n], last_value [n] (the bootstrap value) and the done / truncated bytes of pnr_step
  * (terminal = done | truncated, as RLlib 0.8's postprocessing treats the TimeLimit cut; truncated may be NULL).
  * terminals [T][n] (1.0 / 0.0) is optional.  gamma / lambda: the reference leaves RLlib's defaults (0.99 / 1.0).
+ * stats (optional): the rollout's bookkeeping in the same launch — the episode statistics behind the reference's result
+ * columns episode_reward_{max,min,mean} / episode_len_mean (cli.py:32-38): ep_ret / ep_len [n] are each env's running return
+ * and length (in / out, carried across rollouts), w_sum / w_len / w_cnt (float64) and w_max / w_min (float32) the window
+ * accumulators of the episodes that ended, updated in place; adv_stats [3] (float64) receives the advantages' sum, sum of
+ * squares and count (PPO standardises them over the global batch).  scratch: pnr_ppo_gae_scratch(n) doubles.
  */
+typedef struct pnr_rollout_stats {
+    float* ep_ret; float* ep_len;
+    double* scratch; int64_t scratch_doubles;
+    double* w_sum; double* w_len; double* w_cnt; float* w_max; float* w_min;
+    double* adv_stats;
+} pnr_rollout_stats;
+int64_t pnr_ppo_gae_scratch(int64_t n);
 int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, const float* last_value, const uint8_t* done,
                 const uint8_t* truncated, const float* actions, const float* mean, const float* log_std, double gamma,
-                double lambda, float* logp, float* adv, float* value_target, float* terminals, void* stream);
+                double lambda, float* logp, float* adv, float* value_target, float* terminals, const pnr_rollout_stats* stats,
+                void* stream);
 
 /*
  * Host-driver helper: the moment pass of the observation filter ('observation_filter': 'ConcurrentMeanStdFilter',

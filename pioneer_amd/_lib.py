@@ -75,6 +75,12 @@ class PnrConstants(C.Structure):
     ]
 
 
+class PnrRolloutStats(C.Structure):
+    _fields_ = [("ep_ret", C.c_void_p), ("ep_len", C.c_void_p), ("scratch", C.c_void_p), ("scratch_doubles", C.c_int64),
+                ("w_sum", C.c_void_p), ("w_len", C.c_void_p), ("w_cnt", C.c_void_p), ("w_max", C.c_void_p), ("w_min", C.c_void_p),
+                ("adv_stats", C.c_void_p)]
+
+
 class PnrMlpStep(C.Structure):
     """pnr_mlp_step of include/pioneer_amd.h (one PPO minibatch update, pnr_mlp_train_step)."""
     _fields_ = [
@@ -120,7 +126,8 @@ SIGNATURES = {
     "pnr_mlp_slab_floats": (C.c_int64, [C.c_int64]),
     "pnr_mlp_pack": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     "pnr_mlp_forward": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_int32, C.c_int32, _VP]),
-    "pnr_ppo_gae": (C.c_int, [C.c_int32, C.c_int64] + [_VP] * 8 + [C.c_double, C.c_double] + [_VP] * 5),
+    "pnr_ppo_gae_scratch": (C.c_int64, [C.c_int64]),
+    "pnr_ppo_gae": (C.c_int, [C.c_int32, C.c_int64] + [_VP] * 8 + [C.c_double, C.c_double] + [_VP] * 6),
     "pnr_filter_moments_scratch": (C.c_int64, [C.c_int64]),
     "pnr_filter_moments": (C.c_int, [C.c_int64, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "pnr_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _VP, _VP]),

@@ -1244,19 +1244,36 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
     return PNR_OK;
 }
 
+int64_t pnr_ppo_gae_scratch(int64_t n) { return n < 1 ? 0 : ((n + 255) / 256) * 8; }
+
 int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, const float* last_value, const uint8_t* done,
                 const uint8_t* truncated, const float* actions, const float* mean, const float* log_std, double gamma,
-                double lambda, float* logp, float* adv, float* value_target, float* terminals, void* stream)
+                double lambda, float* logp, float* adv, float* value_target, float* terminals, const pnr_rollout_stats* stats,
+                void* stream)
 {
     if (T < 1 || n < 1 || !reward || !values || !last_value || !done || !adv || !value_target)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: null argument or empty rollout");
     if (actions && (!mean || !log_std || !logp)) return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: actions need mean, log_std and logp");
+    const long long blocks = (n + 255) / 256;
+    if (stats) {
+        if (!stats->ep_ret || !stats->ep_len || !stats->scratch || !stats->w_sum || !stats->w_len || !stats->w_cnt || !stats->w_max ||
+            !stats->w_min || !stats->adv_stats)
+            return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: null pointer in pnr_rollout_stats");
+        if (stats->scratch_doubles < blocks * 8)
+            return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: scratch holds %lld doubles, the launch needs %lld",
+                        (long long)stats->scratch_doubles, blocks * 8);
+    }
     GaeParams P;
     P.reward = reward; P.values = values; P.last_value = last_value; P.done = done; P.trunc = truncated;
     P.actions = actions; P.mean = mean; P.log_std = log_std; P.logp = logp; P.adv = adv; P.vtarg = value_target;
     P.terminals = terminals; P.N = n; P.T = T;
+    P.ep_ret = stats ? stats->ep_ret : nullptr; P.ep_len = stats ? stats->ep_len : nullptr; P.partials = stats ? stats->scratch : nullptr;
     P.gamma = (float)gamma; P.gamma_lam = (float)(gamma * lambda);      // the host formula's Python-float product, then float32
-    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P);
+    if (stats)
+        hipLaunchKernelGGL(gae_finish_kernel, dim3(1), dim3(64), 0, st, stats->scratch, blocks, (long long)T * n, stats->w_sum, stats->w_len,
+                           stats->w_cnt, stats->w_max, stats->w_min, stats->adv_stats);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }

@@ -214,6 +214,13 @@ struct GaeParams {
     float* adv;                // [T][N]
     float* vtarg;              // [T][N]
     float* terminals;          // [T][N] 1.0 / 0.0, or null
+    // the rollout's bookkeeping sums, optional (partials == null: none): the episode statistics of the reference's result
+    // columns (cli.py:32-38) — per-env running return / length carried across rollouts in ep_ret / ep_len — and the
+    // advantages' sum and sum of squares (PPO standardises them over the batch)
+    float* ep_ret;             // [N] in / out
+    float* ep_len;             // [N] in / out
+    double* partials;          // [gridDim.x][8]: adv sum, adv sum of squares, episodes ended, their return sum, length sum,
+                               //                 max return, min return, 0
     long long N;
     int T;
     float gamma, gamma_lam;
@@ -221,37 +228,100 @@ struct GaeParams {
 
 __global__ __launch_bounds__(256) void gae_logp_kernel(const GaeParams P)
 {
+    __shared__ double red[8][4];
     const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= P.N) return;
-    float nxt_v = P.last_value[n], nxt_a = 0.f;
-    const float gl = P.gamma_lam;
-    for (int t = P.T - 1; t >= 0; --t) {
-        const long long i = (long long)t * P.N + n;
-        const bool term = P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0);
-        const float live = term ? 0.f : 1.f;
-        const float v = P.values[i];
-        // delta = r + gamma * nxt_v * live - v ; adv = delta + gamma * lam * live * nxt_a
-        const float delta = __fsub_rn(__fadd_rn(P.reward[i], __fmul_rn(__fmul_rn(P.gamma, nxt_v), live)), v);
-        nxt_a = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, live), nxt_a));
-        nxt_v = v;
-        P.adv[i] = nxt_a;
-        P.vtarg[i] = __fadd_rn(nxt_a, v);
-        if (P.terminals) P.terminals[i] = term ? 1.f : 0.f;
-        if (P.actions) {
-            const float* a = P.actions + i * 6;
-            const float* m = P.mean + i * 6;
-            const float* l = P.log_std + i * 6;
-            float s = 0.f;
+    const bool in = n < P.N;
+    double a_sum = 0.0, a_sq = 0.0, e_cnt = 0.0, e_ret = 0.0, e_len = 0.0;
+    float e_max = -__builtin_inff(), e_min = __builtin_inff();
+    if (in) {
+        float nxt_v = P.last_value[n], nxt_a = 0.f;
+        const float gl = P.gamma_lam;
+        for (int t = P.T - 1; t >= 0; --t) {
+            const long long i = (long long)t * P.N + n;
+            const bool term = P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0);
+            const float live = term ? 0.f : 1.f;
+            const float v = P.values[i];
+            // delta = r + gamma * nxt_v * live - v ; adv = delta + gamma * lam * live * nxt_a
+            const float delta = __fsub_rn(__fadd_rn(P.reward[i], __fmul_rn(__fmul_rn(P.gamma, nxt_v), live)), v);
+            nxt_a = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, live), nxt_a));
+            nxt_v = v;
+            P.adv[i] = nxt_a;
+            P.vtarg[i] = __fadd_rn(nxt_a, v);
+            a_sum += (double)nxt_a; a_sq += (double)nxt_a * (double)nxt_a;
+            if (P.terminals) P.terminals[i] = term ? 1.f : 0.f;
+            if (P.actions) {
+                const float* a = P.actions + i * 6;
+                const float* m = P.mean + i * 6;
+                const float* l = P.log_std + i * 6;
+                float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float z = __fmul_rn(__fsub_rn(a[j], m[j]), expf(-l[j]));
-                // (-0.5 z) z - log_std - 0.5 log(2 pi), summed over j in order
-                const float term_j = __fsub_rn(__fsub_rn(__fmul_rn(__fmul_rn(-0.5f, z), z), l[j]), 0.91893853320467274178f);
-                s = __fadd_rn(s, term_j);
+                for (int j = 0; j < 6; ++j) {
+                    const float z = __fmul_rn(__fsub_rn(a[j], m[j]), expf(-l[j]));
+                    // (-0.5 z) z - log_std - 0.5 log(2 pi), summed over j in order
+                    const float term_j = __fsub_rn(__fsub_rn(__fmul_rn(__fmul_rn(-0.5f, z), z), l[j]), 0.91893853320467274178f);
+                    s = __fadd_rn(s, term_j);
+                }
+                P.logp[i] = s;
             }
-            P.logp[i] = s;
+        }
+        if (P.partials) {
+            // episode bookkeeping walks forward: EpisodeStats.step()'s arithmetic (return and length accumulate in float32)
+            float ret = P.ep_ret[n], len = P.ep_len[n];
+            for (int t = 0; t < P.T; ++t) {
+                const long long i = (long long)t * P.N + n;
+                ret = __fadd_rn(ret, P.reward[i]);
+                len += 1.0f;
+                if (P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0)) {
+                    e_cnt += 1.0; e_ret += (double)ret; e_len += (double)len;
+                    e_max = fmaxf(e_max, ret); e_min = fminf(e_min, ret);
+                    ret = 0.f; len = 0.f;
+                }
+            }
+            P.ep_ret[n] = ret; P.ep_len[n] = len;
         }
     }
+    if (!P.partials) return;
+    double v[7] = {a_sum, a_sq, e_cnt, e_ret, e_len, (double)e_max, (double)e_min};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_down(v[k], off, 64);
+            v[k] = k == 5 ? fmax(v[k], o) : (k == 6 ? fmin(v[k], o) : v[k] + o);
+        }
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        double x = 0.0;
+        if (k < 7) {
+            x = red[k][0];
+            for (int w = 1; w < 4; ++w) x = k == 5 ? fmax(x, red[k][w]) : (k == 6 ? fmin(x, red[k][w]) : x + red[k][w]);
+        }
+        P.partials[(size_t)blockIdx.x * 8 + k] = x;
+    }
+}
+
+// the partial rows in block order -> the window accumulators of EpisodeStats (in place) and the advantages' moments
+__global__ __launch_bounds__(64) void gae_finish_kernel(const double* __restrict__ partials, long long blocks, long long count,
+                                                       double* __restrict__ w_sum, double* __restrict__ w_len, double* __restrict__ w_cnt,
+                                                       float* __restrict__ w_max, float* __restrict__ w_min, double* __restrict__ adv_stats)
+{
+    const int k = threadIdx.x;
+    if (k >= 7) return;
+    double x = k == 5 ? -__builtin_inf() : (k == 6 ? __builtin_inf() : 0.0);
+    for (long long b = 0; b < blocks; ++b) {
+        const double p = partials[(size_t)b * 8 + k];
+        x = k == 5 ? fmax(x, p) : (k == 6 ? fmin(x, p) : x + p);
+    }
+    if (k == 0) { adv_stats[0] = x; adv_stats[2] = (double)count; }
+    else if (k == 1) adv_stats[1] = x;
+    else if (k == 2) *w_cnt += x;
+    else if (k == 3) *w_sum += x;
+    else if (k == 4) *w_len += x;
+    else if (k == 5) *w_max = fmaxf(*w_max, (float)x);
+    else *w_min = fminf(*w_min, (float)x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -433,9 +433,12 @@ def _dp(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def hip_gae_logp(reward, values, last_value, done, trunc, actions, mean, log_std, gamma, lam, *, logp, adv, vtarg, terminals=None):
+def hip_gae_logp(reward, values, last_value, done, trunc, actions, mean, log_std, gamma, lam, *, logp, adv, vtarg, terminals=None,
+                 stats=None, adv_stats=None):
     """compute_gae + gaussian_logp of a [T, N] rollout in ONE launch (pnr_ppo_gae) on the current stream; outputs are
-    written in place.  Advantages bit-identical to compute_gae (same float32 operations in the same order)."""
+    written in place.  Advantages bit-identical to compute_gae (same float32 operations in the same order).  With
+    ``stats`` (an EpisodeStats) and ``adv_stats`` (float64 [3]) the same launch also does the rollout's bookkeeping: the
+    episode statistics (EpisodeStats.step()'s arithmetic) and the advantages' sum / sum of squares / count."""
     import ctypes
     from . import _lib
     T, N = reward.shape
@@ -443,9 +446,24 @@ def hip_gae_logp(reward, values, last_value, done, trunc, actions, mean, log_std
     assert all(x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda for x in f32)
     assert done.dtype == torch.uint8 and done.is_contiguous() and (trunc is None or (trunc.dtype == torch.uint8 and trunc.is_contiguous()))
     assert values.shape == (T, N) and last_value.shape == (N,) and actions.shape == (T, N, 6) and adv.shape == (T, N)
-    _lib.check(_lib.load_library().pnr_ppo_gae(T, N, _dp(reward), _dp(values), _dp(last_value), _dp(done), _dp(trunc), _dp(actions),
-                                                _dp(mean), _dp(log_std), float(gamma), float(lam), _dp(logp), _dp(adv), _dp(vtarg),
-                                                _dp(terminals), ctypes.c_void_p(torch.cuda.current_stream(reward.device).cuda_stream)))
+    lib = _lib.load_library()
+    st = None
+    if stats is not None:
+        assert adv_stats is not None and adv_stats.dtype == torch.float64 and adv_stats.numel() == 3 and adv_stats.is_cuda
+        need = int(lib.pnr_ppo_gae_scratch(N))
+        if getattr(stats, "_scratch", None) is None or stats._scratch.numel() < need:
+            stats._scratch = torch.empty(need, dtype=torch.float64, device=reward.device)
+        for x, dt, shape in ((stats.ret, torch.float32, (N,)), (stats.len, torch.float32, (N,)), (stats.w_sum, torch.float64, ()),
+                             (stats.w_len, torch.float64, ()), (stats.w_cnt, torch.float64, ()), (stats.w_max, torch.float32, ()),
+                             (stats.w_min, torch.float32, ())):
+            assert x.dtype == dt and tuple(x.shape) == shape and x.is_cuda and x.is_contiguous()
+        st = _lib.PnrRolloutStats(stats.ret.data_ptr(), stats.len.data_ptr(), stats._scratch.data_ptr(), stats._scratch.numel(),
+                                  stats.w_sum.data_ptr(), stats.w_len.data_ptr(), stats.w_cnt.data_ptr(), stats.w_max.data_ptr(),
+                                  stats.w_min.data_ptr(), adv_stats.data_ptr())
+    _lib.check(lib.pnr_ppo_gae(T, N, _dp(reward), _dp(values), _dp(last_value), _dp(done), _dp(trunc), _dp(actions), _dp(mean), _dp(log_std),
+                               float(gamma), float(lam), _dp(logp), _dp(adv), _dp(vtarg), _dp(terminals),
+                               ctypes.byref(st) if st is not None else None,
+                               ctypes.c_void_p(torch.cuda.current_stream(reward.device).cuda_stream)))
 
 
 def hip_permutation(n: int, seed: int, stream_id: int, out: torch.Tensor) -> torch.Tensor:
@@ -627,7 +645,10 @@ class PPOLearner:
         mbs = min(cfg.sgd_minibatch_size, B)
         adv = batch["adv"]
         # standardise advantages over the GLOBAL batch
-        stats = torch.stack([adv.sum().double(), (adv.double() ** 2).sum(), torch.tensor(float(B), dtype=torch.float64, device=adv.device)])
+        if batch.get("adv_stats") is not None:          # this rank's moments, made by the rollout's pnr_ppo_gae launch
+            stats = batch["adv_stats"].clone()
+        else:
+            stats = torch.stack([adv.sum().double(), (adv.double() ** 2).sum(), torch.tensor(float(B), dtype=torch.float64, device=adv.device)])
         pdist.allreduce_sum_(stats)
         mu = stats[0] / stats[2]
         sd = torch.sqrt(torch.clamp(stats[1] / stats[2] - mu * mu, min=1e-12))
@@ -637,7 +658,7 @@ class PPOLearner:
         agg: Dict[str, torch.Tensor] = {}
         nmb = 0
         filt = batch.get("filt")
-        tens = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor)}
+        tens = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and k != "adv_stats"}
         tens["adv"] = adv_n
         if self.hip and adv.is_cuda:
             out = self._update_hip(tens, filt, B, mbs, generator)
@@ -850,6 +871,7 @@ class PPOTrainer:
             self.sample_mlp = HipMLP(self.learner.model, N, self.device)   # packed weights for the rollout's T forwards
             self._last_heads = torch.empty((2, N, 16), **f32)
             self._last_v = torch.empty((N,), **f32)
+            self._adv_stats = torch.zeros(3, dtype=torch.float64, device=self.device)     # sum, sum of squares, count (pnr_ppo_gae)
         else:
             self.buf["obs"] = torch.empty((T, N, D), **f32)            # filtered, what the nets saw
 
@@ -872,7 +894,7 @@ class PPOTrainer:
         if self.hip:
             hip_gae_logp(buf["reward"], buf["values"], last_v.contiguous(), buf["done"], buf["trunc"], buf["actions"], buf["mean"],
                          buf["log_std"], cfg.gamma, cfg.lambda_, logp=buf["logp"], adv=buf["adv"], vtarg=buf["vtarg"],
-                         terminals=buf["terminals"])
+                         terminals=buf["terminals"], stats=self.stats, adv_stats=self._adv_stats)
             return
         buf["logp"].copy_(gaussian_logp(buf["actions"], buf["mean"], buf["log_std"]))
         torch.bitwise_or(buf["done"], buf["trunc"], out=buf["term_u8"])
@@ -941,7 +963,8 @@ class PPOTrainer:
         library was involved.  The filter only changes at sync(), so observing all inputs here, in one pass, is
         identical to observing them one by one inside the loop."""
         buf, T = self.buf, self.cfg.rollout_fragment_length
-        self.stats.rollout(buf["reward"], buf["terminals"])
+        if not self.hip:                                  # the HIP path's pnr_ppo_gae launch has done the episode statistics
+            self.stats.rollout(buf["reward"], buf["terminals"])
         self.filter.observe(self.raw_in[:T])
 
     _capturing = False
@@ -968,6 +991,7 @@ class PPOTrainer:
                  "logp": flat(buf["logp"]), "values": flat(buf["values"]), "adv": flat(buf["adv"]), "vtarg": flat(buf["vtarg"])}
         if self.hip:
             batch.update(obs=flat(self.raw_in[:T]), filt=self._filt())      # raw: the kernels filter on load
+            batch["adv_stats"] = self._adv_stats
         else:
             batch["obs"] = flat(buf["obs"])
         return batch

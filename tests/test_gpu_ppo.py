@@ -280,6 +280,45 @@ def test_gae_logp_kernel_equals_the_host_formulas():
         assert float(((out["logp"] - lp).abs() / (lp.abs() + 1)).max()) < 5e-6
 
 
+def test_gae_kernel_bookkeeping_equals_episode_stats_and_advantage_moments():
+    """The optional bookkeeping of pnr_ppo_gae over three consecutive rollouts (carry-over of running returns included,
+    one rollout without any terminal, terminals on the first and last step) against EpisodeStats.step() on the same
+    data, and the advantages' moments against float64 sums."""
+    from pioneer_amd.ppo import EpisodeStats, compute_gae, hip_gae_logp
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(8)
+    T, N = 32, 4099
+    a, b = EpisodeStats(N, dev), EpisodeStats(N, dev)
+    adv_stats = torch.zeros(3, dtype=torch.float64, device=dev)
+    for it in range(3):
+        r = torch.randn(T, N, generator=g, device=dev)
+        v = torch.randn(T, N, generator=g, device=dev)
+        last = torch.randn(N, generator=g, device=dev)
+        p = 0.0 if it == 1 else 0.06
+        done = (torch.rand(T, N, generator=g, device=dev) < p).to(torch.uint8)
+        trunc = ((torch.rand(T, N, generator=g, device=dev) < p) & (done == 0)).to(torch.uint8)
+        if it == 2:
+            done[0] = 1; trunc[0] = 0; done[-1] = 0; trunc[-1] = 1
+        act = torch.randn(T, N, 6, generator=g, device=dev); z = torch.zeros(T, N, 6, device=dev)
+        out = {k: torch.empty(T, N, device=dev) for k in ("logp", "adv", "vtarg")}
+        hip_gae_logp(r, v, last, done, trunc, act, z, z, 0.99, 0.95, stats=b, adv_stats=adv_stats, **out)
+        term = (done | trunc).float()
+        for t in range(T):
+            a.step(r[t], term[t])
+        assert torch.equal(a.ret, b.ret) and torch.equal(a.len, b.len)            # same float32 accumulation per env
+        assert float(a.w_cnt) == float(b.w_cnt) and float(a.w_len) == float(b.w_len)
+        # (step() sums the ended episodes' float32 returns in float32 per step, the kernel in float64)
+        assert abs(float(a.w_sum) - float(b.w_sum)) <= 1e-6 * float(a.w_cnt) + 1e-9
+        if float(a.w_cnt) > 0:
+            assert float(a.w_max) == float(b.w_max) and float(a.w_min) == float(b.w_min)
+        adv = compute_gae(r, v, last, term, 0.99, 0.95)[0]
+        assert torch.equal(out["adv"], adv)
+        want = torch.stack([adv.double().sum(), (adv.double() ** 2).sum(), torch.tensor(float(T * N), dtype=torch.float64, device=dev)])
+        assert torch.allclose(adv_stats, want, rtol=1e-12, atol=1e-9)
+        ra, rb = a.summarize(), b.summarize()
+        assert all((ra[k] == rb[k]) or (ra[k] != ra[k] and rb[k] != rb[k]) or abs(ra[k] - rb[k]) <= 1e-6 for k in ra)
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 4099, 32768, 524288, 1000003])
 def test_permutation_kernel_is_a_permutation(n):
     from pioneer_amd.ppo import hip_permutation
