@@ -308,6 +308,31 @@ def test_dynamic_rollout_with_randomised_resets_equals_steps(n):
     e1.close(); e2.close()
 
 
+def test_dynamic_rollout_with_contacts_equals_steps():
+    """The contact instantiations of the two kernels (dyn_step_kernel / dyn_rollout_kernel <.., CONTACT = true>): the
+    legacy plane, all 23 link samples and the three scene bodies, randomised, with resets inside the rollout.  One-sided
+    springs switch on at depth 0, so an env within float32 noise of a surface may take the other branch for a sub-step in
+    one of the two separately compiled kernels: all but 1 % of the envs to rounding, the rest bounded."""
+    n, T = 2048, 9
+    kw = dict(seed=12, gravity=9.81, auto_reset=True, max_steps=5, randomize=1, ground_z=0.5, link_contacts=1, scene=SCENE)
+    e1, _ = make(n, **kw)
+    e2, _ = make(n, **kw)
+    assert torch.equal(e1.reset(), e2.reset())
+    g = torch.Generator(device="cpu").manual_seed(3)
+    acts = ((torch.rand(T, n, 6, generator=g) * 2 - 1) * 0.3 * torch.from_numpy(e1.a_max)).cuda()
+    obs_r, rew_r, done_r, trunc_r = e1.rollout(acts)
+    assert bool(torch.isfinite(obs_r).all()) and int(trunc_r.sum()) >= n
+    for t in range(T):
+        o, r, d, tr = e2.vector_step(acts[t])
+        err = (o - obs_r[t]).abs().amax(1)
+        assert float((err <= ROLL_OBS_TOL).float().mean()) >= 0.99 and float(err.max()) < 1.0, (t, float(err.max()))
+        assert torch.equal(tr, trunc_r[t])
+    s1, s2 = e1.get_state(), e2.get_state()
+    assert torch.equal(s1[:21], s2[:21]) and torch.equal(s1[22:], s2[22:])       # command state, counters, targets
+    assert torch.equal(e1.get_dyn_state()[12:35], e2.get_dyn_state()[12:35])     # the per-env draws
+    e1.close(); e2.close()
+
+
 def test_full_size_65536_rollout_properties():
     """BASELINE config[4] size through the in-launch rollout kernel: finite outputs, joints inside their limits, every
     env truncated exactly when its TimeLimit says so, counters consistent after the launch."""
