@@ -1244,7 +1244,7 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
     return PNR_OK;
 }
 
-int64_t pnr_ppo_gae_scratch(int64_t n) { return n < 1 ? 0 : ((n + 255) / 256) * 8; }
+int64_t pnr_ppo_gae_scratch(int64_t n) { return n < 1 ? 0 : ((n + 63) / 64) * 8; }
 
 int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, const float* last_value, const uint8_t* done,
                 const uint8_t* truncated, const float* actions, const float* mean, const float* log_std, double gamma,
@@ -1254,7 +1254,7 @@ int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, 
     if (T < 1 || n < 1 || !reward || !values || !last_value || !done || !adv || !value_target)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: null argument or empty rollout");
     if (actions && (!mean || !log_std || !logp)) return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: actions need mean, log_std and logp");
-    const long long blocks = (n + 255) / 256;
+    const long long blocks = (n + 63) / 64;
     if (stats) {
         if (!stats->ep_ret || !stats->ep_len || !stats->scratch || !stats->w_sum || !stats->w_len || !stats->w_cnt || !stats->w_max ||
             !stats->w_min || !stats->adv_stats)
@@ -1270,7 +1270,7 @@ int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, 
     P.ep_ret = stats ? stats->ep_ret : nullptr; P.ep_len = stats ? stats->ep_len : nullptr; P.partials = stats ? stats->scratch : nullptr;
     P.gamma = (float)gamma; P.gamma_lam = (float)(gamma * lambda);      // the host formula's Python-float product, then float32
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)blocks), dim3(64), 0, st, P);
     if (stats)
         hipLaunchKernelGGL(gae_finish_kernel, dim3(1), dim3(64), 0, st, stats->scratch, blocks, (long long)T * n, stats->w_sum, stats->w_len,
                            stats->w_cnt, stats->w_max, stats->w_min, stats->adv_stats);
@@ -1291,7 +1291,7 @@ int pnr_filter_moments(int64_t rows, const float* obs, const float* pivot, float
                     (long long)scratch_floats, blocks * 2 * kFmCols);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(filter_moments_kernel, dim3((unsigned)blocks), dim3(kFmThreads), 0, st, obs, (long long)rows, pivot, scratch);
-    hipLaunchKernelGGL(filter_moments_finish_kernel, dim3(1), dim3(kFmThreads), 0, st, scratch, blocks, (long long)rows, dsum, dsq, dn);
+    hipLaunchKernelGGL(filter_moments_finish_kernel, dim3(kFmCols, 2), dim3(256), 0, st, scratch, blocks, (long long)rows, dsum, dsq, dn);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }
