@@ -13,6 +13,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
+from . import seeding
 from .config import EngineConfig, PioneerKinematicConfig, RenderConfig, SimulationConfig
 from .spaces import Box
 from .vector_env import PioneerVectorEnv
@@ -49,7 +50,8 @@ class PioneerKinematicEnv:
 
         # the env itself never truncates or auto-resets: TimeLimit / the sampler do
         engine = EngineConfig(max_episode_steps=0, auto_reset=False, mode=mode)
-        self._seed_value = self._fresh_seed()
+        self.np_random = None                                              # :45
+        self.seed()                                                        # :46
         self._vec = PioneerVectorEnv(1, device=device, seed=self._seed_value,
                                      pioneer_config=self.config,
                                      simulation_config=self.simulation_config, engine_config=engine)
@@ -69,14 +71,15 @@ class PioneerKinematicEnv:
         return (_rebuild_env, (self._ctor,))
 
     # -- randomness ------------------------------------------------------------------
-    @staticmethod
-    def _fresh_seed() -> int:
-        return int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).view(np.uint64)[0] >> np.uint64(1))
-
     def seed(self, seed=None) -> List[int]:                                # :107-109
-        self._seed_value = self._fresh_seed() if seed is None else int(seed)
-        self._vec.seed(self._seed_value)
-        return [self._seed_value]
+        """The reference's seeding: gym.utils.seeding.np_random (pioneer_amd/seeding.py restates it), a NumPy RandomState
+        whose draws reset_world() takes exactly as the reference does — so ``env.seed(s); env.reset()`` starts from the
+        reference's joint angles and target.  (The batched engine's own per-env Philox streams are for PioneerVectorEnv.)"""
+        self.np_random, seed = seeding.np_random(seed)
+        self._seed_value = int(seed)
+        if getattr(self, "_vec", None) is not None:
+            self._vec.seed(self._seed_value)
+        return [seed]
 
     # -- state mirrors -------------------------------------------------------------------
     def _state(self):
@@ -103,6 +106,12 @@ class PioneerKinematicEnv:
     def reset_world(self, joint_positions: Optional[np.ndarray] = None,
                     target_position: Optional[Tuple[float, float, float]] = None) -> Observation:
         """pioneer_knm_env.py:76-105; returns the observation of the new state."""
+        if joint_positions is None:
+            joint_positions = self.np_random.uniform(self.r_lo, self.r_hi)  # :80-81 (float64 draws between the float32 limits)
+        if target_position is None:
+            assert len(self.config.target_lo) == 3                         # :84
+            assert len(self.config.target_hi) == 3                         # :85
+            target_position = tuple(self.np_random.uniform(np.array(self.config.target_lo), np.array(self.config.target_hi)))  # :87-90
         jp = tp = None
         if joint_positions is not None:
             positions_list = list(joint_positions)
