@@ -839,6 +839,7 @@ class PPOTrainer:
         self.filter = (MeanStdFilter(self.cfg.obs_dim, self.device, self.cfg.filter_clip)
                        if self.cfg.observation_filter in ("MeanStdFilter", "ConcurrentMeanStdFilter") else NoFilter())
         self.stats = EpisodeStats(env.num_envs, self.device)
+        self._ev = None             # timing events of train()
         self.gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed * 1000003 + self.rank)
         self.a_max = torch.from_numpy(env.a_max).to(self.device)
         self._a_lo = -self.a_max
@@ -997,18 +998,30 @@ class PPOTrainer:
         return batch
 
     def train(self) -> Dict[str, float]:
+        """One iteration: collect, merge the filter, update.  On the GPU the phase split (sample_time_s / learn_time_s, RLlib's
+        sample_time_ms / learn_time_ms) comes from an event recorded between the phases, not from a host synchronisation there:
+        the learner's first kernels are queued while the sampler's last ones still run."""
+        cuda = self.device.type == "cuda"
         t0 = time.perf_counter()
+        if cuda:
+            if self._ev is None:
+                self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            self._ev[0].record()
         batch = self.collect()
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
+        if cuda:
+            self._ev[1].record()
         t1 = time.perf_counter()
         self.filter.sync()
         steps = batch["obs"].shape[0] * self.world
         self.learner.timesteps_total += steps
         info = self.learner.update(batch, self.gen)
-        if self.device.type == "cuda":
+        if cuda:
+            self._ev[2].record()
             torch.cuda.synchronize(self.device)
         t2 = time.perf_counter()
+        if cuda:
+            gpu_sample = self._ev[0].elapsed_time(self._ev[1]) * 1e-3
+            t1 = t0 + min(max(gpu_sample, t1 - t0), t2 - t0)       # the sampler's share of the wall time of this iteration
         self.iteration += 1
         res = self.stats.summarize()
         res.update(info)
