@@ -537,11 +537,19 @@ class EpisodeStats:
         self.ret.copy_(tail + torch.where(open_, self.ret, torch.zeros_like(self.ret)))
         self.len.copy_(float(T) - end + torch.where(open_, self.len, torch.zeros_like(self.len)))
 
-    def summarize(self) -> Dict[str, float]:
+    def window_tensor(self) -> torch.Tensor:
+        """The window's (return sum, length sum, episode count, max, min) over all ranks as ONE float64 device tensor: read
+        it back with whatever else the iteration reports (one host synchronisation), then call finish_window()."""
         packed = torch.stack([self.w_sum, self.w_len, self.w_cnt])
         pdist.allreduce_sum_(packed)
         mx = pdist.allreduce_max_(self.w_max.clone()); mn = pdist.allreduce_min_(self.w_min.clone())
-        s, l, c = (float(x) for x in packed)
+        return torch.cat([packed, mx.double().reshape(1), mn.double().reshape(1)])
+
+    def summarize(self) -> Dict[str, float]:
+        return self.finish_window(self.window_tensor().tolist())
+
+    def finish_window(self, vals) -> Dict[str, float]:
+        s, l, c, mx, mn = vals
         self.total += int(c)
         out = {"episode_reward_mean": s / c if c else float("nan"),
                "episode_len_mean": l / c if c else float("nan"),
@@ -637,7 +645,7 @@ class PPOLearner:
         return total, {"policy_loss": -surr.mean().detach(), "vf_loss": vf.mean().detach(),
                        "kl": kl.mean().detach(), "entropy": ent.mean().detach(), "total_loss": total.detach()}
 
-    def update(self, batch: Dict[str, torch.Tensor], generator: Optional[torch.Generator] = None) -> Dict[str, float]:
+    def update(self, batch: Dict[str, torch.Tensor], generator: Optional[torch.Generator] = None, readback: bool = True):
         """batch tensors are flat [B, ...] (this rank's share).  Every rank must run the same number
         of minibatches (equal shard sizes)."""
         cfg = self.cfg
@@ -661,8 +669,10 @@ class PPOLearner:
         tens = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and k != "adv_stats"}
         tens["adv"] = adv_n
         if self.hip and adv.is_cuda:
-            out = self._update_hip(tens, filt, B, mbs, generator)
-            return self._finish_update(out, adv.device)
+            m = self._update_hip(tens, filt, B, mbs, generator)
+            if not readback:
+                return m                                            # PPOTrainer reads it back together with the episode statistics
+            return self.finish_update_values(m.tolist())
 
         def eager_step(mb):
             loss, info = self.loss(mb)
@@ -697,6 +707,18 @@ class PPOLearner:
                 nmb += 1
         out = {k: float(v) / max(1, nmb) for k, v in agg.items()}
         return self._finish_update(out, adv.device)
+
+    def finish_update_values(self, m) -> Dict[str, float]:
+        """The HIP path's loss means (already averaged over the ranks) as the result columns + the adaptive-KL step."""
+        out = {"policy_loss": m[0], "vf_loss": m[1], "kl": m[2], "entropy": m[3], "total_loss": m[4]}
+        cfg = self.cfg
+        if out["kl"] > 2.0 * cfg.kl_target:
+            self.kl_coeff *= 1.5
+        elif out["kl"] < 0.5 * cfg.kl_target:
+            self.kl_coeff *= 0.5
+        out["cur_kl_coeff"] = self.kl_coeff
+        out["entropy_coeff"] = self.entropy_coeff()
+        return out
 
     def _finish_update(self, out: Dict[str, float], device) -> Dict[str, float]:
         cfg = self.cfg
@@ -778,8 +800,11 @@ class PPOLearner:
                     pdist.allreduce_sum_(self._flat_grad)          # the one 0.86 MB bucket
                     mlp.adam(self._flat_grad, 1.0 / world, cfg.lr)
                 k += 1
-        m = self._means.mean(0).tolist()
-        return {"policy_loss": m[0], "vf_loss": m[1], "kl": m[2], "entropy": m[3], "total_loss": m[4]}
+        m = self._means.mean(0).double()
+        if multi:                                                   # the reported losses are averages over the ranks
+            pdist.allreduce_sum_(m)
+            m = m / world
+        return m                                                    # device tensor [8]: read back by the caller
 
 
 def _learner_capture(self, batch, idx):
@@ -1014,7 +1039,13 @@ class PPOTrainer:
         self.filter.sync()
         steps = batch["obs"].shape[0] * self.world
         self.learner.timesteps_total += steps
-        info = self.learner.update(batch, self.gen)
+        info = self.learner.update(batch, self.gen, readback=not self.hip)
+        win = self.stats.window_tensor()
+        if self.hip:                       # ONE device -> host read per iteration: loss means + episode statistics
+            vals = torch.cat([info, win]).tolist()
+            info, win = self.learner.finish_update_values(vals[:8]), vals[8:]
+        else:
+            win = win.tolist()
         if cuda:
             self._ev[2].record()
             torch.cuda.synchronize(self.device)
@@ -1023,7 +1054,7 @@ class PPOTrainer:
             gpu_sample = self._ev[0].elapsed_time(self._ev[1]) * 1e-3
             t1 = t0 + min(max(gpu_sample, t1 - t0), t2 - t0)       # the sampler's share of the wall time of this iteration
         self.iteration += 1
-        res = self.stats.summarize()
+        res = self.stats.finish_window(win)
         res.update(info)
         res.update({"training_iteration": self.iteration, "timesteps_total": self.learner.timesteps_total,
                     "timesteps_this_iter": steps, "sample_time_s": t1 - t0, "learn_time_s": t2 - t1,
