@@ -169,6 +169,9 @@ __global__ __launch_bounds__(64) void ppo_loss_finish_kernel(const float* __rest
 // The same for the fused forward + loss + backward kernel, whose partial rows come from the policy workgroups
 // (-surrogate, KL, entropy) and the value workgroups (value loss) separately: total = the same combination of the
 // four means that the per-sample form sums (linear, so equal up to float32 summation order).
+// Tried and dropped (r02): no separate launch — the workgroup that draws the last ticket (a device-scope fence + atomicAdd
+// after its partial row) sums the rows at the end of the fused kernel.  Correct, but every workgroup's fence writes its
+// XCD's L2 back (the tile's 160 KB of activation stores are in flight): learn phase 7.7 -> 12.4 ms per iteration.
 __global__ __launch_bounds__(512) void ppo_loss_finish_split_kernel(const float* __restrict__ partials, long long rows, long long B,
                                                                     float* __restrict__ means, float* __restrict__ step_counter,
                                                                     const float* __restrict__ kl_coeff, const float* __restrict__ ent_coeff,
