@@ -495,7 +495,7 @@ def run_rank(args):
         barrier()
         tp = max_over_ranks(time.perf_counter() - tp)
         graphed = {"sampling": tr._graph is not None,
-                   "learner": ("hip kernels: pnr_mlp_train_step, 4 launches per update, no graph needed" if tr.learner.hip
+                   "learner": ("hip kernels: pnr_mlp_train_step, 3 launches per update, no graph needed" if tr.learner.hip
                                else ("graph" if tr.learner._graph is not None else "eager")),
                    "learner_split_around_allreduce": bool(tr.learner._split) or (tr.learner.hip and world > 1)}
         finite = all(math.isfinite(float(r[k])) for r in rs for k in ("kl", "total_loss"))

@@ -337,10 +337,11 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
                      int32_t n3_value, int32_t accumulate, const float* scale, void* stream);
 
 /*
- * One PPO minibatch update of both nets in four launches, nothing of it on the host: (1) per 64-sample tile and net the
+ * One PPO minibatch update of both nets in three launches, nothing of it on the host: (1) per 64-sample tile and net the
  * forward pass (activations saved for the weight gradients), the tile's share of the loss and its backward-data pass in
- * ONE kernel; (2) the loss means (which also counts the update in *adam_step); (3) weight gradients per batch slice;
- * (4) EITHER the fused slab-reduction + Adam + bf16 repacking (flat_grad == NULL) OR the reduction into flat_grad
+ * ONE kernel (which also counts the update in *adam_step); (2) weight gradients per batch slice; (3) EITHER the fused
+ * slab-reduction + Adam + bf16 repacking, one extra block of which sums the loss means (flat_grad == NULL), OR the
+ * loss means in a small launch of their own and the reduction into flat_grad
  * [pnr_mlp_grad_floats()] with no update: a multi-GPU run all-reduces that bucket and calls pnr_mlp_adam(s, flat_grad,
  * 1 / world_size, stream).  The update is Adam with the arithmetic of the optimiser the reference trains with ('lr' of its
  * config, pioneer_knm_train.py:64; betas 0.9 / 0.999, eps 1e-8; no weight decay) with its state m, v kept as

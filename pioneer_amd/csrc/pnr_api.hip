@@ -1381,9 +1381,12 @@ static int mlp_step_check(const pnr_mlp_step* s, const char* who)
     return PNR_OK;
 }
 
-static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices, float scale, hipStream_t st)
+// loss_rows > 0: the launch also sums the update's loss means (rows of the fused kernel in s->partials)
+static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices, float scale, hipStream_t st, long long loss_rows = 0)
 {
     MlpAdamParams A;
+    A.partials = loss_rows > 0 ? s->partials : nullptr; A.loss_rows = loss_rows; A.batch = s->batch; A.means = s->means;
+    A.kl_coeff = s->kl_coeff; A.ent_coeff = s->entropy_coeff; A.vf_coeff = s->vf_loss_coeff;
     A.grad = grad; A.slices = slices; A.grad_scale = scale;
     for (int n = 0; n < kMlpNets; ++n) {
         A.w1[n] = s->params[6 * n + 0]; A.b1[n] = s->params[6 * n + 1]; A.w2[n] = s->params[6 * n + 2];
@@ -1393,7 +1396,7 @@ static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices
     A.m = s->adam_m; A.v = s->adam_v; A.step = s->adam_step;
     A.lr = s->lr; A.beta1 = s->beta1; A.beta2 = s->beta2; A.eps = s->eps;
     A.wpack = static_cast<__bf16*>(s->wpack); A.bias = s->bias;
-    hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256, kMlpNets), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, kMlpNets), dim3(256), 0, st, A);
 }
 
 int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
@@ -1429,11 +1432,12 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     F.rec_adv = s->adv; F.rec_vtarg = s->value_target; F.rec_values = s->value_old;
     F.kl_coeff = s->kl_coeff; F.ent_coeff = s->entropy_coeff;
     F.clip = s->clip_param; F.vf_clip = s->vf_clip_param; F.vf_coeff = s->vf_loss_coeff;
-    F.g_head = s->g_head; F.partials = s->partials;
+    F.g_head = s->g_head; F.partials = s->partials; F.adam_step = s->adam_step;
     F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
     hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, thr, 0, st, F);
-    hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(512), 0, st, s->partials, prow, B, s->means, s->adam_step,
-                       s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
+    if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
+        hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
+                           s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
     MlpWgradParams Wp;
     Wp.g_head = s->g_head; Wp.xs = F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
     Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows;
@@ -1441,7 +1445,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     if (s->flat_grad)
         hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((kMlpNets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad);
     else
-        mlp_launch_adam(s, s->slabs, (int)slices, 1.0f, st);
+        mlp_launch_adam(s, s->slabs, (int)slices, 1.0f, st, prow);      // + the loss means, in the same launch
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }

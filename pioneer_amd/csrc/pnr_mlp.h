@@ -266,6 +266,7 @@ struct MlpFwdParams {
     float clip, vf_clip, vf_coeff;
     float* g_head;             // [2][B][16] d loss / d head (float32; the weight-gradient kernel reads it)
     float* partials;           // [tiles * nets][8] per-workgroup sums: policy rows (-surr, 0, kl, entropy), value rows (0, vf)
+    float* adam_step;          // the optimiser's update count (device scalar), incremented once per launch; or null
     __bf16* dz1;               // [2][B][256]
     __bf16* dz2;
 };
@@ -286,6 +287,9 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     const long long row0 = (long long)blockIdx.x * kMlpBM;
     const __bf16* wp = P.wpack + (size_t)net * kPackElems;
     const float* bias = P.bias + net * kBiasElems;
+    if constexpr (FUSED) {       // this launch is one optimiser update: counted here, read by the Adam kernel two launches on
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
+    }
 
     // ---- stage 0: the tile's observations, filtered, as bf16 pairs [128][144] (columns 137.. zero)
     {
@@ -1001,12 +1005,26 @@ struct MlpAdamParams {
     float lr, beta1, beta2, eps;
     __bf16* wpack;             // [2][kPackElems]: refreshed in place
     float* bias;               // [2][kBiasElems]
+    // the loss means of the update ride in this launch (one extra block; null partials: none)
+    const float* partials;     // [loss_rows][8] of the fused forward + loss + backward kernel
+    long long loss_rows, batch;
+    float* means;              // [8]
+    const float* kl_coeff; const float* ent_coeff; float vf_coeff;
 };
 
 __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
 {
     const int net = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) {
+        // the extra block (the FIRST one, so that it starts with the launch and not as its tail): the five loss means from the fused kernel's per-workgroup rows (ppo_loss_finish_split_kernel's
+        // job), in the shadow of the other 838 blocks
+        // instead of a 5.6 us launch of its own
+        __shared__ float red[4][kPpoSums];
+        if (net != 0 || !P.partials) return;
+        ppo_loss_means_block(P.partials, P.loss_rows, P.batch, P.means, P.kl_coeff, P.ent_coeff, P.vf_coeff, red);
+        return;
+    }
+    const int e = (blockIdx.x - 1) * 256 + threadIdx.x;
     if (e >= kGradElems) return;
     float* dst = nullptr;
     int wp0 = -1, wp1 = -1, bp = -1;               // where the bf16 / bias copies of this element go

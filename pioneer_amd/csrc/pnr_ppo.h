@@ -172,28 +172,46 @@ __global__ __launch_bounds__(64) void ppo_loss_finish_kernel(const float* __rest
 // Tried and dropped (r02): no separate launch — the workgroup that draws the last ticket (a device-scope fence + atomicAdd
 // after its partial row) sums the rows at the end of the fused kernel.  Correct, but every workgroup's fence writes its
 // XCD's L2 back (the tile's 160 KB of activation stores are in flight): learn phase 7.7 -> 12.4 ms per iteration.
-__global__ __launch_bounds__(512) void ppo_loss_finish_split_kernel(const float* __restrict__ partials, long long rows, long long B,
+// One 256-thread block: thread t = (slot k = t & 7, walker t >> 3 of 32) adds rows walker, walker + 32, ... (eight loads
+// in flight), the walkers of a wave are combined by a fixed shuffle tree and the four waves' sums in order: deterministic,
+// ~1 us.  Used by the finishing launch below AND by the extra block of mlp_adam_kernel: same bits either way.
+__device__ __forceinline__ void ppo_loss_means_block(const float* __restrict__ partials, long long rows, long long B, float* __restrict__ means,
+                                                     const float* __restrict__ kl_coeff, const float* __restrict__ ent_coeff, float vf_coeff,
+                                                     float (&red)[4][kPpoSums])
+{
+    const int t = threadIdx.x, k = t & 7, part = t >> 3;
+    float s = 0.f;
+    long long r = part;
+    for (; r + 7 * 32 < rows; r += 8 * 32) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = partials[(r + 32 * j) * kPpoSums + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j];
+    }
+    for (; r < rows; r += 32) s += partials[r * kPpoSums + k];
+    s += __shfl_down(s, 32, 64);
+    s += __shfl_down(s, 16, 64);
+    s += __shfl_down(s, 8, 64);
+    if ((t & 63) < kPpoSums) red[t >> 6][k] = s;
+    __syncthreads();
+    if (t < 64) {
+        float v = 0.f;
+        if (t < kPpoSums) v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+        const float mean = v / (float)B;
+        const float m0 = __shfl(mean, 0, 64), m1 = __shfl(mean, 1, 64), m2 = __shfl(mean, 2, 64), m3 = __shfl(mean, 3, 64);
+        if (t < kPpoSums) means[t] = t == 4 ? m0 + *kl_coeff * m2 + vf_coeff * m1 - *ent_coeff * m3 : mean;
+    }
+}
+
+__global__ __launch_bounds__(256) void ppo_loss_finish_split_kernel(const float* __restrict__ partials, long long rows, long long B,
                                                                     float* __restrict__ means, float* __restrict__ step_counter,
                                                                     const float* __restrict__ kl_coeff, const float* __restrict__ ent_coeff,
                                                                     float vf_coeff)
 {
-    // 64 walkers per sum slot, rows 64 apart, then a fixed-order sum of the 64 partial sums: deterministic, and short
-    // (a 64-thread block walked 1 024 rows of a 32 768-sample update in 31 us of dependent loads)
-    __shared__ float red[64][kPpoSums];
+    __shared__ float red[4][kPpoSums];
     if (step_counter && threadIdx.x == 0) *step_counter += 1.0f;
-    const int k = threadIdx.x & 7, part = threadIdx.x >> 3;
-    float s = 0.f;
-    for (long long r = part; r < rows; r += 64) s += partials[r * kPpoSums + k];
-    red[part][k] = s;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        float t = 0.f;
-        if (threadIdx.x < kPpoSums)
-            for (int p = 0; p < 64; ++p) t += red[p][threadIdx.x];
-        const float mean = t / (float)B;
-        const float m0 = __shfl(mean, 0, 64), m1 = __shfl(mean, 1, 64), m2 = __shfl(mean, 2, 64), m3 = __shfl(mean, 3, 64);
-        if (threadIdx.x < kPpoSums) means[threadIdx.x] = threadIdx.x == 4 ? m0 + *kl_coeff * m2 + vf_coeff * m1 - *ent_coeff * m3 : mean;
-    }
+    ppo_loss_means_block(partials, rows, B, means, kl_coeff, ent_coeff, vf_coeff, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

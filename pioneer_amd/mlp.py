@@ -142,7 +142,7 @@ class HipMLP:
         return out[0], out[1]
 
 
-    # -- the learner path without autograd: one PPO minibatch update = pnr_mlp_train_step (four launches) ------
+    # -- the learner path without autograd: one PPO minibatch update = pnr_mlp_train_step (three launches) ------
     def adam_state(self):
         """(m, v, step): Adam's moments in the padded gradient layout [pnr_mlp_grad_floats()] and the update count."""
         if not hasattr(self, "_adam"):

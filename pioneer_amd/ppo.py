@@ -755,7 +755,7 @@ class PPOLearner:
             self.opt.load_state_dict(sd)
         self._hip_dirty = True           # the master weights changed behind the packed bf16 copies
 
-    # -- the HIP path: every minibatch update is pnr_mlp_train_step, four launches, no autograd, no hipGraph needed ----
+    # -- the HIP path: every minibatch update is pnr_mlp_train_step, three launches, no autograd, no hipGraph needed ----
     def hip_mlp(self, batch: int):
         if self._mlp is None or self._mlp.max_batch < batch:
             from .mlp import HipMLP
