@@ -1270,7 +1270,7 @@ int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, 
     P.ep_ret = stats ? stats->ep_ret : nullptr; P.ep_len = stats ? stats->ep_len : nullptr; P.partials = stats ? stats->scratch : nullptr;
     P.gamma = (float)gamma; P.gamma_lam = (float)(gamma * lambda);      // the host formula's Python-float product, then float32
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)blocks), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)blocks, (unsigned)(1 + ((actions || terminals) ? T : 0))), dim3(64), 0, st, P);
     if (stats)
         hipLaunchKernelGGL(gae_finish_kernel, dim3(1), dim3(64), 0, st, stats->scratch, blocks, (long long)T * n, stats->w_sum, stats->w_len,
                            stats->w_cnt, stats->w_max, stats->w_min, stats->adv_stats);

@@ -247,55 +247,86 @@ struct GaeParams {
     float gamma, gamma_lam;
 };
 
-// one wave per block: 16 384 envs are 256 blocks = every CU (with 256-thread blocks 64 CUs walked the T steps: 54 us)
+// grid (ceil(N / 64), 1 + T): row 0 of the grid is the per-env scan (one wave per block: 16 384 envs are 256 blocks =
+// every CU; eight steps' loads in flight), rows 1 .. T do the log-probabilities and terminal flags of step t = y - 1, which
+// need no scan (as part of the scan loop their 18 loads and 6 exp per step sat on its critical path: 49 us per rollout)
 __global__ __launch_bounds__(64) void gae_logp_kernel(const GaeParams P)
 {
     const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = n < P.N;
+    if (blockIdx.y > 0) {
+        if (!in) return;
+        const long long i = (long long)(blockIdx.y - 1) * P.N + n;
+        if (P.terminals) P.terminals[i] = (P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0)) ? 1.f : 0.f;
+        if (P.actions) {
+            const float* a = P.actions + i * 6;
+            const float* m = P.mean + i * 6;
+            const float* l = P.log_std + i * 6;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float z = __fmul_rn(__fsub_rn(a[j], m[j]), expf(-l[j]));
+                // (-0.5 z) z - log_std - 0.5 log(2 pi), summed over j in order
+                const float term_j = __fsub_rn(__fsub_rn(__fmul_rn(__fmul_rn(-0.5f, z), z), l[j]), 0.91893853320467274178f);
+                s = __fadd_rn(s, term_j);
+            }
+            P.logp[i] = s;
+        }
+        return;
+    }
     double a_sum = 0.0, a_sq = 0.0, e_cnt = 0.0, e_ret = 0.0, e_len = 0.0;
     float e_max = -__builtin_inff(), e_min = __builtin_inff();
     if (in) {
         float nxt_v = P.last_value[n], nxt_a = 0.f;
         const float gl = P.gamma_lam;
-        for (int t = P.T - 1; t >= 0; --t) {
-            const long long i = (long long)t * P.N + n;
-            const bool term = P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0);
-            const float live = term ? 0.f : 1.f;
-            const float v = P.values[i];
-            // delta = r + gamma * nxt_v * live - v ; adv = delta + gamma * lam * live * nxt_a
-            const float delta = __fsub_rn(__fadd_rn(P.reward[i], __fmul_rn(__fmul_rn(P.gamma, nxt_v), live)), v);
-            nxt_a = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, live), nxt_a));
-            nxt_v = v;
-            P.adv[i] = nxt_a;
-            P.vtarg[i] = __fadd_rn(nxt_a, v);
-            a_sum += (double)nxt_a; a_sq += (double)nxt_a * (double)nxt_a;
-            if (P.terminals) P.terminals[i] = term ? 1.f : 0.f;
-            if (P.actions) {
-                const float* a = P.actions + i * 6;
-                const float* m = P.mean + i * 6;
-                const float* l = P.log_std + i * 6;
-                float s = 0.f;
+        constexpr int U = 8;
+        for (int t1 = P.T; t1 > 0; t1 -= U) {                           // steps t1 - 1 down to max(t1 - U, 0)
+            float rw[U], vv[U]; bool tm[U];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const float z = __fmul_rn(__fsub_rn(a[j], m[j]), expf(-l[j]));
-                    // (-0.5 z) z - log_std - 0.5 log(2 pi), summed over j in order
-                    const float term_j = __fsub_rn(__fsub_rn(__fmul_rn(__fmul_rn(-0.5f, z), z), l[j]), 0.91893853320467274178f);
-                    s = __fadd_rn(s, term_j);
-                }
-                P.logp[i] = s;
+            for (int u = 0; u < U; ++u) {
+                const int t = t1 - 1 - u;
+                const long long i = (long long)(t < 0 ? 0 : t) * P.N + n;
+                rw[u] = P.reward[i]; vv[u] = P.values[i];
+                tm[u] = P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t1 - 1 - u;
+                if (t < 0) break;
+                const long long i = (long long)t * P.N + n;
+                const float live = tm[u] ? 0.f : 1.f;
+                const float v = vv[u];
+                // delta = r + gamma * nxt_v * live - v ; adv = delta + gamma * lam * live * nxt_a
+                const float delta = __fsub_rn(__fadd_rn(rw[u], __fmul_rn(__fmul_rn(P.gamma, nxt_v), live)), v);
+                nxt_a = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, live), nxt_a));
+                nxt_v = v;
+                P.adv[i] = nxt_a;
+                P.vtarg[i] = __fadd_rn(nxt_a, v);
+                a_sum += (double)nxt_a; a_sq += (double)nxt_a * (double)nxt_a;
             }
         }
         if (P.partials) {
             // episode bookkeeping walks forward: EpisodeStats.step()'s arithmetic (return and length accumulate in float32)
             float ret = P.ep_ret[n], len = P.ep_len[n];
-            for (int t = 0; t < P.T; ++t) {
-                const long long i = (long long)t * P.N + n;
-                ret = __fadd_rn(ret, P.reward[i]);
-                len += 1.0f;
-                if (P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0)) {
-                    e_cnt += 1.0; e_ret += (double)ret; e_len += (double)len;
-                    e_max = fmaxf(e_max, ret); e_min = fminf(e_min, ret);
-                    ret = 0.f; len = 0.f;
+            for (int t0 = 0; t0 < P.T; t0 += U) {
+                float rw[U]; bool tm[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u;
+                    const long long i = (long long)(t < P.T ? t : P.T - 1) * P.N + n;
+                    rw[u] = P.reward[i];
+                    tm[u] = P.done[i] | (P.trunc ? P.trunc[i] : (unsigned char)0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (t0 + u >= P.T) break;
+                    ret = __fadd_rn(ret, rw[u]);
+                    len += 1.0f;
+                    if (tm[u]) {
+                        e_cnt += 1.0; e_ret += (double)ret; e_len += (double)len;
+                        e_max = fmaxf(e_max, ret); e_min = fminf(e_min, ret);
+                        ret = 0.f; len = 0.f;
+                    }
                 }
             }
             P.ep_ret[n] = ret; P.ep_len[n] = len;
