@@ -8,7 +8,9 @@ from pioneer_amd.ppo import PPOConfig, PPOTrainer
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 mode = sys.argv[2] if len(sys.argv) > 2 else "kinematic"       # "dynamic": ABA + PD tracking of the same commands
 mbs = int(sys.argv[3]) if len(sys.argv) > 3 else 131072        # 32768: the contract's minibatch (four times as many updates)
-env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500, mode=mode))
+kp = float(sys.argv[4]) if len(sys.argv) > 4 else 4000.0        # dynamics mode: PD gains of the motor
+kd = float(sys.argv[5]) if len(sys.argv) > 5 else 400.0
+env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500, mode=mode, pd_kp=kp, pd_kd=kd))
 cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, lr=3e-4, amp_bf16=True,
                 entropy_coeff_start=3e-3, entropy_decay_steps=100_000_000, seed=0)
 tr = PPOTrainer(env, cfg, use_graph=True)
