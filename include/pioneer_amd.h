@@ -138,7 +138,12 @@ typedef struct pnr_config {
     double max_velocity;          /* control_position's maxVelocity (bullet_scene.py:126,136): cap on the velocity the
                                    * motor asks for, rad/s; <= 0 = none */
     int32_t n_scene;              /* static scene bodies in use, 0 .. PNR_MAX_SCENE */
-    int32_t reserved0;
+    int32_t pd_inertia_scaled;    /* 1: the motor asks for an ACCELERATION pd_kp (r - q) + pd_kd (v* - qd) and applies the torque
+                                   * clip(D_i x that, +-torque_limit), D_i being joint i's articulated-body inertia at the current
+                                   * pose (the ABA forms it anyway): pd_kp = omega^2 and pd_kd = 2 zeta omega then hold for every
+                                   * joint and pose alike, and the explicit motor is stable whenever pd_kd x timestep < 2 — on the
+                                   * light wrist (inertia 6.6) as on the shoulder (1477).  Bullet's own motors are implicit
+                                   * constraints and need no such care.  0: plain torque gains, the same for all joints */
     pnr_scene_body scene[PNR_MAX_SCENE];
 } pnr_config;
 

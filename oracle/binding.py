@@ -201,7 +201,7 @@ class OrcDynParams(C.Structure):
         ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
         ("pointer_radius", C.c_double),
         ("control_mode", C.c_int32), ("link_contacts", C.c_int32), ("max_velocity", C.c_double),
-        ("n_scene", C.c_int32), ("pad2", C.c_int32), ("scene", OrcSceneBody * ORC_MAX_SCENE),
+        ("n_scene", C.c_int32), ("pd_inertia_scaled", C.c_int32), ("scene", OrcSceneBody * ORC_MAX_SCENE),
     ]
 
 
@@ -297,6 +297,11 @@ class DynOracle(COracle):
     def motor_torque(self, r_ref, v_ref, q, qd):
         self.lib.orc_dyn_motor_torque.restype = C.c_double
         return self.lib.orc_dyn_motor_torque(C.byref(self.d), C.c_double(r_ref), C.c_double(v_ref), C.c_double(q), C.c_double(qd))
+
+    def nominal_inertia(self):
+        J = np.zeros(DOF)
+        self.lib.orc_dyn_nominal_inertia(_ptr(J, C.c_double))
+        return J
 
     def contact_samples(self):
         arr = (OrcContactSample * 23)()

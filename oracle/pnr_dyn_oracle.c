@@ -156,6 +156,16 @@ void orc_dyn_aba(const orc_dyn_state* s, const double tau[ORC_DOF], double gravi
 void orc_dyn_aba_ext(const orc_dyn_state* s, const double tau[ORC_DOF], double gravity,
                      const double fext[ORC_DOF][6], double qdd[ORC_DOF])
 {
+    orc_dyn_aba_motor(s, tau, NULL, 0.0, gravity, fext, qdd);
+}
+
+/* The same recursion with an acceleration-level motor term: joint i receives, on top of tau[i], the torque
+ * clip(D_i * ades[i], +-tcap) (tcap <= 0: no cap), D_i being the joint's articulated-body inertia at this pose — the
+ * number pass 2 forms anyway.  A PD law fed in as ades therefore acts with the same stiffness and damping PER UNIT OF
+ * INERTIA on every joint and in every pose (the "pd_inertia_scaled" motor). */
+void orc_dyn_aba_motor(const orc_dyn_state* s, const double tau[ORC_DOF], const double ades[ORC_DOF], double tcap, double gravity,
+                       const double fext[ORC_DOF][6], double qdd[ORC_DOF])
+{
     mat6 I[ORC_DOF], X[ORC_DOF], IA[ORC_DOF];
     vec6 v[ORC_DOF], c[ORC_DOF], pA[ORC_DOF], U[ORC_DOF];
     double mass[ORC_DOF], h[ORC_DOF][3], D[ORC_DOF], u[ORC_DOF];
@@ -179,7 +189,13 @@ void orc_dyn_aba_ext(const orc_dyn_state* s, const double tau[ORC_DOF], double g
         int k = AXIS[i];
         for (int r = 0; r < 6; r++) U[i][r] = IA[i][r][k];
         D[i] = U[i][k];
-        u[i] = tau[i] - pA[i][k];
+        double tq = tau[i];
+        if (ades) {
+            double m = D[i] * ades[i];
+            if (tcap > 0) m = m > tcap ? tcap : (m < -tcap ? -tcap : m);
+            tq += m;
+        }
+        u[i] = tq - pA[i][k];
         if (i > 0) {
             mat6 Ia, T; vec6 pa, Iac, t6;
             for (int r = 0; r < 6; r++) for (int cc = 0; cc < 6; cc++) Ia[r][cc] = IA[i][r][cc] - U[i][r] * U[i][cc] / D[i];
@@ -251,6 +267,29 @@ static void quat_to_matrix(const double qq[4], double R[3][3])
     R[0][0] = 1 - 2 * (y * y + z * z); R[0][1] = 2 * (x * y - z * w);     R[0][2] = 2 * (x * z + y * w);
     R[1][0] = 2 * (x * y + z * w);     R[1][1] = 1 - 2 * (x * x + z * z); R[1][2] = 2 * (y * z - x * w);
     R[2][0] = 2 * (x * z - y * w);     R[2][1] = 2 * (y * z + x * w);     R[2][2] = 1 - 2 * (x * x + y * y);
+}
+
+void orc_dyn_nominal_inertia(double J[ORC_DOF])
+{
+    /* zero pose: every body frame is parallel to the world's (no rpy in the URDF's joint origins); joint i sits at the sum
+     * of the origins up to i.  A link of mass 1 and inertia diag(1,1,1) at position c adds 1 + |a x (c - p_i)|^2 about the
+     * axis a through p_i (parallel-axis theorem; the isotropic inertia gives 1 about any axis). */
+    double p[ORC_DOF][3];
+    for (int i = 0; i < ORC_DOF; i++)
+        for (int k = 0; k < 3; k++) p[i][k] = (i ? p[i - 1][k] : 0.0) + ORIGIN[i][k];
+    for (int i = 0; i < ORC_DOF; i++) {
+        J[i] = 0.0;
+        for (int l = 0; l < ORC_LINKS; l++) {
+            int b = LINK_BODY[l];
+            if (b < i) continue;                               /* inboard of joint i (or the static base) */
+            double c[3], d[3], x[3], a[3] = {0, 0, 0};
+            for (int k = 0; k < 3; k++) c[k] = p[b][k] + ((l == ORC_LINKS - 1) ? TIP[k] : 0.0);
+            for (int k = 0; k < 3; k++) d[k] = c[k] - p[i][k];
+            a[AXIS[i]] = 1.0;
+            cross3(a, d, x);
+            J[i] += 1.0 + x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+        }
+    }
 }
 
 static int contact_force_sphere(const orc_dyn_params* d, const double pos[3], const double vel[3], double radius, double f[3]);
@@ -431,6 +470,7 @@ void orc_dyn_params_default(orc_dyn_params* d)
     d->obstacle_half_extents[0] = d->obstacle_half_extents[1] = d->obstacle_half_extents[2] = 0.0;  /* disabled */
     d->pointer_radius = 0.2;                                                                          /* urdf:193 */
     d->control_mode = 0; d->link_contacts = 0; d->max_velocity = 0.0;
+    d->n_scene = 0; d->pd_inertia_scaled = 0;
 }
 
 void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state* s,
@@ -438,16 +478,24 @@ void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state
 {
     double tau[ORC_DOF], qdd[ORC_DOF], fext[ORC_DOF][6];
     int have_ext = 0;
+    double ades[ORC_DOF];
     for (int i = 0; i < ORC_DOF; i++) {
         double t = 0.0;
-        if (!d->teleport) t = orc_dyn_motor_torque(d, r_ref[i], v_ref[i], s->q[i], s->qd[i]);
+        ades[i] = 0.0;
+        if (!d->teleport) {
+            if (d->pd_inertia_scaled) {          /* the motor law UNCAPPED, as an acceleration request; the cap acts on D_i * ades */
+                orc_dyn_params u = *d; u.torque_limit = 0.0;
+                ades[i] = orc_dyn_motor_torque(&u, r_ref[i], v_ref[i], s->q[i], s->qd[i]);
+            } else t = orc_dyn_motor_torque(d, r_ref[i], v_ref[i], s->q[i], s->qd[i]);
+        }
         t -= s->damping[i] * s->qd[i];
         t -= s->friction[i] * s->qd[i] / sqrt(s->qd[i] * s->qd[i] + FRICTION_EPS * FRICTION_EPS);
         tau[i] = t;
     }
     if (d->ground_z == d->ground_z || d->obstacle_half_extents[0] > 0 || d->n_scene > 0)
         have_ext = orc_dyn_contact_wrenches(d, s, fext);
-    orc_dyn_aba_ext(s, tau, d->gravity, have_ext ? (const double (*)[6])fext : NULL, qdd);
+    orc_dyn_aba_motor(s, tau, d->pd_inertia_scaled ? ades : NULL, d->torque_limit, d->gravity,
+                      have_ext ? (const double (*)[6])fext : NULL, qdd);
     for (int i = 0; i < ORC_DOF; i++) {          /* semi-implicit Euler + inelastic joint limits */
         s->qd[i] += qdd[i] * d->timestep;
         s->q[i] += s->qd[i] * d->timestep;

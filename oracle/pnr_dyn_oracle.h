@@ -62,7 +62,9 @@ typedef struct orc_dyn_params {
                                  (capsules fitted to the URDF's visual boxes, which carry no <collision> of their own) */
     double max_velocity;      /* control_position's maxVelocity: cap on the velocity the motor asks for; <= 0 = none */
     int32_t n_scene;          /* static scene bodies every contact sample sphere collides with (surface to surface) */
-    int32_t pad2;
+    int32_t pd_inertia_scaled;/* 1: kp / kd are per unit of each joint's articulated-body inertia D_i at the current pose (the motor
+                                 asks for an ACCELERATION kp (r - q) + kd (v* - qd); torque = clip(D_i x that, +-torque_limit)), i.e.
+                                 kp = omega^2 and kd = 2 zeta omega for every joint and pose alike; 0: plain torque gains */
     orc_scene_body scene[ORC_MAX_SCENE];
 } orc_dyn_params;
 
@@ -90,6 +92,12 @@ void orc_dyn_aba_ext(const orc_dyn_state* s, const double tau[ORC_DOF], double g
 
 /* the motor torque of one joint (PD / velocity servo with the maxVelocity and force caps), before damping and friction */
 double orc_dyn_motor_torque(const orc_dyn_params* d, double r_ref, double v_ref, double q, double qd);
+/* J_i: rotational inertia about joint i's axis of everything outboard of it at the zero pose, unscaled link masses
+ * (= the mass-matrix diagonal there; a yardstick for gains, not used by the motor) */
+void orc_dyn_nominal_inertia(double J[ORC_DOF]);
+/* ABA with an acceleration-level motor term: + clip(D_i ades[i], +-tcap) on joint i (ades NULL: plain ABA) */
+void orc_dyn_aba_motor(const orc_dyn_state* s, const double tau[ORC_DOF], const double ades[ORC_DOF], double tcap, double gravity,
+                       const double fext[ORC_DOF][6], double qdd[ORC_DOF]);
 
 /* penalty contact forces of all active sample spheres as per-body spatial forces; returns 1 if any contact is active */
 int orc_dyn_contact_wrenches(const orc_dyn_params* d, const orc_dyn_state* s, double fext[ORC_DOF][6]);

@@ -63,7 +63,7 @@ class PnrConfig(C.Structure):
         ("obstacle_position", C.c_double * 3), ("obstacle_half_extents", C.c_double * 3),
         ("pointer_radius", C.c_double),
         ("control_mode", C.c_int32), ("link_contacts", C.c_int32), ("max_velocity", C.c_double),
-        ("n_scene", C.c_int32), ("reserved0", C.c_int32), ("scene", PnrSceneBody * MAX_SCENE),
+        ("n_scene", C.c_int32), ("pd_inertia_scaled", C.c_int32), ("scene", PnrSceneBody * MAX_SCENE),
     ]
 
 

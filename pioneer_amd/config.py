@@ -119,6 +119,10 @@ class EngineConfig:
     # contacts of the LINKS with the plane / box: sample spheres along capsules fitted to the URDF's visual boxes (the
     # reference URDF carries no <collision> elements, so without this only the pointer sphere collides)
     link_contacts: bool = False
+    # the motor asks for the acceleration pd_kp (r - q) + pd_kd (v* - qd), scaled by each joint's articulated-body inertia at
+    # the current pose: pd_kp = omega^2, pd_kd = 2 zeta omega for every joint and pose alike (e.g. 400 / 40), stable whenever
+    # pd_kd * timestep < 2 on the light wrist as on the heavy shoulder
+    pd_inertia_scaled: bool = False
     # further static bodies (up to 8): planes of any normal, oriented boxes, spheres — see SceneBody
     scene: Tuple[SceneBody, ...] = ()
 
@@ -170,6 +174,7 @@ def to_c_config(pioneer: PioneerKinematicConfig, sim: SimulationConfig, engine: 
     c.control_mode = _CONTROLS[engine.control_mode]
     c.max_velocity = float(engine.max_velocity)
     c.link_contacts = int(bool(engine.link_contacts))
+    c.pd_inertia_scaled = int(bool(engine.pd_inertia_scaled))
     shapes = {"plane": _lib.SHAPE_PLANE, "box": _lib.SHAPE_BOX, "sphere": _lib.SHAPE_SPHERE}
     if len(engine.scene) > _lib.MAX_SCENE:
         raise AssertionError(f"at most {_lib.MAX_SCENE} scene bodies")

@@ -294,7 +294,7 @@ __device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParam
 
 // Leading scalar arguments as in step_kernel: preloaded into SGPRs, they repeat P.state / D.dyn / P.actions /
 // P.n / P.dt / P.eps and carry max_v_to_r.
-template <bool OBS_EM, bool ACT_EM, bool RAND, bool CONTACT>
+template <bool OBS_EM, bool ACT_EM, bool RAND, int PHYS>
 __global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
                                                          const float* __restrict__ actions_, const long long n_,
                                                          const double dt_, const double eps_, const float max_v_to_r_,
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restric
         float4 k0[2] = {z4, z4}, k1[2] = {z4, z4}, k2[2] = {z4, z4};
         float q[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qd[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
-        if (e < n) dyn_substeps_lane<ACT_EM, RAND, CONTACT>(lead, D, e, k0, k1, k2, q, qd, tile);   // tile: free during phase A
+        if (e < n) dyn_substeps_lane<ACT_EM, RAND, PHYS>(lead, D, e, k0, k1, k2, q, qd, tile);   // tile: free during phase A
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             hrec[2 * lane + p] = k0[p];
@@ -505,7 +505,7 @@ __device__ __forceinline__ void dyn_rollout_tile(const KParams& P, const DynPara
 // The obs stores of step t drain under the sub-steps of step t + 1.  The hand-off has its own 9 KB here (the
 // kernel runs one wave per SIMD anyway), so a tile's values are read right before that tile is finished and
 // nothing of phase B is live during the sub-steps.
-template <bool OBS_EM, bool ACT_EM, bool RAND, bool CONTACT>
+template <bool OBS_EM, bool ACT_EM, bool RAND, int PHYS>
 __global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
                                                          const float* __restrict__ actions_, const long long n_,
                                                          const double dt_, const double eps_, const float max_v_to_r_,
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __rest
     const int T = P.T;
     for (int t = 0; t < T; ++t) {
         // ---- phase A: one env per lane
-        if (liveA) dyn_lane_advance<ACT_EM, RAND, CONTACT>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L,
+        if (liveA) dyn_lane_advance<ACT_EM, RAND, PHYS>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L,
                                                            lds + kTileFloats + kComFloats + kRstFloats + kHandFloats);
         dyn_write_handoff(hand, lane, L);
         rst[lane] = 0.f;                                // no reset noted yet (episode counters are >= 1)
@@ -791,6 +791,7 @@ int pnr_config_default(pnr_config* c)
     c->pointer_radius = 0.2;
     c->control_mode = PNR_CONTROL_POSITION; c->max_velocity = 0.0; c->link_contacts = 0;
     c->n_scene = 0;                                         // scene[] zeroed by the memset above
+    c->pd_inertia_scaled = 0;
     return PNR_OK;
 }
 
@@ -891,6 +892,7 @@ static void fill_base(pnr_handle h)
         D.v_cap = capped ? (float)c.max_velocity : INFINITY;
     }
     D.link_contacts = c.link_contacts ? 1 : 0;
+    D.inertia_scaled = c.pd_inertia_scaled ? 1 : 0;
     D.n_scene = h->scene ? c.n_scene : 0;
     D.scene = h->scene;
     SceneBody host_scene[kMaxScene];
@@ -1109,7 +1111,10 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
         else hipLaunchKernelGGL((dyn_step_kernel<O, A, R, C>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                 Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); } while (0)
             // contact-free handles run instantiations without any contact code
-#define PNR_DYN_LAUNCH(O, A, R) do { if (D.has_ground || D.has_box || D.n_scene > 0) PNR_DYN_LAUNCH2(O, A, R, true); else PNR_DYN_LAUNCH2(O, A, R, false); } while (0)
+            // (PHYS: bit 0 contacts, bit 1 the inertia-scaled motor)
+#define PNR_DYN_LAUNCH(O, A, R) do { const bool ct_ = D.has_ground || D.has_box || D.n_scene > 0; \
+        if (D.inertia_scaled) { if (ct_) PNR_DYN_LAUNCH2(O, A, R, 3); else PNR_DYN_LAUNCH2(O, A, R, 2); } \
+        else { if (ct_) PNR_DYN_LAUNCH2(O, A, R, 1); else PNR_DYN_LAUNCH2(O, A, R, 0); } } while (0)
             if (oem) {
                 if (aem) { if (rnd) PNR_DYN_LAUNCH(true, true, true); else PNR_DYN_LAUNCH(true, true, false); }
                 else { if (rnd) PNR_DYN_LAUNCH(true, false, true); else PNR_DYN_LAUNCH(true, false, false); }

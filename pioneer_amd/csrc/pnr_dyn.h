@@ -54,6 +54,7 @@ struct DynParams {
     //   tau = clip(kp_eff (r - q) + kd (clamp(v + c_pos (r - q), +-v_cap) - qd), +-tau_max)
     float kp_eff, c_pos, v_cap;
     int link_contacts;          // 1: the link capsules' sample spheres collide too (pnr_model.h kCapsules)
+    int inertia_scaled;         // 1: the motor law is an acceleration request scaled by each joint's articulated inertia
     int n_scene;                // static bodies of create_body_plane / _box / _sphere (bullet_scene.py:193-228)
     const SceneBody* scene;     // [n_scene] in device memory (a by-value array indexed by the loop counter went to scratch)
 };
@@ -335,8 +336,10 @@ __device__ __forceinline__ void build_model(const float (&sc)[kNumLinks], DynMod
 
 // one joint of pass 2 (tip -> base).  IA/pA: articulated inertia / bias force of body J in its own
 // frame (children already folded in).  Emits U, D, u and folds body J into its parent (IP, pP).
-template <int J>
-__device__ __forceinline__ void aba_inward(const SIp& IA, const P3& pA, const P3& vJ, float qdJ, float tauJ,
+// SCALED: the joint's motor asks for the acceleration adesJ; its torque is clip(D adesJ, +-tcap), D being the articulated
+// inertia about the joint axis that this step forms anyway (pnr_config.pd_inertia_scaled)
+template <int J, bool SCALED>
+__device__ __forceinline__ void aba_inward(const SIp& IA, const P3& pA, const P3& vJ, float qdJ, float tauJ, float adesJ, float tcap,
                                            float cJ, float sJ, DynBody& out, SIp& IP, P3& pP)
 {
     constexpr int k = (int)kJoints[J].axis;
@@ -348,7 +351,9 @@ __device__ __forceinline__ void aba_inward(const SIp& IA, const P3& pA, const P3
     });
     out.U = u;
     out.D = pc<k>(u).x;
-    out.u = tauJ - pc<k>(pA).x;
+    float tq = tauJ;
+    if constexpr (SCALED) tq += fminf(fmaxf(out.D * adesJ, -tcap), tcap);
+    out.u = tq - pc<k>(pA).x;
     if (J == 0) return;
     const float invD = fast_rcp(out.D);
     // Ia = IA - U U^T / D
@@ -583,10 +588,13 @@ __device__ __forceinline__ void contact_wrenches(const DynParams& D, const float
 // qdd = ABA(q, qd, tau).  CONTACT: the penalty contacts' external forces are subtracted from the bodies' bias forces
 // (a separate instantiation: the contact-free kernels carry none of that code or its registers)
 // c, s: cos / sin of the joint angles (dyn_core carries them across the sub-steps)
-template <bool CONTACT>
+// PHYS: bit 0 = contacts, bit 1 = the inertia-scaled motor (its acceleration requests in ades, torque cap tcap)
+template <int PHYS>
 __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const float (&c)[kDof], const float (&s)[kDof],
-                                    const float (&qd)[kDof], const float (&tau)[kDof], float (&qdd)[kDof])
+                                    const float (&qd)[kDof], const float (&tau)[kDof], const float (&ades)[kDof], float tcap,
+                                    float (&qdd)[kDof])
 {
+    constexpr bool CONTACT = (PHYS & 1) != 0, SCALED = (PHYS & 2) != 0;
 
     // pass 1: body velocities
     P3 v[kDof];
@@ -612,20 +620,20 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
     if (CONTACT) pA = pA - fext[5];
     rigid_body<4>(M, v[4], IP, pP);
     if (CONTACT) pP = pP - fext[4];
-    aba_inward<5>(IA, pA, v[5], qd[5], tau[5], c[5], s[5], B[5], IP, pP);
+    aba_inward<5, SCALED>(IA, pA, v[5], qd[5], tau[5], ades[5], tcap, c[5], s[5], B[5], IP, pP);
     IA = IP; pA = pP; rigid_body<3>(M, v[3], IP, pP);
     if (CONTACT) pP = pP - fext[3];
-    aba_inward<4>(IA, pA, v[4], qd[4], tau[4], c[4], s[4], B[4], IP, pP);
+    aba_inward<4, SCALED>(IA, pA, v[4], qd[4], tau[4], ades[4], tcap, c[4], s[4], B[4], IP, pP);
     IA = IP; pA = pP; rigid_body<2>(M, v[2], IP, pP);
     if (CONTACT) pP = pP - fext[2];
-    aba_inward<3>(IA, pA, v[3], qd[3], tau[3], c[3], s[3], B[3], IP, pP);
+    aba_inward<3, SCALED>(IA, pA, v[3], qd[3], tau[3], ades[3], tcap, c[3], s[3], B[3], IP, pP);
     IA = IP; pA = pP; rigid_body<1>(M, v[1], IP, pP);
     if (CONTACT) pP = pP - fext[1];
-    aba_inward<2>(IA, pA, v[2], qd[2], tau[2], c[2], s[2], B[2], IP, pP);
+    aba_inward<2, SCALED>(IA, pA, v[2], qd[2], tau[2], ades[2], tcap, c[2], s[2], B[2], IP, pP);
     IA = IP; pA = pP; rigid_body<0>(M, v[0], IP, pP);
-    aba_inward<1>(IA, pA, v[1], qd[1], tau[1], c[1], s[1], B[1], IP, pP);
+    aba_inward<1, SCALED>(IA, pA, v[1], qd[1], tau[1], ades[1], tcap, c[1], s[1], B[1], IP, pP);
     IA = IP; pA = pP;
-    aba_inward<0>(IA, pA, v[0], qd[0], tau[0], c[0], s[0], B[0], IP, pP);
+    aba_inward<0, SCALED>(IA, pA, v[0], qd[0], tau[0], ades[0], tcap, c[0], s[0], B[0], IP, pP);
 
     // pass 3: base -> tip; gravity as a base acceleration +g along z
     P3 a0 = {{0.f, 0.f}, {0.f, 0.f}, {0.f, D.gravity}}, a1;
@@ -733,7 +741,7 @@ __device__ __forceinline__ void dyn_lane_load(const DynLead& in, long long base,
 #endif
 constexpr int kDynStageWords = 33;
 
-template <bool CONTACT>
+template <int PHYS>
 __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, float (&a)[kDof], float (&v)[kDof],
                                          float (&r)[kDof], float (&q)[kDof], float (&qd)[kDof], const float (&sc)[kNumLinks],
                                          const float (&fric_)[kDof], const float (&damp_)[kDof], const float (&act)[kDof],
@@ -781,7 +789,7 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
 #pragma unroll
     for (int i = 0; i < kDof; ++i) { float sn, cn; sincos_bounded(q[i], sn, cn); cs[i] = (f2){cn, sn}; }
     for (int k = 0; k < D.nsub; ++k) {
-        float tau[kDof], qdd[kDof];
+        float tau[kDof], qdd[kDof], ades[kDof];
 #if PNR_DYN_LDS_MODEL
         {   // re-read the staged model: the offset is opaque per iteration, so nothing is hoisted out of the loop
             int off = threadIdx.x & 63;
@@ -799,7 +807,8 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
             const float dq = r[i] - q[i];
             const float v_ask = fminf(fmaxf(v[i] + cpos * dq, -vcap), vcap);
             float tq = kp * dq + kd * (v_ask - qd[i]);
-            tq = fminf(fmaxf(tq, -tcap), tcap);
+            if constexpr ((PHYS & 2) != 0) { ades[i] = tq; tq = 0.f; }        // an acceleration request: scaled and capped inside the ABA
+            else { ades[i] = 0.f; tq = fminf(fmaxf(tq, -tcap), tcap); }
             tq -= damp[i] * qd[i];
             tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
             tau[i] = tq;
@@ -808,7 +817,7 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
             float c[kDof], s[kDof];
 #pragma unroll
             for (int i = 0; i < kDof; ++i) { c[i] = cs[i].x; s[i] = cs[i].y; }
-            aba<CONTACT>(D, M, c, s, qd, tau, qdd);
+            aba<PHYS>(D, M, c, s, qd, tau, ades, tcap, qdd);
         }
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits (selects, no branches)
@@ -835,7 +844,7 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
     }
 }
 
-template <bool ACT_EM, bool RAND, bool CONTACT>
+template <bool ACT_EM, bool RAND, int PHYS>
 __device__ __forceinline__ void dyn_lane_advance(const DynLead& in, const DynParams& D, long long base, int lane,
                                                  const float* __restrict__ next_actions, DynLane& L, float* stage = nullptr)
 {
@@ -844,7 +853,7 @@ __device__ __forceinline__ void dyn_lane_advance(const DynLead& in, const DynPar
     for (int i = 0; i < kDof; ++i) act[i] = L.act[i];
     // the action after this one is requested now: it arrives under the sub-steps (next_actions: null on the last step)
     if (next_actions) dyn_load_action<ACT_EM>(next_actions, in.n, base, lane, L.act);
-    dyn_core<CONTACT>(in, D, L.a, L.v, L.r, L.q, L.qd, L.sc, L.fric, L.damp, act, stage);
+    dyn_core<PHYS>(in, D, L.a, L.v, L.r, L.q, L.qd, L.sc, L.fric, L.damp, act, stage);
 }
 
 // The per-env parameter draws of a reset: Philox blocks 3..8 of the env's counter (the joints and the target
@@ -879,7 +888,7 @@ __device__ __forceinline__ void dyn_draw_params(const KParams& P, const DynParam
 // the single-step kernel (A/B inside one library: 32.15 vs 32.85 us per 65 536-env step; SQ_WAIT_INST_ANY +40 %).
 // In: nothing but the env index.  Out: the env's two state records as they lie in HBM (a, v, r updated), q, qd.
 // ---------------------------------------------------------------------------------
-template <bool ACT_EM, bool RAND, bool CONTACT>
+template <bool ACT_EM, bool RAND, int PHYS>
 __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynParams& D, long long e,
                                                   float4 (&k0)[2], float4 (&k1)[2], float4 (&k2)[2],
                                                   float (&q)[kDof], float (&qd)[kDof], float* stage = nullptr)
@@ -916,7 +925,7 @@ __device__ __forceinline__ void dyn_substeps_lane(const DynLead& in, const DynPa
 #pragma unroll
         for (int i = 0; i < kDof; ++i) act[i] = in.actions[(long long)i * n + e];
     }
-    dyn_core<CONTACT>(in, D, a, v, r, q, qd, sc, fric, damp, act, stage);
+    dyn_core<PHYS>(in, D, a, v, r, q, qd, sc, fric, damp, act, stage);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         k0[p] = make_float4(a[3 * p], a[3 * p + 1], a[3 * p + 2], v[3 * p]);

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import COracle, DynOracle
-from oracle.binding import ORC_DEV
+from oracle.binding import ORC_DEV, _ptr
 from oracle.numpy_twin import CHAIN, _axis_angle
 
 # URDF link order (tests/golden/urdf_chain.json): world, base, rotator1, hinge1, arm1, arm2,
@@ -399,3 +399,53 @@ def test_scene_sphere_pushes_the_pointer_radially():
     assert np.allclose(f[5, 3:6], want, rtol=1e-9, atol=1e-9)
     any_, f = _wrench(dict(scene=[("sphere", tuple(tip + 10.0), (0, 0, 0, 1), (R, 0, 0))]), q)
     assert not any_ and not f.any()
+
+
+def test_nominal_joint_inertias_are_the_mass_matrix_diagonal_at_the_zero_pose(oracle_built):
+    """A yardstick for motor gains: J_i = M_ii(q = 0) of the independent per-link Lagrangian formulation above; 6.6 on the
+    wrist, 1 477 on the shoulder — why one pair of torque gains cannot serve all six joints."""
+    o = DynOracle(1, seed=0)
+    J = o.nominal_inertia()
+    M = mass_matrix(np.zeros(6), np.ones(11))
+    assert np.allclose(J, np.diag(M), rtol=1e-12)
+    assert np.allclose(J, [592.16, 1476.57, 586.77, 9.61, 20.57, 6.61], atol=5e-3)
+
+
+def test_inertia_scaled_motor_is_an_acceleration_request(oracle_built):
+    """pd_inertia_scaled: joint i gets the torque D_i a_i with a_i = kp (r - q) + kd (v - qd) and D_i its articulated-body
+    inertia.  With the other joints' requests at zero and no velocity, the ABA then returns qdd_i = a_i up to the coupling
+    through the parent's acceleration — exactly a_i for the base joint, whose parent is the fixed world."""
+    import ctypes as C
+    rng = np.random.RandomState(2)
+    o = DynOracle(1, seed=0, dyn=dict(kp=400.0, kd=40.0, pd_inertia_scaled=1))
+    L = o.lib
+    for _ in range(10):
+        q = rng.uniform(-1.2, 1.2, 6)
+        set_state(o, q, np.zeros(6))
+        ades = np.zeros(6); ades[0] = rng.uniform(0.5, 5) * rng.choice([-1.0, 1.0])
+        qdd = np.zeros(6)
+        L.orc_dyn_aba_motor(o._one(0), _ptr(np.zeros(6), C.c_double), _ptr(ades, C.c_double), C.c_double(0.0), C.c_double(0.0), None,
+                            _ptr(qdd, C.c_double))
+        assert abs(qdd[0] - ades[0]) < 1e-9 * abs(ades[0])
+        # and the cap acts on the torque D_i a_i
+        qdd_c = np.zeros(6)
+        L.orc_dyn_aba_motor(o._one(0), _ptr(np.zeros(6), C.c_double), _ptr(ades, C.c_double), C.c_double(1e-3), C.c_double(0.0), None,
+                            _ptr(qdd_c, C.c_double))
+        assert abs(qdd_c[0]) < abs(qdd[0]) * 1e-2
+
+
+def test_inertia_scaled_gains_track_every_joint_alike(oracle_built):
+    """omega = 20 rad/s, zeta = 1 on every joint: a step in the command is followed within half a second by the heavy base
+    joints and the light wrist alike (cross-coupling leaves a few hundredths of a radian of ringing); with the plain gains
+    4000 / 400 the base joints have covered less than two thirds of the way by then."""
+    r = np.array([0.5, 0.3, -0.3, 0.5, 0.4, -0.5])
+    err = {}
+    for name, dyn in (("scaled", dict(kp=400.0, kd=40.0, pd_inertia_scaled=1)), ("plain", dict(kp=4000.0, kd=400.0))):
+        o = DynOracle(1, seed=0, dyn=dyn)
+        o.reset(joint_pos=np.zeros((1, 6)))
+        o.state["r"][0] = r.astype(o.state["r"].dtype); o.state["v"][0] = 0.0
+        for _ in range(12):                                    # twelve env steps = 0.5 s, zero action: the command stays put
+            o.step(np.zeros((1, 6), np.float32))
+        err[name] = np.abs(o.dstate["q"][0] - o.state["r"][0])
+    assert err["scaled"].max() < 0.03, err
+    assert err["plain"][:3].max() > 0.1, err

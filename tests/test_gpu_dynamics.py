@@ -49,6 +49,7 @@ def make(n, seed=0, auto_reset=False, max_steps=0, layout="env_major", gravity=0
                        pointer_radius=ek.pop("pointer_radius", 0.2),
                        control_mode={0: "position", 1: "velocity"}[ek.pop("control_mode", 0)],
                        max_velocity=ek.pop("max_velocity", 0.0), link_contacts=bool(ek.pop("link_contacts", 0)),
+                       pd_inertia_scaled=bool(ek.pop("pd_inertia_scaled", 0)),
                        scene=tuple(SceneBody(sh, tuple(p), tuple(q), tuple(sz)) for sh, p, q, sz in ek.pop("scene", ())))
     assert not ek
     env = PioneerVectorEnv(n, device="cuda:0", seed=seed, simulation_config=SimulationConfig(gravity=gravity),
@@ -84,7 +85,7 @@ def test_teleport_zero_gravity_equals_kinematic_kernel():
 
 @pytest.mark.parametrize("scenario", ["pd", "gravity_friction", "randomized", "ground", "torque_limited", "box", "box_and_ground",
                                       "velocity_control", "max_velocity", "links_ground", "box_links", "scene_pointer",
-                                      "scene_links"])
+                                      "scene_links", "inertia_scaled_pd"])
 def test_single_step_parity_resynced(scenario):
     cfg = {
         "pd": dict(),
@@ -105,6 +106,8 @@ def test_single_step_parity_resynced(scenario):
         "box_links": dict(gravity=9.81, link_contacts=1, obstacle_position=(12.0, 0.0, 4.0), obstacle_half_extents=(4.0, 6.0, 4.0)),
         # static scene bodies (create_body_plane / _box / _sphere, bullet_scene.py:193-228): a tilted plane, a box turned
         # about a skew axis and a large sphere, all inside the arm's reach; first the pointer alone, then all 23 samples
+        # gains per unit of each joint's nominal inertia: omega = 20 rad/s, zeta = 1 on every joint
+        "inertia_scaled_pd": dict(gravity=9.81, kp=400.0, kd=40.0, pd_inertia_scaled=1, joint_damping=0.02),
         "scene_pointer": dict(gravity=9.81, pointer_radius=1.0, scene=SCENE),
         "scene_links": dict(gravity=9.81, link_contacts=1, scene=SCENE),
     }[scenario]

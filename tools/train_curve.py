@@ -10,7 +10,8 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "kinematic"       # "dynamic": ABA 
 mbs = int(sys.argv[3]) if len(sys.argv) > 3 else 131072        # 32768: the contract's minibatch (four times as many updates)
 kp = float(sys.argv[4]) if len(sys.argv) > 4 else 4000.0        # dynamics mode: PD gains of the motor
 kd = float(sys.argv[5]) if len(sys.argv) > 5 else 400.0
-env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500, mode=mode, pd_kp=kp, pd_kd=kd))
+scaled = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False  # gains per unit of each joint's nominal inertia (e.g. 400 40 1)
+env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500, mode=mode, pd_kp=kp, pd_kd=kd, pd_inertia_scaled=scaled))
 cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, lr=3e-4, amp_bf16=True,
                 entropy_coeff_start=3e-3, entropy_decay_steps=100_000_000, seed=0)
 tr = PPOTrainer(env, cfg, use_graph=True)
