@@ -10,9 +10,11 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "kinematic"       # "dynamic": ABA 
 mbs = int(sys.argv[3]) if len(sys.argv) > 3 else 131072        # 32768: the contract's minibatch (four times as many updates)
 kp = float(sys.argv[4]) if len(sys.argv) > 4 else 4000.0        # dynamics mode: PD gains of the motor
 kd = float(sys.argv[5]) if len(sys.argv) > 5 else 400.0
-scaled = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False  # gains per unit of each joint's nominal inertia (e.g. 400 40 1)
+scaled = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False  # gains per unit of each joint's articulated inertia (e.g. 400 40 1)
+bf16 = bool(int(sys.argv[7])) if len(sys.argv) > 7 else True     # 0: float32 torch learner (autograd, BLAS) instead of the HIP kernels
+lr = float(sys.argv[8]) if len(sys.argv) > 8 else 3e-4
 env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500, mode=mode, pd_kp=kp, pd_kd=kd, pd_inertia_scaled=scaled))
-cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, lr=3e-4, amp_bf16=True,
+cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, lr=lr, amp_bf16=bf16,
                 entropy_coeff_start=3e-3, entropy_decay_steps=100_000_000, seed=0)
 tr = PPOTrainer(env, cfg, use_graph=True)
 t0 = time.time(); rows = []
