@@ -34,9 +34,12 @@ class PioneerKinematicEnv:
                  simulation_config: Optional[SimulationConfig] = None,
                  render_config: Optional[RenderConfig] = None,
                  device=None,
-                 mode: str = "kinematic"):
+                 mode: str = "kinematic",
+                 engine_config: Optional[EngineConfig] = None):
+        """``engine_config`` (optional, no reference counterpart): the engine's own options, e.g. the dynamics-mode motor and
+        scene; its ``mode`` wins over the ``mode`` argument, and the env itself never truncates or auto-resets."""
         self._ctor = dict(headless=headless, pioneer_config=pioneer_config, simulation_config=simulation_config,
-                          render_config=render_config, device=device, mode=mode)
+                          render_config=render_config, device=device, mode=mode, engine_config=engine_config)
         self.headless = headless
         self.config = pioneer_config or PioneerKinematicConfig()
         self.simulation_config = simulation_config or SimulationConfig()
@@ -49,7 +52,11 @@ class PioneerKinematicEnv:
         self.step_index = 0
 
         # the env itself never truncates or auto-resets: TimeLimit / the sampler do
-        engine = EngineConfig(max_episode_steps=0, auto_reset=False, mode=mode)
+        if engine_config is not None:
+            import dataclasses
+            engine = dataclasses.replace(engine_config, max_episode_steps=0, auto_reset=False)
+        else:
+            engine = EngineConfig(max_episode_steps=0, auto_reset=False, mode=mode)
         self.np_random = None                                              # :45
         self.seed()                                                        # :46
         self._vec = PioneerVectorEnv(1, device=device, seed=self._seed_value,

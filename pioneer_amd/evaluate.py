@@ -29,12 +29,12 @@ def load_policy(checkpoint: str, device):
 @torch.no_grad()
 def evaluate(checkpoint: str, episodes: int = 3, max_episode_steps: int = 500, gif_path: Optional[str] = None,
              device="cuda:0", mode: str = "kinematic", seed: Optional[int] = 0, frame_stride: int = 1,
-             deterministic: bool = True) -> Dict:
+             deterministic: bool = True, engine_config=None) -> Dict:
     """Returns {"episode_rewards", "episode_lengths", "successes", "frames"}; writes an animated GIF of all
     episodes when gif_path is given (24 frames per second, the env's metadata rate)."""
     device = torch.device(device)
     model, filt, cfg = load_policy(checkpoint, device)
-    env = TimeLimit(PioneerKinematicEnv(device=device, mode=mode), max_episode_steps=max_episode_steps)
+    env = TimeLimit(PioneerKinematicEnv(device=device, mode=mode, engine_config=engine_config), max_episode_steps=max_episode_steps)
     if seed is not None:
         env.seed(seed)
     a_max = torch.from_numpy(env.action_space.high).to(device)

@@ -9,15 +9,19 @@ from pioneer_amd.ppo import PPOConfig, PPOTrainer
 
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+dynamic = len(sys.argv) > 3 and sys.argv[3] == "dynamic"         # ABA + the inertia-scaled motor instead of the kinematic arm
 os.makedirs(out, exist_ok=True)
-env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500))
-tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=131072, lr=3e-4, amp_bf16=True,
+eng = EngineConfig(max_episode_steps=500, mode="dynamic", pd_kp=400.0, pd_kd=40.0, pd_inertia_scaled=True) if dynamic \
+    else EngineConfig(max_episode_steps=500)
+env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=eng)
+tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=32768, lr=1e-4, amp_bf16=True,
                                entropy_coeff_start=3e-3, entropy_decay_steps=100_000_000, seed=0), use_graph=True)
 for _ in range(iters):
     r = tr.train()
 ck = tr.save(os.path.join(out, "demo_policy.pt"))
 env.close()
-res = evaluate(ck, episodes=4, max_episode_steps=500, gif_path=os.path.join(out, "demo_full.gif"), frame_stride=2, seed=11)
+res = evaluate(ck, episodes=4, max_episode_steps=500, gif_path=os.path.join(out, "demo_full.gif"), frame_stride=2, seed=11,
+               engine_config=eng if dynamic else None)
 im = Image.open(os.path.join(out, "demo_full.gif"))
 small = []
 for k in range(im.n_frames):
