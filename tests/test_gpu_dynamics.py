@@ -388,3 +388,30 @@ def test_link_contacts_hold_an_arm_on_the_plane_and_flags_are_checked():
     with pytest.raises(AssertionError):
         PioneerVectorEnv(4, device="cuda:0", simulation_config=SimulationConfig(self_collision=True),
                          engine_config=EngineConfig(mode="dynamic", link_contacts=True))
+
+
+def test_facade_with_an_engine_config_runs_the_dynamics_motor():
+    """PioneerKinematicEnv(engine_config=...): the single-env façade on the dynamics engine with the inertia-scaled motor —
+    its TimeLimit / auto-reset stay the wrapper's business, a zero action keeps the arm at rest without gravity, a
+    commanded move is followed within half a second, and the env pickles by constructor arguments."""
+    import pickle
+    from pioneer_amd import PioneerKinematicEnv, EngineConfig
+    eng = EngineConfig(mode="dynamic", pd_kp=400.0, pd_kd=40.0, pd_inertia_scaled=True, max_episode_steps=7, auto_reset=True)
+    env = PioneerKinematicEnv(engine_config=eng)
+    assert env._vec.engine_config.mode == "dynamic" and env._vec.engine_config.max_episode_steps == 0
+    assert not env._vec.engine_config.auto_reset and env._vec.engine_config.pd_inertia_scaled
+    env.seed(3)
+    env.reset_world(joint_positions=np.zeros(6), target_position=(20.0, 0.0, 4.0))
+    for _ in range(5):
+        obs, rew, done, info = env.step(np.zeros(6, np.float32))
+    assert np.abs(obs[0:6]).max() < 1e-6                                  # q stays at rest
+    a = np.array([0.5, 0.2, -0.2, 0.3, 0.2, -0.3], np.float32) * env.a_max
+    for k in range(20):
+        obs, rew, done, info = env.step(a if k < 3 else np.zeros(6, np.float32))
+    q = env._vec.get_dyn_state()[0:6, 0].cpu().numpy()
+    assert np.abs(q).max() > 0.01                                          # it moved
+    v_cmd = env.v                                                          # the command keeps drifting at v; q follows r closely
+    assert np.abs(q - env.r).max() < 0.05 + 0.1 * np.abs(v_cmd).max()
+    env2 = pickle.loads(pickle.dumps(env))
+    assert env2._vec.engine_config.pd_inertia_scaled and env2._vec.engine_config.mode == "dynamic"
+    env.close(); env2.close()
