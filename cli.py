@@ -63,8 +63,12 @@ def main(argv=None) -> int:
     if args.command == "pioneer-eval":
         import json
         from pioneer_amd.evaluate import evaluate
+        eng = None
+        if args.mode == "dynamic":        # the launcher's dynamics-mode default: the inertia-scaled motor
+            from pioneer_amd import EngineConfig
+            eng = EngineConfig(mode="dynamic", pd_kp=400.0, pd_kd=40.0, pd_inertia_scaled=True)
         res = evaluate(args.checkpoint, args.episodes, args.max_steps, args.gif, mode=args.mode,
-                       deterministic=not args.stochastic, frame_stride=2)
+                       deterministic=not args.stochastic, frame_stride=2, engine_config=eng)
         print(json.dumps(res))
         return 0
     from pioneer_amd.launch import RESULT_COLUMNS, dump, train

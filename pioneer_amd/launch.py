@@ -40,8 +40,17 @@ def train(results_dir: str,
           mode: str = "kinematic",
           log_every: int = 10,
           use_graph: bool = True,
-          monitor_steps: int = 500):
+          monitor_steps: int = 500,
+          engine_config: Optional[EngineConfig] = None):
     """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list."""
+    # the engine's own options: as given, or — dynamics mode — the inertia-scaled motor (omega = 20 rad/s, zeta = 1 on every
+    # joint: with plain torque gains PPO does not learn the task, DESIGN.md section 6); TimeLimit(500) and auto-reset as
+    # the reference's prepare_env wraps it (pioneer_knm_train.py:27)
+    import dataclasses
+    engine = engine_config or (EngineConfig(mode="dynamic", pd_kp=400.0, pd_kd=40.0, pd_inertia_scaled=True) if mode == "dynamic"
+                               else EngineConfig())
+    engine = dataclasses.replace(engine, max_episode_steps=500, auto_reset=True)
+    mode = engine.mode
     rank, local_rank, world = pdist.world_info()
     if os.environ.get("PNR_DIST_BACKEND") == "gloo":        # rehearsal: ranks may share the visible GPUs
         local_rank %= max(1, torch.cuda.device_count())
@@ -76,7 +85,7 @@ def train(results_dir: str,
             penalty_step=float(ENV_CONFIG["penalty_step"]))
         env = PioneerVectorEnv(count, device=device, seed=cfg.seed, env_id_offset=start,
                                pioneer_config=pioneer_config,
-                               engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=mode))
+                               engine_config=engine)
         trainer = PPOTrainer(env, cfg, use_graph=use_graph)   # hipGraph-captured sampling and updates
         last = {}
         # the files Tune leaves in a trial directory: params.json, result.json (one line per iteration), progress.csv,
@@ -106,9 +115,9 @@ def train(results_dir: str,
                           f"len {last['episode_len_mean']:.1f} steps/s {last['env_steps_per_s']:.3g}", flush=True)
             if checkpoint_freq and it % checkpoint_freq == 0:
                 ck = trainer.save(os.path.join(tdir, f"checkpoint_{it}.pt"))
-                _record(monitor and rank == 0, ck, os.path.join(tdir, f"monitor_{it}.gif"), device, mode, monitor_steps)
+                _record(monitor and rank == 0, ck, os.path.join(tdir, f"monitor_{it}.gif"), device, mode, monitor_steps, engine)
         ck = trainer.save(os.path.join(tdir, "checkpoint_final.pt"))      # checkpoint_at_end=True, :73
-        _record(monitor and rank == 0, ck, os.path.join(tdir, "monitor_final.gif"), device, mode, monitor_steps)
+        _record(monitor and rank == 0, ck, os.path.join(tdir, "monitor_final.gif"), device, mode, monitor_steps, engine)
         if log:
             log.close()
         if csv_log:
@@ -124,7 +133,7 @@ def train(results_dir: str,
         return rows
 
 
-def _record(enabled: bool, checkpoint: str, gif_path: str, device, mode: str, max_steps: int) -> None:
+def _record(enabled: bool, checkpoint: str, gif_path: str, device, mode: str, max_steps: int, engine_config=None) -> None:
     """RLlib's 'monitor': True (pioneer_knm_train.py:51) records episodes as videos into the results directory; here one
     evaluation episode of the checkpointed policy is written as a GIF next to each checkpoint."""
     if not enabled:
@@ -132,7 +141,7 @@ def _record(enabled: bool, checkpoint: str, gif_path: str, device, mode: str, ma
     try:
         from .evaluate import evaluate
         evaluate(checkpoint, episodes=1, max_episode_steps=max_steps, gif_path=gif_path, device=device, mode=mode,
-                 frame_stride=4)
+                 frame_stride=4, engine_config=engine_config)
     except Exception as exc:          # a recording problem must not end a training run
         print(f"monitor: recording {gif_path} failed: {type(exc).__name__}: {exc}", flush=True)
 
