@@ -162,6 +162,28 @@ def cpu_baseline(n_envs, seconds):
             best, best_t = c, t
     k = max(5, min(20000, int(seconds / max(best_t, 1e-6))))
     dt = run(k, best)
+    # SURVEY 8(d) baseline (ii): the same oracle on ONE thread, 4 096 envs, median of five short runs
+    single = None
+    try:
+        n1 = 4096
+        o1 = COracle(n1, seed=0, precision=ORC_REF, auto_reset=True, nthreads=1)
+        o1.reset(want_obs=False)
+        a1 = (rng.uniform(-1, 1, size=(n1, 6)) * o1.a_max).astype(np.float32)
+        ob1 = np.empty((n1, 137)); rw1 = np.empty(n1); dn1 = np.empty(n1, np.uint8); tr1 = np.empty(n1, np.uint8)
+
+        def run1(k):
+            t0 = time.perf_counter()
+            for _ in range(k):
+                o1.lib.orc_step_batch(C_.byref(o1.p), o1._sp(), C_.c_int64(n1), C_.c_int64(0), _ptr(a1, C_.c_float),
+                                      _ptr(ob1, C_.c_double), _ptr(rw1, C_.c_double), _ptr(dn1, C_.c_uint8), _ptr(tr1, C_.c_uint8),
+                                      None, C_.c_int(1))
+            return time.perf_counter() - t0
+        t1 = run1(2) / 2
+        k1 = max(2, int(0.4 / max(t1, 1e-6)))
+        rates = sorted(n1 * k1 / run1(k1) for _ in range(5))
+        single = {"value": rates[2], "unit": "env-steps/s", "cores": 1, "sample": f"{n1} envs x {k1} steps, median of 5 runs"}
+    except Exception as exc:
+        single = {"error": f"{type(exc).__name__}: {exc}"}
     # BASELINE.md plan B1: PyBullet single-process replay, only if pybullet exists on this host
     try:
         pyb = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pybullet_replay.py"),
@@ -169,7 +191,7 @@ def cpu_baseline(n_envs, seconds):
                                         timeout=120).stdout.strip().splitlines()[-1])
     except Exception as exc:                       # never fabricate a number
         pyb = {"pybullet": f"replay failed: {type(exc).__name__}"}
-    return {"pybullet_single_process": pyb, "value": n * k / dt, "unit": "env-steps/s", "cores": best, "kind": "port",
+    return {"pybullet_single_process": pyb, "single_thread": single, "value": n * k / dt, "unit": "env-steps/s", "cores": best, "kind": "port",
             "sample": f"{n} envs x {k} steps, float64 C oracle (oracle/pnr_oracle.c), OpenMP over envs, "
                       f"{best} threads (host advertises {os.cpu_count()}), {dt:.1f} s"}
 
