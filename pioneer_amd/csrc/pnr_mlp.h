@@ -687,7 +687,9 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
 // x 2 nets = 640 workgroups are 2.5 rounds of the 256 CUs instead of 2, 41 -> 45-50 us; db2 moved from part 3 into part 0
 // (one read of dZ2 less, 64 more accumulator registers): 35.0 -> 35.0 us; two chunks in flight per workgroup in parts 0 / 1
 // (48 more registers): 37.3 us, in parts 0 / 1 / 3: 37.6 us, in every part (part 2's 160 accumulator registers + two chunk
-// sets: 52 B of scratch): 60 us.  The kernel is bound neither by its byte count nor by the depth of its prefetch.
+// sets: 52 B of scratch): 60 us; five roles (dW1 as two row halves, 80 accumulator registers) x 25 slices with two chunks in
+// flight everywhere, no scratch: 47.4 us = the 28 % more rows per workgroup.  A workgroup costs ~2.2 us per 64-sample chunk
+// whatever its role and prefetch depth; the kernel is bound neither by its byte count nor by the depth of its prefetch.
 // ---------------------------------------------------------------------------------------------------------------
 struct MlpWgradParams {
     const float* g_head;       // [2][B][16]
