@@ -372,7 +372,20 @@ typedef struct pnr_mlp_step {
     float* partials; int64_t partial_rows; float* slabs; int64_t slab_floats;
     float* means;
     float* flat_grad;
+    const void* xs_in;      /* optional [batch][144] bf16: the nets' input already gathered, filtered and rounded by
+                             * pnr_mlp_gather.  Then obs / idx / the filter vectors are not read, the record arrays (actions ..
+                             * value_old) are read row by row, and `xs` is not written */
 } pnr_mlp_step;
+/*
+ * An SGD epoch's shuffle applied once: row i of every output is row idx[i] of the corresponding input — the observation
+ * filtered and rounded to the nets' input layout (xs_out [batch][144] bf16) and the rollout record — so that the epoch's
+ * minibatch updates read contiguous rows (pnr_mlp_step.xs_in = xs_out + 144 * first_row, record pointers likewise).
+ */
+int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo,
+                   const float* f_hi, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
+                   const float* adv, const float* value_target, const float* value_old, void* xs_out, float* actions_out,
+                   float* logp_out, float* mean_out, float* log_std_out, float* adv_out, float* value_target_out,
+                   float* value_old_out, void* stream);
 int64_t pnr_mlp_grad_floats(void);
 int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream);
 int pnr_mlp_adam(const pnr_mlp_step* s, const float* flat_grad, float grad_scale, void* stream);

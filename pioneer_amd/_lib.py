@@ -98,7 +98,7 @@ class PnrMlpStep(C.Structure):
         ("head", C.c_void_p), ("g_head", C.c_void_p), ("xs", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p),
         ("dz1", C.c_void_p), ("dz2", C.c_void_p),
         ("partials", C.c_void_p), ("partial_rows", C.c_int64), ("slabs", C.c_void_p), ("slab_floats", C.c_int64),
-        ("means", C.c_void_p), ("flat_grad", C.c_void_p),
+        ("means", C.c_void_p), ("flat_grad", C.c_void_p), ("xs_in", C.c_void_p),
     ]
 
 
@@ -134,6 +134,7 @@ SIGNATURES = {
     "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 16),
     "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "pnr_mlp_grad_floats": (C.c_int64, []),
+    "pnr_mlp_gather": (C.c_int, [C.c_int64] + [_VP] * 22),
     "pnr_mlp_train_step": (C.c_int, [C.POINTER(PnrMlpStep), _VP]),
     "pnr_mlp_adam": (C.c_int, [C.POINTER(PnrMlpStep), _VP, C.c_float, _VP]),
     "pnr_num_envs": (C.c_int64, [_VP]),

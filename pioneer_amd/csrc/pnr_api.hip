@@ -1404,12 +1404,34 @@ static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices
     hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, kMlpNets), dim3(256), 0, st, A);
 }
 
+int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo,
+                   const float* f_hi, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
+                   const float* adv, const float* value_target, const float* value_old, void* xs_out, float* actions_out,
+                   float* logp_out, float* mean_out, float* log_std_out, float* adv_out, float* value_target_out,
+                   float* value_old_out, void* stream)
+{
+    if (batch < 1 || !obs || !actions || !logp_old || !mean_old || !log_std_old || !adv || !value_target || !value_old || !xs_out ||
+        !actions_out || !logp_out || !mean_out || !log_std_out || !adv_out || !value_target_out || !value_old_out)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_gather: null argument or empty batch");
+    if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_gather: the four filter vectors come together or not at all");
+    MlpGatherParams G;
+    G.obs = obs; G.idx = reinterpret_cast<const long long*>(idx); G.f_loc = f_loc; G.f_inv = f_inv; G.f_lo = f_lo; G.f_hi = f_hi;
+    G.actions = actions; G.logp = logp_old; G.mean = mean_old; G.log_std = log_std_old; G.adv = adv; G.vtarg = value_target;
+    G.values = value_old; G.xs_out = static_cast<__bf16*>(xs_out); G.actions_out = actions_out; G.logp_out = logp_out;
+    G.mean_out = mean_out; G.log_std_out = log_std_out; G.adv_out = adv_out; G.vtarg_out = value_target_out; G.values_out = value_old_out;
+    G.B = batch;
+    hipLaunchKernelGGL(mlp_gather_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(kMlpThreads), 0, (hipStream_t)stream, G);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
 int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
 {
     int rc = mlp_step_check(s, "pnr_mlp_train_step");
     if (rc) return rc;
     const long long B = s->batch;
-    if (B < 1 || !s->obs || !s->actions || !s->logp_old || !s->mean_old || !s->log_std_old || !s->adv || !s->value_target ||
+    if (B < 1 || (!s->obs && !s->xs_in) || !s->actions || !s->logp_old || !s->mean_old || !s->log_std_old || !s->adv || !s->value_target ||
         !s->value_old || !s->kl_coeff || !s->entropy_coeff || !s->head || !s->g_head || !s->xs || !s->h1 || !s->h2 || !s->dz1 ||
         !s->dz2 || !s->partials || !s->slabs || !s->means)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: null argument or empty batch");
@@ -1431,7 +1453,9 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     MlpFwdParams F = {};
     F.obs = s->obs; F.idx = reinterpret_cast<const long long*>(s->idx); F.f_loc = s->f_loc; F.f_inv = s->f_inv; F.f_lo = s->f_lo; F.f_hi = s->f_hi;
     F.wpack = static_cast<const __bf16*>(s->wpack); F.bias = s->bias; F.head = nullptr;
-    F.xs = static_cast<__bf16*>(s->xs); F.h1 = static_cast<__bf16*>(s->h1); F.h2 = static_cast<__bf16*>(s->h2);
+    F.xs_in = static_cast<const __bf16*>(s->xs_in);
+    if (F.xs_in) { F.idx = nullptr; F.f_loc = F.f_inv = F.f_lo = F.f_hi = nullptr; }       // everything was applied by pnr_mlp_gather
+    F.xs = F.xs_in ? nullptr : static_cast<__bf16*>(s->xs); F.h1 = static_cast<__bf16*>(s->h1); F.h2 = static_cast<__bf16*>(s->h2);
     F.B = B; F.first_net = 0; F.n_nets = kMlpNets;
     F.rec_actions = s->actions; F.rec_logp = s->logp_old; F.rec_mean = s->mean_old; F.rec_log_std = s->log_std_old;
     F.rec_adv = s->adv; F.rec_vtarg = s->value_target; F.rec_values = s->value_old;
@@ -1444,7 +1468,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
         hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
                            s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
     MlpWgradParams Wp;
-    Wp.g_head = s->g_head; Wp.xs = F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
+    Wp.g_head = s->g_head; Wp.xs = F.xs_in ? F.xs_in : F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
     Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows;
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), thr, 0, st, Wp);
     if (s->flat_grad)

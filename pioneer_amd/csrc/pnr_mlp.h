@@ -235,6 +235,8 @@ __device__ __forceinline__ void mlp_load_htile(__bf16* tile, const __bf16* __res
 struct MlpFwdParams {
     const float* obs;          // [rows][137] float32 observations (raw when the filter vectors are given)
     const long long* idx;      // [B] row of `obs` for sample b (minibatch gather), or null: row b
+    const __bf16* xs_in;       // [B][144] the nets' input ALREADY filtered and rounded (mlp_gather_kernel: an epoch's shuffle applied
+                               // once), or null: stage 0 makes it from obs / idx / the filter vectors
     const float* f_loc;        // [137] MeanStdFilter vectors of PPOTrainer.filter.prepare(), or null (identity):
     const float* f_inv;        //   x = clamp((obs - loc) * inv, lo, hi)
     const float* f_lo;
@@ -294,6 +296,14 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     // ---- stage 0: the tile's observations, filtered, as bf16 pairs [128][144] (columns 137.. zero)
     {
         float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
+        if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy
+            for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kMlpThreads) {
+                const int row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (row0 + row < P.B) v = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
+                *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = v;
+            }
+        } else {
         if (P.f_loc) {
             for (int i = tid; i < 4 * kMlpInPad; i += kMlpThreads) {
                 const int which = i / kMlpInPad, k = i % kMlpInPad;
@@ -339,6 +349,7 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
                 for (int k = 0; k < 4; ++k) pk[k] = (__bf16)((live && col + k < kMlpIn) ? x[k] : 0.f);
                 *reinterpret_cast<bf16x4*>(xt + row * kXS + col) = pk;
             }
+        }
         }
         __syncthreads();
         if (P.xs && net == 0) {                                   // the input is the same for both nets: saved once
@@ -577,6 +588,80 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
         __syncthreads();
         mlp_store_htile(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// An SGD epoch's shuffle applied ONCE: row i of the outputs is row idx[i] of the rollout — the observation filtered and
+// rounded exactly as stage 0 above does it ([B][144] bf16, columns 137.. zero) and the rollout record (22 floats).  The
+// epoch's 16 minibatch updates then read contiguous rows (mlp_forward_kernel's xs_in path: a plain 18 KB copy per tile
+// instead of 64 scattered 548-byte rows and the filter arithmetic, no idx gather in the loss, and no `xs` store: the
+// weight-gradient kernel reads these rows directly).  One block = 64 samples, four threads per row, like stage 0.
+// ---------------------------------------------------------------------------------------------------------------
+struct MlpGatherParams {
+    const float* obs; const long long* idx;
+    const float* f_loc; const float* f_inv; const float* f_lo; const float* f_hi;     // all four or none
+    const float* actions; const float* logp; const float* mean; const float* log_std;
+    const float* adv; const float* vtarg; const float* values;
+    __bf16* xs_out;            // [B][144]
+    float* actions_out; float* logp_out; float* mean_out; float* log_std_out; float* adv_out; float* vtarg_out; float* values_out;
+    long long B;
+};
+
+__global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGatherParams P)
+{
+    __shared__ __attribute__((aligned(16))) float fv[4 * kMlpInPad];
+    const int tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * 64;
+    if (P.f_loc) {
+        for (int i = tid; i < 4 * kMlpInPad; i += kMlpThreads) {
+            const int which = i / kMlpInPad, k = i % kMlpInPad;
+            const float* src = which == 0 ? P.f_loc : (which == 1 ? P.f_inv : (which == 2 ? P.f_lo : P.f_hi));
+            fv[i] = k < kMlpIn ? src[k] : 0.f;
+        }
+    }
+    __syncthreads();
+    constexpr int TPR = kMlpThreads / 64, CPT = kMlpInPad / TPR, NV = CPT / 4;
+    const int row = tid / TPR, part = tid % TPR;
+    const long long b = row0 + row;
+    if (b >= P.B) return;
+    const long long r = P.idx ? P.idx[b] : b;
+    const float* src = P.obs + r * kMlpIn + CPT * part;
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    f32x4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = CPT * part + 4 * j;
+        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (col + 3 < kMlpIn) v[j] = *reinterpret_cast<const f32x4u*>(src + 4 * j);
+        else if (col < kMlpIn) v[j][0] = src[4 * j];
+    }
+    float recv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};             // this thread's share of the record: part 0 actions, 1 mean, 2 log_std
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};                         // part 3: logp, adv, vtarg, values
+    if (part < 3) {
+        const float* a = (part == 0 ? P.actions : (part == 1 ? P.mean : P.log_std)) + r * 6;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) recv[j] = a[j];
+    } else { sc[0] = P.logp[r]; sc[1] = P.adv[r]; sc[2] = P.vtarg[r]; sc[3] = P.values[r]; }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int col = CPT * part + 4 * j;
+        f32x4 x = v[j];
+        if (P.f_loc) {
+            const f32x4 loc = *reinterpret_cast<const f32x4*>(fv + col), inv = *reinterpret_cast<const f32x4*>(fv + kMlpInPad + col);
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(fv + 2 * kMlpInPad + col), hi = *reinterpret_cast<const f32x4*>(fv + 3 * kMlpInPad + col);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = fminf(fmaxf((x[k] - loc[k]) * inv[k], lo[k]), hi[k]);
+        }
+        bf16x4 pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = (__bf16)((col + k < kMlpIn) ? x[k] : 0.f);
+        *reinterpret_cast<bf16x4*>(P.xs_out + b * kMlpInPad + col) = pk;
+    }
+    if (part < 3) {
+        float* o = (part == 0 ? P.actions_out : (part == 1 ? P.mean_out : P.log_std_out)) + b * 6;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o[j] = recv[j];
+    } else { P.logp_out[b] = sc[0]; P.adv_out[b] = sc[1]; P.vtarg_out[b] = sc[2]; P.values_out[b] = sc[3]; }
 }
 
 struct MlpBwdParams {

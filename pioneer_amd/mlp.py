@@ -163,25 +163,60 @@ class HipMLP:
         s.lr, s.beta1, s.beta2, s.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
         return s
 
+    REC_KEYS = ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values")
+
+    def gather_epoch(self, obs, idx, filt, rec) -> dict:
+        """An SGD epoch's shuffle applied ONCE (pnr_mlp_gather): returns {"xs": bf16 [n, 144] — the filtered, rounded net
+        inputs of rows ``idx`` —, and the record fields gathered the same way}.  Slices of it feed ``train_step(xs_in=...)``.
+        The buffers live in this object and are overwritten by the next call."""
+        self._check_inputs(obs, idx, filt, self.device)
+        n = int(idx.numel())
+        g = getattr(self, "_gathered", None)
+        if g is None or g["xs"].shape[0] < n:
+            f32 = dict(dtype=torch.float32, device=self.device)
+            g = {"xs": torch.empty((n, 144), dtype=torch.bfloat16, device=self.device)}
+            for k in self.REC_KEYS:
+                g[k] = torch.empty((n, 6) if k in ("actions", "mean", "log_std") else (n,), **f32)
+            self._gathered = g
+        f = filt if filt is not None else (None, None, None, None)
+        R = obs.shape[0]
+        for k in self.REC_KEYS:
+            v = rec[k]
+            assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
+        _lib.check(self.lib.pnr_mlp_gather(n, _p(idx), _p(obs), _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]),
+                                           *[_p(rec[k]) for k in self.REC_KEYS], _p(g["xs"]), *[_p(g[k]) for k in self.REC_KEYS],
+                                           self._stream()))
+        return {k: v[:n] for k, v in g.items()}
+
     def train_step(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float, means_out: torch.Tensor,
-                   lr: float, betas=(0.9, 0.999), eps: float = 1e-8, flat_grad: Optional[torch.Tensor] = None) -> None:
+                   lr: float, betas=(0.9, 0.999), eps: float = 1e-8, flat_grad: Optional[torch.Tensor] = None,
+                   xs_in: Optional[torch.Tensor] = None) -> None:
         """Forward, loss, backward and — unless ``flat_grad`` is given — the Adam update of the float32 master
         parameters plus the refresh of the packed bf16 weights, all on the device (pnr_mlp_train_step).  With
         ``flat_grad`` ([pnr_mlp_grad_floats()]) the reduced gradient lands there instead and nothing is updated: all-reduce
         it and call ``adam(flat_grad, 1 / world)``.  ``pack()`` must have run once after the parameters last changed
         behind this object's back (construction, restore)."""
-        self._check_inputs(obs, idx, filt, self.device)
-        B = int(idx.numel()) if idx is not None else int(obs.shape[0])
+        if xs_in is not None:
+            # the epoch's pre-gathered rows (gather_epoch): inputs and record are read row by row, nothing is filtered
+            assert xs_in.dtype == torch.bfloat16 and xs_in.is_contiguous() and xs_in.shape[1] == 144 and xs_in.device == self.device
+            assert obs is None and idx is None and filt is None
+            B = R = int(xs_in.shape[0])
+        else:
+            self._check_inputs(obs, idx, filt, self.device)
+            B = int(idx.numel()) if idx is not None else int(obs.shape[0])
+            R = obs.shape[0]
         self._batch_of_ws(B)
         ws = self._workspace()
-        R = obs.shape[0]
         for k in ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values"):
             v = rec[k]
             assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
         assert means_out.dtype == torch.float32 and means_out.numel() >= 8 and means_out.is_contiguous()
         s = self._step_args(lr, betas, eps)
         s.batch = B
-        s.obs, s.idx = obs.data_ptr(), (idx.data_ptr() if idx is not None else None)
+        if xs_in is not None:
+            s.xs_in = xs_in.data_ptr()
+        else:
+            s.obs, s.idx = obs.data_ptr(), (idx.data_ptr() if idx is not None else None)
         if filt is not None:
             s.f_loc, s.f_inv, s.f_lo, s.f_hi = (t.data_ptr() for t in filt)
         s.actions, s.logp_old, s.mean_old, s.log_std_old = (rec[k].data_ptr() for k in ("actions", "logp", "mean", "log_std"))

@@ -793,9 +793,12 @@ class PPOLearner:
             # each epoch's shuffle: pnr_permutation keyed by (seed, rank, epoch counter) — one launch, no sort
             perm = hip_permutation(B, cfg.seed * 1000003 + (pdist.dist.get_rank() if multi else 0), self._epochs, self._perm)
             self._epochs += 1
+            # ... applied once per epoch (pnr_mlp_gather): the 16 updates then read contiguous rows
+            g = mlp.gather_epoch(rec["obs"], perm, filt, rec)
             for s in range(0, B - mbs + 1, mbs):
-                mlp.train_step(rec["obs"], perm[s:s + mbs], filt, rec, self._kl_c, self._ent_c, cfg.clip_param, cfg.vf_clip_param,
-                               cfg.vf_loss_coeff, self._means[k], cfg.lr, flat_grad=self._flat_grad if multi else None)
+                mlp.train_step(None, None, None, {k: g[k][s:s + mbs] for k in mlp.REC_KEYS}, self._kl_c, self._ent_c, cfg.clip_param,
+                               cfg.vf_clip_param, cfg.vf_loss_coeff, self._means[k], cfg.lr,
+                               flat_grad=self._flat_grad if multi else None, xs_in=g["xs"][s:s + mbs])
                 if multi:
                     pdist.allreduce_sum_(self._flat_grad)          # the one 0.86 MB bucket
                     mlp.adam(self._flat_grad, 1.0 / world, cfg.lr)

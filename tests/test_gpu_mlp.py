@@ -252,3 +252,36 @@ def test_train_step_equals_autograd_plus_torch_adam(B):
     w_now = mlp.wpack.clone(); b_now = mlp.bias.clone()
     mlp.pack()
     assert torch.equal(w_now, mlp.wpack) and torch.equal(b_now, mlp.bias)         # the refreshed bf16 copies are exact
+
+
+@pytest.mark.parametrize("B", [8192, 4099])
+def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
+    """pnr_mlp_gather + train_step(xs_in=...) against train_step(obs, idx, filt): the same filter arithmetic and rounding,
+    the same record rows, so gradients, loss means and updated weights are bit-identical — on a minibatch that is a slice
+    of a longer gathered epoch (pointer offsets into the gathered arrays)."""
+    import copy
+    from pioneer_amd.mlp import HipMLP
+    R, lr = 20000, 1e-3
+    model, mlp, obs, _, filt = make(B, seed=33, rows=R, with_filter=True)
+    dev = obs.device
+    rec = _record(R, dev)
+    klc = torch.tensor(0.2, device=dev); entc = torch.tensor(0.01, device=dev)
+    model_g = copy.deepcopy(model); mlp_g = HipMLP(model_g, B, dev)
+    mlp.pack(); mlp_g.pack()
+    g = torch.Generator(device=dev).manual_seed(5)
+    perm = torch.randperm(R, generator=g, device=dev)
+    gathered = mlp_g.gather_epoch(obs, perm, filt, rec)
+    assert torch.equal(gathered["actions"], rec["actions"][perm]) and torch.equal(gathered["adv"], rec["adv"][perm])
+    x = torch.clamp((obs[perm] - filt[0]) * filt[1], min=filt[2], max=filt[3]).to(torch.bfloat16)
+    assert torch.equal(gathered["xs"][:, :137], x) and float(gathered["xs"][:, 137:].float().abs().max()) == 0.0
+    means = torch.zeros(2, 8, device=dev); means_g = torch.zeros(2, 8, device=dev)
+    flat = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), device=dev); flat_g = torch.zeros_like(flat)
+    for it, s0 in enumerate((0, R - B)):                       # the first and the last B rows of the epoch
+        idx = perm[s0:s0 + B].contiguous()
+        mlp.train_step(obs, idx, filt, rec, klc, entc, 0.3, 10.0, 1.0, means[it], lr, flat_grad=flat)
+        mlp_g.train_step(None, None, None, {k: gathered[k][s0:s0 + B] for k in mlp_g.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means_g[it], lr,
+                         flat_grad=flat_g, xs_in=gathered["xs"][s0:s0 + B])
+        assert torch.equal(flat, flat_g) and torch.equal(means[it], means_g[it])
+        mlp.adam(flat, 1.0, lr); mlp_g.adam(flat_g, 1.0, lr)
+    for a, b in zip(mlp.params, mlp_g.params):
+        assert torch.equal(a, b)
