@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--gravity", type=float, default=0.0, help="dynamics mode: gravity (reference default 0)")
     ap.add_argument("--ppo-iters", type=int, default=-1,
                     help="also time N iterations of the full rollout+learn PPO loop (BASELINE config[2]/[3]) and report it as "
-                         "\"ppo_loop\"; default 3 (0 in dynamics mode); at N>1 the gradients are all-reduced over RCCL")
+                         "\"ppo_loop\"; default 10 (0 in dynamics mode); at N>1 the gradients are all-reduced over RCCL")
     ap.add_argument("--ppo-envs", type=int, default=0,
                     help="TOTAL envs of the ppo_loop leg (0: 16 384 at N=1 = config[2]; 65 536 sharded over the ranks at N>1 = config[3])")
     ap.add_argument("--ppo-minibatch", type=int, default=32768, help="GLOBAL sgd_minibatch_size of the ppo_loop leg (SURVEY 8(d) config 3)")
@@ -593,7 +593,7 @@ def run_rank(args):
     ppo_loop = ppo_large = None
     rc = 0
     if args.ppo_iters < 0:
-        args.ppo_iters = 3 if args.mode == "kinematic" else 0
+        args.ppo_iters = 10 if args.mode == "kinematic" else 0      # ~90 ms of timed work per PPO leg
     if args.ppo_iters > 0:
         # the extra leg must never take the main result down: the line is still printed when it fails, but the
         # process then ends NON-ZERO — exceptions are reported in place (rc 5), and a leg that does not come back
