@@ -332,11 +332,13 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
  * action draw of RLlib's DiagGaussian (what the reference's PPO config samples with): log_std = clamp(raw, -20, 2),
  * actions = mean + exp(log_std) * noise (noise [batch][6] standard-normal draws supplied by the caller), env_actions =
  * clamp(actions, -a_max, a_max) (a_max [6]; the env's action space, pioneer_knm_env.py:60-61; NULL: no clipping and
- * env_actions is not written).  mean / log_std / actions / env_actions [batch][6], values [batch]; head [2][batch][16] or NULL.
+ * env_actions is not written).  mean / log_std / actions / env_actions [batch][6], values [batch]; head [2][batch][16] or NULL;
+ * xs_out [batch][144] bf16 or NULL: the nets' input as they saw it (filtered, rounded), which the learner's epoch gather
+ * (pnr_mlp_gather's xs_rows) copies instead of re-making it from the float32 observations.
  */
 int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
                 const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
-                float* log_std, float* values, float* actions, float* env_actions, void* stream);
+                float* log_std, float* values, float* actions, float* env_actions, void* xs_out, void* stream);
 int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
                      void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
                      int32_t n3_value, int32_t accumulate, const float* scale, void* stream);
@@ -380,12 +382,20 @@ typedef struct pnr_mlp_step {
  * An SGD epoch's shuffle applied once: row i of every output is row idx[i] of the corresponding input — the observation
  * filtered and rounded to the nets' input layout (xs_out [batch][144] bf16) and the rollout record — so that the epoch's
  * minibatch updates read contiguous rows (pnr_mlp_step.xs_in = xs_out + 144 * first_row, record pointers likewise).
+ * record_rows (optional): the same record as ONE row of 24 floats per sample, made once per iteration by
+ * pnr_ppo_pack_record (actions 0..5 | mean 6..11 | log_std 12..17 | logp, adv, value_target, value_old | 2 pad; adv
+ * standardised as (adv - *adv_mu) / *adv_den when the two device scalars are given): the gather then reads one or two cache
+ * lines per sample for the record instead of seven, and the seven input arrays may be NULL.  xs_rows (optional, [rows][144]
+ * bf16): the net inputs saved by pnr_mlp_act; then obs and the filter vectors are not read (288-byte rows instead of 548).
  */
+int pnr_ppo_pack_record(int64_t rows, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
+                        const float* adv, const float* value_target, const float* value_old, const float* adv_mu, const float* adv_den,
+                        float* record_rows, void* stream);
 int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo,
                    const float* f_hi, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
                    const float* adv, const float* value_target, const float* value_old, void* xs_out, float* actions_out,
                    float* logp_out, float* mean_out, float* log_std_out, float* adv_out, float* value_target_out,
-                   float* value_old_out, void* stream);
+                   float* value_old_out, const float* record_rows, const void* xs_rows, void* stream);
 int64_t pnr_mlp_grad_floats(void);
 int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream);
 int pnr_mlp_adam(const pnr_mlp_step* s, const float* flat_grad, float grad_scale, void* stream);

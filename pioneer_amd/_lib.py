@@ -131,10 +131,11 @@ SIGNATURES = {
     "pnr_filter_moments_scratch": (C.c_int64, [C.c_int64]),
     "pnr_filter_moments": (C.c_int, [C.c_int64, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "pnr_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _VP, _VP]),
-    "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 16),
+    "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 17),
     "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "pnr_mlp_grad_floats": (C.c_int64, []),
-    "pnr_mlp_gather": (C.c_int, [C.c_int64] + [_VP] * 22),
+    "pnr_ppo_pack_record": (C.c_int, [C.c_int64] + [_VP] * 11),
+    "pnr_mlp_gather": (C.c_int, [C.c_int64] + [_VP] * 24),
     "pnr_mlp_train_step": (C.c_int, [C.POINTER(PnrMlpStep), _VP]),
     "pnr_mlp_adam": (C.c_int, [C.POINTER(PnrMlpStep), _VP, C.c_float, _VP]),
     "pnr_num_envs": (C.c_int64, [_VP]),

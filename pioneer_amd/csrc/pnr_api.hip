@@ -1316,7 +1316,7 @@ int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, 
 
 int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
                 const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
-                float* log_std, float* values, float* actions, float* env_actions, void* stream)
+                float* log_std, float* values, float* actions, float* env_actions, void* xs_out, void* stream)
 {
     if (batch < 1 || !obs || !wpack || !bias || !noise || !mean || !log_std || !values || !actions)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: null argument or empty batch");
@@ -1330,6 +1330,7 @@ int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float
     P.B = batch; P.first_net = 0; P.n_nets = kMlpNets;
     P.noise = noise; P.a_max = a_max; P.mean = mean; P.log_std = log_std; P.values = values; P.actions = actions;
     P.env_actions = a_max ? env_actions : actions;
+    P.xs = static_cast<__bf16*>(xs_out);                     // the nets' input as they saw it, for the learner (or null)
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0,
                        (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
@@ -1404,13 +1405,30 @@ static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices
     hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, kMlpNets), dim3(256), 0, st, A);
 }
 
+int pnr_ppo_pack_record(int64_t rows, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
+                        const float* adv, const float* value_target, const float* value_old, const float* adv_mu, const float* adv_den,
+                        float* record_rows, void* stream)
+{
+    if (rows < 1 || !actions || !logp_old || !mean_old || !log_std_old || !adv || !value_target || !value_old || !record_rows)
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_pack_record: null argument or no rows");
+    if ((adv_mu == nullptr) != (adv_den == nullptr))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_pack_record: adv_mu and adv_den come together");
+    RecordPackParams R;
+    R.actions = actions; R.logp = logp_old; R.mean = mean_old; R.log_std = log_std_old; R.adv = adv; R.vtarg = value_target;
+    R.values = value_old; R.adv_mu = adv_mu; R.adv_den = adv_den; R.aos = record_rows; R.rows = rows;
+    hipLaunchKernelGGL(record_pack_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
 int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo,
                    const float* f_hi, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
                    const float* adv, const float* value_target, const float* value_old, void* xs_out, float* actions_out,
                    float* logp_out, float* mean_out, float* log_std_out, float* adv_out, float* value_target_out,
-                   float* value_old_out, void* stream)
+                   float* value_old_out, const float* record_rows, const void* xs_rows, void* stream)
 {
-    if (batch < 1 || !obs || !actions || !logp_old || !mean_old || !log_std_old || !adv || !value_target || !value_old || !xs_out ||
+    const bool soa = actions && logp_old && mean_old && log_std_old && adv && value_target && value_old;
+    if (batch < 1 || !(obs || xs_rows) || !(soa || record_rows) || !xs_out ||
         !actions_out || !logp_out || !mean_out || !log_std_out || !adv_out || !value_target_out || !value_old_out)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_gather: null argument or empty batch");
     if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
@@ -1418,7 +1436,7 @@ int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const fl
     MlpGatherParams G;
     G.obs = obs; G.idx = reinterpret_cast<const long long*>(idx); G.f_loc = f_loc; G.f_inv = f_inv; G.f_lo = f_lo; G.f_hi = f_hi;
     G.actions = actions; G.logp = logp_old; G.mean = mean_old; G.log_std = log_std_old; G.adv = adv; G.vtarg = value_target;
-    G.values = value_old; G.xs_out = static_cast<__bf16*>(xs_out); G.actions_out = actions_out; G.logp_out = logp_out;
+    G.values = value_old; G.rec_aos = record_rows; G.xs_src = static_cast<const __bf16*>(xs_rows); G.xs_out = static_cast<__bf16*>(xs_out); G.actions_out = actions_out; G.logp_out = logp_out;
     G.mean_out = mean_out; G.log_std_out = log_std_out; G.adv_out = adv_out; G.vtarg_out = value_target_out; G.values_out = value_old_out;
     G.B = batch;
     hipLaunchKernelGGL(mlp_gather_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(kMlpThreads), 0, (hipStream_t)stream, G);

@@ -597,11 +597,42 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
 // instead of 64 scattered 548-byte rows and the filter arithmetic, no idx gather in the loss, and no `xs` store: the
 // weight-gradient kernel reads these rows directly).  One block = 64 samples, four threads per row, like stage 0.
 // ---------------------------------------------------------------------------------------------------------------
+// The rollout record of one sample as one 96-byte row: actions 0..5 | mean 6..11 | log_std 12..17 | logp, adv, vtarg, value |
+// 2 pad.  Packed once per iteration (contiguous reads and writes), with the advantages standardised on the way
+// ((adv - mu) / den, PPO's batch standardisation, the same float32 operations as the element-wise form): the epoch
+// gathers then touch one or two cache lines per sample for the record instead of seven.
+constexpr int kRecAos = 24;
+struct RecordPackParams {
+    const float* actions; const float* logp; const float* mean; const float* log_std;
+    const float* adv; const float* vtarg; const float* values;
+    const float* adv_mu; const float* adv_den;      // device scalars, or null: advantages as they are
+    float* aos;                                     // [rows][24]
+    long long rows;
+};
+
+__global__ __launch_bounds__(256) void record_pack_kernel(const RecordPackParams P)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= P.rows) return;
+    float o[kRecAos];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { o[j] = P.actions[r * 6 + j]; o[6 + j] = P.mean[r * 6 + j]; o[12 + j] = P.log_std[r * 6 + j]; }
+    o[18] = P.logp[r];
+    const float a = P.adv[r];
+    o[19] = P.adv_mu ? __fdiv_rn(__fsub_rn(a, *P.adv_mu), *P.adv_den) : a;
+    o[20] = P.vtarg[r]; o[21] = P.values[r]; o[22] = 0.f; o[23] = 0.f;
+    f32x4* dst = reinterpret_cast<f32x4*>(P.aos + r * kRecAos);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dst[q] = (f32x4){o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+}
+
 struct MlpGatherParams {
     const float* obs; const long long* idx;
     const float* f_loc; const float* f_inv; const float* f_lo; const float* f_hi;     // all four or none
     const float* actions; const float* logp; const float* mean; const float* log_std;
     const float* adv; const float* vtarg; const float* values;
+    const float* rec_aos;      // [rows][24] the same record as ONE 96-byte row per sample (record_pack_kernel), or null: the seven arrays
+    const __bf16* xs_src;      // [rows][144] the nets' inputs as the sampler saw them (pnr_mlp_act's xs_out), or null: made from obs
     __bf16* xs_out;            // [B][144]
     float* actions_out; float* logp_out; float* mean_out; float* log_std_out; float* adv_out; float* vtarg_out; float* values_out;
     long long B;
@@ -625,6 +656,14 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGather
     const long long b = row0 + row;
     if (b >= P.B) return;
     const long long r = P.idx ? P.idx[b] : b;
+    if (P.xs_src) {     // a 288-byte row copied as 18 16-byte pieces (thread `part` takes pieces part, part + 4, ...): 3 lines, not 5
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int cc = part + TPR * j;
+            if (cc < kMlpInPad / 8)
+                *reinterpret_cast<uint4*>(P.xs_out + b * kMlpInPad + cc * 8) = *reinterpret_cast<const uint4*>(P.xs_src + r * kMlpInPad + cc * 8);
+        }
+    }
     const float* src = P.obs + r * kMlpIn + CPT * part;
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     f32x4 v[NV];
@@ -632,16 +671,24 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGather
     for (int j = 0; j < NV; ++j) {
         const int col = CPT * part + 4 * j;
         v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (P.xs_src) continue;
         if (col + 3 < kMlpIn) v[j] = *reinterpret_cast<const f32x4u*>(src + 4 * j);
         else if (col < kMlpIn) v[j][0] = src[4 * j];
     }
     float recv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};             // this thread's share of the record: part 0 actions, 1 mean, 2 log_std
     float sc[4] = {0.f, 0.f, 0.f, 0.f};                         // part 3: logp, adv, vtarg, values
-    if (part < 3) {
+    if (P.rec_aos) {                                            // the row's four threads read its 96 contiguous bytes
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2* a2 = reinterpret_cast<const f32x2*>(P.rec_aos + r * kRecAos + 6 * part);
+        const f32x2 x0 = a2[0], x1 = a2[1], x2 = a2[2];
+        if (part < 3) { recv[0] = x0[0]; recv[1] = x0[1]; recv[2] = x1[0]; recv[3] = x1[1]; recv[4] = x2[0]; recv[5] = x2[1]; }
+        else { sc[0] = x0[0]; sc[1] = x0[1]; sc[2] = x1[0]; sc[3] = x1[1]; }
+    } else if (part < 3) {
         const float* a = (part == 0 ? P.actions : (part == 1 ? P.mean : P.log_std)) + r * 6;
 #pragma unroll
         for (int j = 0; j < 6; ++j) recv[j] = a[j];
     } else { sc[0] = P.logp[r]; sc[1] = P.adv[r]; sc[2] = P.vtarg[r]; sc[3] = P.values[r]; }
+    if (!P.xs_src) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int col = CPT * part + 4 * j;
@@ -656,6 +703,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGather
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = (__bf16)((col + k < kMlpIn) ? x[k] : 0.f);
         *reinterpret_cast<bf16x4*>(P.xs_out + b * kMlpInPad + col) = pk;
+    }
     }
     if (part < 3) {
         float* o = (part == 0 ? P.actions_out : (part == 1 ? P.mean_out : P.log_std_out)) + b * 6;

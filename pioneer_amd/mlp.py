@@ -116,7 +116,7 @@ class HipMLP:
     @torch.no_grad()
     def act(self, obs: torch.Tensor, filt, noise: torch.Tensor, a_max: Optional[torch.Tensor], *, mean: torch.Tensor,
             log_std: torch.Tensor, values: torch.Tensor, actions: torch.Tensor, env_actions: Optional[torch.Tensor] = None,
-            head: Optional[torch.Tensor] = None) -> None:
+            head: Optional[torch.Tensor] = None, xs_out: Optional[torch.Tensor] = None) -> None:
         """One sampler step in ONE launch (pnr_mlp_act): both nets on ``obs`` [B, 137] and the DiagGaussian draw
         ``actions = mean + exp(clamp(log_std, -20, 2)) * noise`` in the policy net's epilogue; ``env_actions`` =
         ``actions`` clipped to +-``a_max`` (what the env is stepped with) when ``a_max`` is given."""
@@ -129,9 +129,10 @@ class HipMLP:
             if x is not None:
                 assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == shape and x.device == self.device, name
         assert (a_max is None) or (env_actions is not None and env_actions.data_ptr() != actions.data_ptr())
+        assert xs_out is None or (xs_out.dtype == torch.bfloat16 and xs_out.is_contiguous() and tuple(xs_out.shape) == (B, 144))
         _lib.check(self.lib.pnr_mlp_act(B, _p(obs), _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(self.wpack), _p(self.bias), _p(noise),
                                         _p(a_max), _p(head), _p(mean), _p(log_std), _p(values), _p(actions), _p(env_actions),
-                                        self._stream()))
+                                        _p(xs_out), self._stream()))
 
     # -- the learner path -------------------------------------------------------------------------------------
     def apply(self, obs: torch.Tensor, idx: Optional[torch.Tensor] = None, filt=None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -165,11 +166,32 @@ class HipMLP:
 
     REC_KEYS = ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values")
 
-    def gather_epoch(self, obs, idx, filt, rec) -> dict:
+    def pack_record(self, rec, adv_mu: Optional[torch.Tensor] = None, adv_den: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The rollout record as one 24-float row per sample (pnr_ppo_pack_record), advantages standardised as
+        (adv - adv_mu) / adv_den when the two float32 device scalars are given.  Feed it to ``gather_epoch(rec_rows=...)``."""
+        R = int(rec["actions"].shape[0])
+        for k in self.REC_KEYS:
+            v = rec[k]
+            assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
+        for x in (adv_mu, adv_den):
+            assert x is None or (x.dtype == torch.float32 and x.numel() == 1 and x.device == self.device)
+        if getattr(self, "_rec_rows", None) is None or self._rec_rows.shape[0] < R:
+            self._rec_rows = torch.empty((R, 24), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pnr_ppo_pack_record(R, *[_p(rec[k]) for k in self.REC_KEYS], _p(adv_mu), _p(adv_den), _p(self._rec_rows),
+                                                self._stream()))
+        return self._rec_rows[:R]
+
+    def gather_epoch(self, obs, idx, filt, rec, rec_rows: Optional[torch.Tensor] = None, xs_rows: Optional[torch.Tensor] = None) -> dict:
         """An SGD epoch's shuffle applied ONCE (pnr_mlp_gather): returns {"xs": bf16 [n, 144] — the filtered, rounded net
         inputs of rows ``idx`` —, and the record fields gathered the same way}.  Slices of it feed ``train_step(xs_in=...)``.
         The buffers live in this object and are overwritten by the next call."""
-        self._check_inputs(obs, idx, filt, self.device)
+        if xs_rows is not None:       # the sampler's saved net inputs (act(xs_out=...)): copied, nothing is filtered
+            assert xs_rows.dtype == torch.bfloat16 and xs_rows.is_contiguous() and xs_rows.shape[1] == 144 and xs_rows.device == self.device
+            assert idx.dtype == torch.int64 and idx.is_contiguous()
+            obs_p, R, filt = None, int(xs_rows.shape[0]), None
+        else:
+            self._check_inputs(obs, idx, filt, self.device)
+            obs_p, R = _p(obs), obs.shape[0]
         n = int(idx.numel())
         g = getattr(self, "_gathered", None)
         if g is None or g["xs"].shape[0] < n:
@@ -179,13 +201,16 @@ class HipMLP:
                 g[k] = torch.empty((n, 6) if k in ("actions", "mean", "log_std") else (n,), **f32)
             self._gathered = g
         f = filt if filt is not None else (None, None, None, None)
-        R = obs.shape[0]
-        for k in self.REC_KEYS:
-            v = rec[k]
-            assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
-        _lib.check(self.lib.pnr_mlp_gather(n, _p(idx), _p(obs), _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]),
-                                           *[_p(rec[k]) for k in self.REC_KEYS], _p(g["xs"]), *[_p(g[k]) for k in self.REC_KEYS],
-                                           self._stream()))
+        if rec_rows is not None:
+            assert rec_rows.dtype == torch.float32 and rec_rows.is_contiguous() and tuple(rec_rows.shape) == (R, 24) and rec_rows.device == self.device
+            src = [None] * len(self.REC_KEYS)
+        else:
+            for k in self.REC_KEYS:
+                v = rec[k]
+                assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
+            src = [_p(rec[k]) for k in self.REC_KEYS]
+        _lib.check(self.lib.pnr_mlp_gather(n, _p(idx), obs_p, _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), *src, _p(g["xs"]),
+                                           *[_p(g[k]) for k in self.REC_KEYS], _p(rec_rows), _p(xs_rows), self._stream()))
         return {k: v[:n] for k, v in g.items()}
 
     def train_step(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float, means_out: torch.Tensor,

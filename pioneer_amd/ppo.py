@@ -660,7 +660,10 @@ class PPOLearner:
         pdist.allreduce_sum_(stats)
         mu = stats[0] / stats[2]
         sd = torch.sqrt(torch.clamp(stats[1] / stats[2] - mu * mu, min=1e-12))
-        adv_n = (adv - mu.float()) / (sd.float() + 1e-8)
+        hip_path = self.hip and adv.is_cuda
+        # (the HIP path standardises while it packs the record, pnr_ppo_pack_record: the same two float32 operations)
+        adv_n = adv if hip_path else (adv - mu.float()) / (sd.float() + 1e-8)
+        self._adv_scalars = (mu.float().reshape(1), (sd.float() + 1e-8).reshape(1)) if hip_path else None
         self._kl_c.fill_(self.kl_coeff)
         self._ent_c.fill_(self.entropy_coeff())
         agg: Dict[str, torch.Tensor] = {}
@@ -788,13 +791,15 @@ class PPOLearner:
             self._flat_grad = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), dtype=torch.float32, device=dev)
         if self._perm is None or self._perm.numel() != B:
             self._perm = torch.empty(B, dtype=torch.int64, device=dev)
+        # the record as one 96-byte row per sample, advantages standardised on the way: once per iteration
+        rows = mlp.pack_record(rec, *(self._adv_scalars or (None, None)))
         k = 0
         for _ in range(cfg.num_sgd_iter):
             # each epoch's shuffle: pnr_permutation keyed by (seed, rank, epoch counter) — one launch, no sort
             perm = hip_permutation(B, cfg.seed * 1000003 + (pdist.dist.get_rank() if multi else 0), self._epochs, self._perm)
             self._epochs += 1
             # ... applied once per epoch (pnr_mlp_gather): the 16 updates then read contiguous rows
-            g = mlp.gather_epoch(rec["obs"], perm, filt, rec)
+            g = mlp.gather_epoch(rec["obs"], perm, filt, None, rec_rows=rows, xs_rows=rec.get("xs"))
             for s in range(0, B - mbs + 1, mbs):
                 mlp.train_step(None, None, None, {k: g[k][s:s + mbs] for k in mlp.REC_KEYS}, self._kl_c, self._ent_c, cfg.clip_param,
                                cfg.vf_clip_param, cfg.vf_loss_coeff, self._means[k], cfg.lr,
@@ -900,6 +905,8 @@ class PPOTrainer:
             self.sample_mlp = HipMLP(self.learner.model, N, self.device)   # packed weights for the rollout's T forwards
             self._last_heads = torch.empty((2, N, 16), **f32)
             self._last_v = torch.empty((N,), **f32)
+            # the nets' inputs as the sampler saw them (filtered, bf16): what the learner trains on, 288 bytes per sample
+            self.buf["xs"] = torch.empty((T, N, 144), dtype=torch.bfloat16, device=self.device)
             self._adv_stats = torch.zeros(3, dtype=torch.float64, device=self.device)     # sum, sum of squares, count (pnr_ppo_gae)
         else:
             self.buf["obs"] = torch.empty((T, N, D), **f32)            # filtered, what the nets saw
@@ -955,7 +962,8 @@ class PPOTrainer:
             clip = self.cfg.clip_actions
             for t in range(T):
                 mlp.act(self.raw_in[t], filt, noise[t], self.a_max if clip else None, mean=buf["mean"][t], log_std=buf["log_std"][t],
-                        values=buf["values"][t], actions=buf["actions"][t], env_actions=self._env_act if clip else None)
+                        values=buf["values"][t], actions=buf["actions"][t], env_actions=self._env_act if clip else None,
+                        xs_out=buf["xs"][t])
                 self.env.vector_step(self._env_act if clip else buf["actions"][t],
                                      out={"obs": self.raw_in[t + 1], "reward": buf["reward"][t], "done": buf["done"][t],
                                           "truncated": buf["trunc"][t]})
@@ -1021,6 +1029,7 @@ class PPOTrainer:
         if self.hip:
             batch.update(obs=flat(self.raw_in[:T]), filt=self._filt())      # raw: the kernels filter on load
             batch["adv_stats"] = self._adv_stats
+            batch["xs"] = flat(buf["xs"])
         else:
             batch["obs"] = flat(buf["obs"])
         return batch

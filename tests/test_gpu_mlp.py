@@ -134,10 +134,13 @@ def test_act_equals_the_torch_glue_on_the_same_heads(B, clip):
     out = {k: torch.full((B, 6), float("nan"), **f32) for k in ("mean", "log_std", "actions", "env_actions")}
     values = torch.full((B,), float("nan"), **f32)
     head2 = torch.full((2, B, 16), float("nan"), **f32)
+    xs = torch.full((B, 144), float("nan"), dtype=torch.bfloat16, device=dev)
     mlp.act(obs, filt, noise, a_max if clip else None, mean=out["mean"], log_std=out["log_std"], values=values,
-            actions=out["actions"], env_actions=out["env_actions"] if clip else None, head=head2)
+            actions=out["actions"], env_actions=out["env_actions"] if clip else None, head=head2, xs_out=xs)
     torch.cuda.synchronize()
     assert torch.equal(head2, heads)
+    # the saved net input: the filtered observation rounded to bf16, seven zero columns of padding
+    assert torch.equal(xs[:, :137], net_input(obs, None, filt).to(torch.bfloat16)) and float(xs[:, 137:].float().abs().max()) == 0.0
     mean, log_std = heads[0, :, :6], torch.clamp(heads[0, :, 6:12], -20.0, 2.0)
     assert torch.equal(out["mean"], mean) and torch.equal(out["log_std"], log_std) and torch.equal(values, heads[1, :, 0])
     act = torch.addcmul(mean, torch.exp(log_std), noise)
@@ -272,6 +275,19 @@ def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
     perm = torch.randperm(R, generator=g, device=dev)
     gathered = mlp_g.gather_epoch(obs, perm, filt, rec)
     assert torch.equal(gathered["actions"], rec["actions"][perm]) and torch.equal(gathered["adv"], rec["adv"][perm])
+    # the same through the packed 24-float rows (pnr_ppo_pack_record), also with the advantages standardised on the way
+    snap = {k: v.clone() for k, v in gathered.items()}
+    via_rows = mlp_g.gather_epoch(obs, perm, filt, None, rec_rows=mlp_g.pack_record(rec))
+    assert all(torch.equal(via_rows[k], snap[k]) for k in snap)
+    # ... and from the sampler's saved net inputs instead of the float32 observations
+    xs_all = torch.zeros(R, 144, dtype=torch.bfloat16, device=dev)
+    xs_all[:, :137] = torch.clamp((obs - filt[0]) * filt[1], min=filt[2], max=filt[3]).to(torch.bfloat16)
+    via_xs = mlp_g.gather_epoch(None, perm, None, None, rec_rows=mlp_g.pack_record(rec), xs_rows=xs_all)
+    assert all(torch.equal(via_xs[k], snap[k]) for k in snap)
+    mu = torch.tensor([0.3], device=dev); den = torch.tensor([1.7], device=dev)
+    std = mlp_g.gather_epoch(obs, perm, filt, None, rec_rows=mlp_g.pack_record(rec, mu, den))
+    assert torch.equal(std["adv"], ((rec["adv"] - mu) / den)[perm]) and torch.equal(std["vtarg"], rec["vtarg"][perm])
+    gathered = mlp_g.gather_epoch(obs, perm, filt, rec)
     x = torch.clamp((obs[perm] - filt[0]) * filt[1], min=filt[2], max=filt[3]).to(torch.bfloat16)
     assert torch.equal(gathered["xs"][:, :137], x) and float(gathered["xs"][:, 137:].float().abs().max()) == 0.0
     means = torch.zeros(2, 8, device=dev); means_g = torch.zeros(2, 8, device=dev)
