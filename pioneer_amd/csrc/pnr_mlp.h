@@ -94,9 +94,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LDS row strides (bf16 elements).  Tiles read with ds_read_b128 as the B operand: rows 16-byte aligned and
 // shifted 4 (12) dwords mod 64, conflict-free for the four 16-lane groups.  Tiles read with ds_read_b64_tr_b16:
 // rows shifted 16 dwords mod 64 (four rows x 16 dwords cover the 64 banks).
-constexpr int kXS = 152;          // [128][144] input tile
-constexpr int kHS = 264;          // [128][256] hidden tile
-constexpr int kGS = 24;           // [128][16] head-gradient tile
+constexpr int kXS = 152;          // row stride of the [BM][144] input tile
+constexpr int kHS = 264;          // row stride of the [BM][256] hidden tile
+constexpr int kGS = 24;           // row stride of the [BM][16] head-gradient tile
 constexpr int kTrH = 288;         // [64][256] tile for transposed reads (144 dwords = 16 mod 64)
 constexpr int kTrX = 160;         // [64][160] (80 dwords = 16 mod 64): 144 inputs, a column of ones, zeros
 constexpr int kTrHalf = 160;      // [64][128] half-width hidden tile (+32 pad)
@@ -149,7 +149,7 @@ __device__ __forceinline__ float tanh_fast(float x)
 
 __device__ __forceinline__ bf16x8 ld_global_bf16x8(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-// acc[rb][cb] += W[64 rows of this wave][K] . tile[128 samples][K]^T.  W: row-major, row stride K (global, L2);
+// acc[rb][cb] += W[64 rows of this wave][K] . tile[BM samples][K]^T.  W: fragment-native packing (global, L2);
 // tile: LDS, row stride STRIDE.
 template <int K, int STRIDE>
 __device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_blocks, const __bf16* tile, f32x16 (&acc)[2][kMlpCB], int lane)
@@ -211,7 +211,7 @@ __device__ __forceinline__ void mlp_bias_acc(f32x16 (&acc)[2][kMlpCB], const flo
         }
 }
 
-// copy a [128][256] bf16 tile between LDS (row stride kHS) and row-major global rows [row0, row0 + 128) of n_rows
+// copy a [BM][256] bf16 tile between LDS (row stride kHS) and row-major global rows [row0, row0 + BM) of n_rows
 __device__ __forceinline__ void mlp_store_htile(const __bf16* tile, __bf16* __restrict__ dst, long long row0, long long n_rows, int tid)
 {
 #pragma unroll
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
     }
 
-    // ---- stage 0: the tile's observations, filtered, as bf16 pairs [128][144] (columns 137.. zero)
+    // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero)
     {
         float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
         if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy
@@ -722,13 +722,13 @@ struct MlpBwdParams {
     long long B;
 };
 
-// Backward-data of one 128-sample tile: dZ2 = (G W3) * (1 - H2^2), dZ1 = (dZ2 W2) * (1 - H1^2).
+// Backward-data of one BM-sample tile: dZ2 = (G W3) * (1 - H2^2), dZ1 = (dZ2 W2) * (1 - H1^2).
 __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const MlpBwdParams P)
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * kMlpBM * kHS + kMlpBM * kGS];
     __bf16* ht = lds;                       // H2, then H1
     __bf16* dz = lds + kMlpBM * kHS;        // dZ2, then dZ1
-    __bf16* gt = lds + 2 * kMlpBM * kHS;    // head gradients as bf16 [128][16]
+    __bf16* gt = lds + 2 * kMlpBM * kHS;    // head gradients as bf16 [BM][16]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int net = blockIdx.y;
     const long long row0 = (long long)blockIdx.x * kMlpBM;
