@@ -16,8 +16,14 @@
 // row-major LDS tiles with ds_read_b64_tr_b16 (the hardware 4x16 transpose read), rows strided 16 dwords mod 64 so
 // that the transposed reads are bank-conflict-free.
 //
-// Roofline: MFMA (bf16 dense ~2.5 PFLOP/s).  Per sample and net: forward 106 496 MAC, backward-data 69 632 MAC,
-// weight gradients 110 592 MAC.  Not HBM-bound: activations cost 1-2.5 KB per sample per pass.
+// Work per sample and net: forward 106 496 MAC, backward-data 69 632 MAC, weight gradients 110 592 MAC.  These are
+// 256-wide layers on 137-float inputs: measured (profiles/r02_*) the kernels sit at 0.6-0.8 PFLOP/s
+// of the ~2.5 dense bf16 peak and 3-5 TB/s of HBM — bound by the chain of dependent products per tile and by the bytes
+// of the saved activations, not by the matrix cores.
+//
+// Kernels here: mlp_pack_kernel, mlp_forward_kernel<FUSED> (FUSED: + the tile's loss and backward-data), mlp_gather_kernel and
+// record_pack_kernel (an epoch's shuffle applied once), mlp_backward_data_kernel, mlp_wgrad_kernel, mlp_reduce_kernel,
+// mlp_reduce_flat_kernel, mlp_adam_kernel (+ the update's loss means).
 #pragma once
 
 #include <hip/hip_runtime.h>
