@@ -298,6 +298,10 @@ int64_t pnr_filter_moments_scratch(int64_t rows);
 int pnr_filter_moments(int64_t rows, const float* obs, const float* pivot, float* scratch, int64_t scratch_floats, double* dsum,
                        double* dsq, double* dn, void* stream);
 
+/* The filter's merge on one rank (MeanStdFilter.sync): the pending delta *dn, dsum / dsq [137] (zeroed on return) about
+ * pivot [137] into the running *n, mean / m2 [137] by Chan's update, float64, one launch. */
+int pnr_filter_merge(double* dn, double* dsum, double* dsq, const float* pivot, double* n, double* mean, double* m2, void* stream);
+
 /*
  * Host-driver helper: out[0..n) = a pseudo-random permutation of 0..n-1 keyed by (seed, stream_id) — a Feistel network
  * with cycle walking, one launch and no sort; the SGD epochs' minibatch shuffle (RLlib sgd.py shuffles each epoch).

@@ -1301,6 +1301,14 @@ int pnr_filter_moments(int64_t rows, const float* obs, const float* pivot, float
     return PNR_OK;
 }
 
+int pnr_filter_merge(double* dn, double* dsum, double* dsq, const float* pivot, double* n, double* mean, double* m2, void* stream)
+{
+    if (!dn || !dsum || !dsq || !pivot || !n || !mean || !m2) return fail(nullptr, PNR_ERR_INVALID, "pnr_filter_merge: null argument");
+    hipLaunchKernelGGL(filter_merge_kernel, dim3(1), dim3(kFmThreads), 0, (hipStream_t)stream, dn, dsum, dsq, pivot, n, mean, m2);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
 int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
 {
     if (n < 1 || !out) return fail(nullptr, PNR_ERR_INVALID, "pnr_permutation: null argument or n < 1");

@@ -483,4 +483,32 @@ __global__ __launch_bounds__(256) void filter_moments_finish_kernel(const float*
     }
 }
 
+// MeanStdFilter.sync() on ONE rank: the pending delta (dn, shifted sums about the pivot) merged into the running (n, mean,
+// m2) by Chan's update, column by column in float64 — the operations of the host formulation (ppo.py) one by one, so the
+// statistics are bit-identical to it; ~25 element-wise launches on 137-vectors become one.  (Several ranks: the host
+// formulation stays, its two all-reduces sit between the same steps.)
+__global__ __launch_bounds__(kFmThreads) void filter_merge_kernel(double* __restrict__ dn_p, double* __restrict__ dsum, double* __restrict__ dsq,
+                                                                 const float* __restrict__ pivot, double* __restrict__ n_p,
+                                                                 double* __restrict__ mean, double* __restrict__ m2)
+{
+    const int c = threadIdx.x;
+    const double dn_r = *dn_p, n = *n_p;
+    __syncthreads();                                   // every thread has read the scalars before thread 0 rewrites them
+    if (c < kFmCols) {
+        const double dn_r_safe = fmax(dn_r, 1.0);
+        const double mean_r = (double)pivot[c] + dsum[c] / dn_r_safe;
+        const double m2_r = fmax(dsq[c] - dsum[c] * dsum[c] / dn_r_safe, 0.0);
+        const double dn = dn_r, dn_safe = fmax(dn, 1.0);
+        const double bmean = (dn_r * mean_r) / dn_safe;
+        const double dev = mean_r - bmean;
+        const double bm2 = m2_r + dn_r * dev * dev;
+        const double tot = n + dn, tot_safe = fmax(tot, 1.0);
+        const double delta = bmean - mean[c];
+        m2[c] = m2[c] + (bm2 + delta * delta * (n * dn / tot_safe));
+        mean[c] = mean[c] + delta * (dn / tot_safe);
+        dsum[c] = 0.0; dsq[c] = 0.0;
+    }
+    if (c == 0) { *n_p = n + dn_r; *dn_p = 0.0; }
+}
+
 }  // namespace pnr

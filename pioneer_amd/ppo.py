@@ -123,6 +123,15 @@ class MeanStdFilter:
         """Merge the pending deltas of all ranks into the running statistics (Chan et al.).
         In place and without host synchronisation, so a captured hipGraph keeps seeing them."""
         d = self.mean.numel()
+        if self.mean.is_cuda and d == 137 and not pdist.is_dist():
+            # one rank: the same float64 operations in one launch (pnr_filter_merge), bit-identical to the formulation below
+            import ctypes
+            from . import _lib
+            _lib.check(_lib.load_library().pnr_filter_merge(_dp(self._dn), _dp(self._dsum), _dp(self._dsq), _dp(self._pivot), _dp(self.n),
+                                                            _dp(self.mean), _dp(self.m2),
+                                                            ctypes.c_void_p(torch.cuda.current_stream(self.mean.device).cuda_stream)))
+            self._pending = 0
+            return
         dn_r = self._dn
         dn_r_safe = torch.clamp(dn_r, min=1.0)
         mean_r = self._pivot.double() + self._dsum / dn_r_safe

@@ -369,3 +369,25 @@ def test_filter_moment_kernel_equals_the_float64_sums(rows):
     if rows > 1:
         assert torch.allclose(f.std, allx.std(0, unbiased=True), rtol=2e-5, atol=1e-9)
         assert bool((f.std[18:54] == 0).all())
+
+
+def test_filter_merge_kernel_equals_the_host_formulation_bit_for_bit(monkeypatch):
+    """MeanStdFilter.sync() through pnr_filter_merge against the element-wise float64 formulation on the same pending
+    deltas, over three syncs (first merge into empty statistics, then two more), constant columns included."""
+    from pioneer_amd import ppo
+    from pioneer_amd.ppo import MeanStdFilter
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    a, b = MeanStdFilter(137, dev), MeanStdFilter(137, dev)
+    for it in range(3):
+        x = torch.randn(4099, 137, generator=g, device=dev) * (it + 1) + 5.0 * it
+        x[:, 18:54] = 1.25
+        a.observe(x); b.observe(x)
+        a.sync()                                               # the kernel
+        monkeypatch.setattr(ppo.pdist, "is_dist", lambda: True)         # forces the host formulation (its all-reduces are no-ops on one rank)
+        monkeypatch.setattr(ppo.pdist, "allreduce_sum_", lambda t: t)
+        b.sync()
+        monkeypatch.undo()
+        assert torch.equal(a.n, b.n) and torch.equal(a.mean, b.mean) and torch.equal(a.m2, b.m2)
+        assert float(a._dn) == 0.0 and not bool(a._dsum.any()) and not bool(a._dsq.any())
+    assert bool((a.std[18:54] == 0).all())
