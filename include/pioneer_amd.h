@@ -27,7 +27,11 @@
 extern "C" {
 #endif
 
-#define PNR_ABI_VERSION 1
+/* Bumped whenever an exported signature or struct changes incompatibly; a caller checks pnr_abi_version() == the
+ * PNR_ABI_VERSION it was compiled against before any other call (pnr_config carries it too).
+ *   1  round 1
+ *   2  pnr_ppo_loss gained `idx` (argument 2) and `means` (before `stream`); pnr_config grew (guarded by struct_size) */
+#define PNR_ABI_VERSION 2
 
 #define PNR_DOF 6          /* revolute joints of pioneer_knm_6dof.urdf:209-264 */
 #define PNR_OBS_DIM 137    /* pioneer_knm_env.py:194-211 (26 pieces)         */

@@ -12,8 +12,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # PNR_LIB_PATH: load another build of the library (A/B experiments such as tools/build_variant.py's); default in-tree
 LIB_PATH = os.environ.get("PNR_LIB_PATH") or os.path.join(CSRC, "libpioneer_amd.so")
-SOURCES = ["pnr_api.hip", "pnr_device.h", "pnr_dyn.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h"]
+SOURCES = ["pnr_api.hip", "pnr_learn.hip", "pnr_host.h", "pnr_env_kernels.h", "pnr_device.h", "pnr_dyn.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pioneer_amd.h")
+
+
+
+def _header_abi_version() -> int:
+    """PNR_ABI_VERSION as include/pioneer_amd.h states it (the header is the single source)."""
+    import re
+    with open(HEADER) as f:
+        m = re.search(r"^#define\s+PNR_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise ImportError(f"{HEADER}: no PNR_ABI_VERSION")
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
 
 DOF = 6
 OBS_DIM = 137
@@ -144,32 +158,81 @@ SIGNATURES = {
 }
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+# the library's translation units and what each includes: a unit is recompiled when one of its files is newer than its object
+UNITS = {
+    "pnr_api.hip": ["pnr_api.hip", "pnr_host.h", "pnr_device.h", "pnr_model.h", "pnr_dyn.h", "pnr_env_kernels.h"],
+    "pnr_learn.hip": ["pnr_learn.hip", "pnr_host.h", "pnr_device.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h"],
+}
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16",      # leading scalar kernel args arrive preloaded in SGPRs
+               "-Wall", "-Wno-unused-function"]
+# the sources that define the env-side kernels (what the counter passes under profiles/ were taken on)
+ENV_KERNEL_SOURCES = ["pnr_env_kernels.h", "pnr_device.h", "pnr_model.h", "pnr_dyn.h"]
+
+
+def source_fingerprint(files=ENV_KERNEL_SOURCES) -> str:
+    """sha256 (first 16 hex digits) over the named csrc files and the compile flags: stored next to looked-up counter values
+    (profiles/pmc_traffic.json, the dynamics SQ-counter summary) so that bench.py can tell when the kernels have changed since
+    the counter pass."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _obj_path(unit: str, tag: str = "") -> str:
+    return os.path.join(CSRC, os.path.splitext(unit)[0] + tag + ".o")
+
+
+def _newer(deps, target) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    t = os.path.getmtime(target)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _stale() -> bool:
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    return _newer(deps, LIB_PATH)
+
+
 def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None) -> str:
-    """hipcc --offload-arch=gfx950 -> pioneer_amd/csrc/libpioneer_amd.so (in-tree).  extra_flags / out_path build a
-    variant next to it (e.g. -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B)."""
-    if out_path is not None:
+    """hipcc --offload-arch=gfx950 -> pioneer_amd/csrc/libpioneer_amd.so (in-tree): the two translation units are compiled in
+    parallel (only those whose sources changed) and linked.  extra_flags / out_path build a variant next to it (e.g.
+    -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B, -DPNR_DIAG_BUILD=1 for the timing-only ablations), with objects of its own."""
+    variant = out_path is not None or bool(extra_flags)
+    if variant:
         force = True
+        if out_path is None:
+            raise ValueError("a variant build (extra_flags) needs its own out_path")
     if not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libpioneer_amd.so")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-slp-vectorize",
-           "-mllvm", "-amdgpu-kernarg-preload-count=16",     # leading scalar kernel args arrive preloaded in SGPRs
-           "-Wall", "-Wno-unused-function", *extra_flags,
-           "-o", out_path or LIB_PATH, os.path.join(CSRC, "pnr_api.hip")]
+    tag = ("." + os.path.splitext(os.path.basename(out_path))[0]) if variant else ""
+    procs, objs = [], []
+    for unit, deps in UNITS.items():
+        obj = _obj_path(unit, tag)
+        objs.append(obj)
+        if not force and not _newer([os.path.join(CSRC, d) for d in deps] + [HEADER], obj):
+            continue
+        cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, os.path.join(CSRC, unit)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path or LIB_PATH, *objs]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=CSRC)
+    if variant:
+        for o in objs:
+            os.remove(o)
     return out_path or LIB_PATH
 
 
@@ -198,8 +261,8 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.pnr_abi_version() != 1:
-        raise ImportError("libpioneer_amd.so ABI version mismatch; rebuild")
+    if lib.pnr_abi_version() != ABI_VERSION:
+        raise ImportError(f"libpioneer_amd.so reports ABI {lib.pnr_abi_version()}, include/pioneer_amd.h says {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
 

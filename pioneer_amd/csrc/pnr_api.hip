@@ -25,684 +25,19 @@
 #include <new>
 
 #include "../../include/pioneer_amd.h"
+
+// Ablation switches (timing-only builds whose OUTPUTS ARE WRONG: stores, the integrator or the obs flush gated off; grid-cap
+// overrides) exist only in a variant library built with -DPNR_DIAG_BUILD=1 (`_lib.build_library(extra_flags=["-DPNR_DIAG_BUILD=1"],
+// out_path=...)`), which reads them from the environment at pnr_create.  The product library ignores the environment
+// (tests/test_abi.py checks that it holds no such string).
+#ifndef PNR_DIAG_BUILD
+#define PNR_DIAG_BUILD 0
+#endif
+
+#include "pnr_host.h"
 #include "pnr_device.h"
 #include "pnr_dyn.h"
-#include "pnr_ppo.h"
-#include "pnr_mlp.h"
-
-namespace pnr {
-
-// ---------------------------------------------------------------------------------
-// step / rollout kernel: BulletEnv.step (bullet_env.py:192-197) for T steps.
-// One wave = 32 envs (lane pair per env), one wave per workgroup.
-// ---------------------------------------------------------------------------------
-// The leading scalar parameters repeat P.state / P.actions / P.n / P.dt / P.eps and carry max_v_to_r (v_max
-// is formed from it and the constexpr limits): plain leading arguments (up to 14 dwords) are preloaded into SGPRs by the command processor (-mllvm
-// -amdgpu-kernarg-preload-count), so neither the first state and action loads nor the integrator wait for
-// a kernarg fetch; the by-value struct, needed from the reward block on, is fetched behind them.
-template <bool OBS_EM, bool ACT_EM>
-__global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_, const float* __restrict__ actions_,
-                                                     const long long n_, const double dt_, const double eps_,
-                                                     const float max_v_to_r_, const KParams P)
-{
-    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
-
-    const int lane = threadIdx.x;
-    const int p = lane & 1;                 // which half of the env's joints
-    const int el = lane >> 1;               // env within the wave's tile
-    const long long n = n_;
-    const long long ntiles = (n + kEnvsPerWave - 1) / kEnvsPerWave;
-
-    // PNR_DIAG timing-only ablations (outputs are wrong when set; see DESIGN.md "Where the time goes")
-    const bool diag_noflush = P.diag & 2, diag_noemit = P.diag & 4, diag_nostate = P.diag & 8;
-
-    const LaneConsts K = lane_consts(p);
-    // v_max = max_v_to_r * (r_hi - r_lo) (pioneer_knm_env.py:57), the same float32 product pnr_get_constants forms
-    const float vmax[kJpl] = {max_v_to_r_ * (K.lim[0] - (-K.lim[0])), max_v_to_r_ * (K.lim[1] - (-K.lim[1])),
-                              max_v_to_r_ * (K.lim[2] - (-K.lim[2]))};
-
-    // Persistent tile loop: the grid is capped (host: <= 8 waves per CU) and every wave strides over
-    // tiles.  The NEXT tile's state and first action are requested before the current tile is
-    // processed, so they never queue behind this CU's own obs stores.
-    const auto load_act0 = [&](long long e_, float (&a_)[kJpl]) {
-        if (ACT_EM) {
-            const float* a3 = actions_ + e_ * kDof + kJpl * p;         // 12 B per lane, lanes contiguous
-            a_[0] = a3[0]; a_[1] = a3[1]; a_[2] = a3[2];
-        } else {
-#pragma unroll
-            for (int i = 0; i < kJpl; ++i) a_[i] = actions_[(long long)(kJpl * p + i) * n + e_];
-        }
-    };
-
-    long long tix = blockIdx.x;
-    RawState raw = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    float act0[kJpl] = {0.f, 0.f, 0.f};
-    if (tix < ntiles && tix * kEnvsPerWave + el < n) {
-        raw = load_state_raw(state_, n, 2 * tix * kEnvsPerWave + lane);
-        load_act0(tix * kEnvsPerWave + el, act0);
-    }
-    bool first_tile = true;
-
-    // the 36 constant obs entries of this lane's tile slots: once per kernel, under the load latency
-    if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K, sink); }
-    else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K, sink); }
-
-    for (; tix < ntiles; tix += gridDim.x) {
-    const long long tile0 = tix * kEnvsPerWave;
-    const long long e = tile0 + el;
-    const long long rec = 2 * tile0 + lane; // state record index (2e + p)
-    const bool valid = e < n;               // the pair shares `valid`, so DPP partners are live
-    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
-
-    LaneState s;
-    unpack_state(raw, p, s);                // all-zero records for lanes past the end
-    float act_first[kJpl] = {act0[0], act0[1], act0[2]};
-
-    // prefetch the next tile
-    {
-        const long long nt = tix + gridDim.x;
-        if (nt < ntiles && nt * kEnvsPerWave + el < n) {
-            raw = load_state_raw(state_, n, 2 * nt * kEnvsPerWave + lane);
-            load_act0(nt * kEnvsPerWave + el, act0);
-        } else {
-            raw = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-        }
-    }
-
-    if (P.diag & 16) { if (valid) P.reward[e] = s.pot; continue; }   // launch + state-load floor
-
-    for (int t = 0; t < P.T; ++t) {
-        {
-            // -- action of this step (this lane's three joints) ----------------------
-            // this step's action was requested one step (or one tile) ago; request the next one now,
-            // ahead of this step's obs stores (VMEM ops of a wave retire in order)
-            float act[kJpl] = {act_first[0], act_first[1], act_first[2]};
-            if (t + 1 < P.T && valid) {
-                const float* A = actions_ + (long long)(t + 1) * n * kDof;
-                if (ACT_EM) {
-                    const float* a3 = A + e * kDof + kJpl * p;
-                    act_first[0] = a3[0]; act_first[1] = a3[1]; act_first[2] = a3[2];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < kJpl; ++i) act_first[i] = A[(long long)(kJpl * p + i) * n + e];
-                }
-            }
-            // -- act(): integrate the PREVIOUS action, then latch the new one -------
-#pragma unroll
-            for (int i = 0; i < kJpl; ++i) {
-                const float lim = K.lim[i];
-                if (!(P.diag & 32)) integrate_joint(s.a[i], s.v[i], s.r[i], vmax[i], -lim, lim, dt_, eps_, s.v[i], s.r[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < kJpl; ++i) s.a[i] = act[i];           // :144 (quirk Q1)
-        }
-        s.step += 1;                                                  // bullet_env.py:193
-
-        Pose q;
-        compute_pose(s, p, q);
-
-        // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
-        const float old_pot = s.pot;
-        const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
-        const bool done = q.dist < P.done_dist;                       // :160
-        const float r_pot = pot - old_pot;
-        const float r_step = -P.penalty;
-        const float r_done = done ? P.award_done : 0.0f;
-        const float rw = (r_pot + r_step) + r_done;                   // :165
-        s.pot = pot;
-        // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
-        const bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
-
-        if (valid && p == 0) {
-            const long long o = (long long)t * n + e;
-            stream_store(P.reward + o, rw);
-            stream_store(P.done + o, (uint8_t)done);
-            if (P.trunc) stream_store(P.trunc + o, (uint8_t)trunc);
-            if (P.info) stream_store(reinterpret_cast<float4*>(P.info) + o, make_float4(r_pot, r_step, r_done, q.dist));
-        }
-
-        // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
-        // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
-        if (P.auto_reset && (done || trunc)) {
-            reset_env(P, K, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
-            compute_pose(s, p, q);
-        }
-
-        // state goes out before the obs is packed: its stores drain under the LDS emit
-        if (t == P.T - 1 && valid && !diag_nostate) store_state(state_, n, rec, p, s);
-
-        // -- observe() ----------------------------------------------------------------
-        float* obs_t = P.obs + (long long)t * n * kObsDim;
-        if (t > 0 || !first_tile) wave_lds_sync();   // previous flush done before the tile is rewritten
-        if (OBS_EM) {
-            SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-            if (!diag_noemit) emit_obs<false>(K, s, q, p, sink);
-            wave_lds_sync();
-            if (!diag_noflush) flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
-        } else {
-            SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-            emit_obs<false>(K, s, q, p, sink);
-            wave_lds_sync();
-            flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
-        }
-    }
-    first_tile = false;
-    }   // tile loop
-}
-
-// ---------------------------------------------------------------------------------
-// dynamics-mode step: ONE launch per pnr_step / pnr_rollout.  A workgroup is one wave and owns 64 envs.
-//   phase A  one env per lane: command integration + the ABA sub-steps (pnr_dyn.h); a, v, r, q, qd of the
-//            env stay in that lane's registers for all T steps of the launch and are handed to phase B
-//            through LDS every step;
-//   phase B  the lanes regroup as pairs (as in step_kernel) and finish two 32-env tiles: reward,
-//            TimeLimit, auto-reset, observation through the LDS tile; the pair lanes keep target,
-//            potential, step and episode counters of their envs in registers.  A reset is reported back
-//            to the env's phase-A lane through a small LDS note (episode counter + the new r), which
-//            re-draws the per-env parameters itself.
-// The hand-off area is the head of the obs tile: both tiles' values are read into registers before the
-// first observation is packed.  With T > 1 the obs stores of step t drain under the sub-steps of t + 1.
-// ---------------------------------------------------------------------------------
-constexpr int kDynEnvsPerWg = kWave;                       // phase A: one env per lane
-constexpr int kHandRecFloats = 3 * 2 * kDynEnvsPerWg * 4;  // three float4 planes of 2 records per env
-constexpr int kHandFloats = kHandRecFloats + 2 * kDof * kDynEnvsPerWg;
-static_assert(kHandFloats <= kTileFloats, "the hand-off area must fit into the obs tile it aliases");
-
-template <bool OBS_EM>
-__device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParams& D, const LaneConsts& K, const RawState& raw,
-                                                const float (&dq)[kJpl], const float (&dqd)[kJpl], float* tile,
-                                                long long tile0, int lane, bool tile_in_use)
-{
-    const int p = lane & 1, el = lane >> 1;
-    const long long n = P.n;
-    const long long e = tile0 + el;
-    const bool valid = e < n;               // the pair shares `valid`, so DPP partners are live
-    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
-
-    LaneState s;
-    unpack_state(raw, p, s);                // all-zero records for lanes past the end
-    LaneState o = s;                        // what reward / obs see: the simulated q, qd
-#pragma unroll
-    for (int i = 0; i < kJpl; ++i) {
-        o.r[i] = dq[i];
-        // teleport = reference semantics: obs shows the env's own v (pioneer_knm_env.py:202)
-        o.v[i] = D.teleport ? s.v[i] : dqd[i];
-    }
-    s.step += 1;                                                  // bullet_env.py:193
-    o.step = s.step;
-
-    Pose q;
-    compute_pose(o, p, q);
-
-    // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
-    const float old_pot = s.pot;
-    const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
-    const bool done = q.dist < P.done_dist;                       // :160
-    const float r_pot = pot - old_pot;
-    const float r_step = -P.penalty;
-    const float r_done = done ? P.award_done : 0.0f;
-    const float rw = (r_pot + r_step) + r_done;                   // :165
-    s.pot = pot;
-    // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
-    bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
-    // a lane whose simulation diverged (non-finite pose) is cut like a time-out, so auto-reset recovers
-    // it instead of carrying NaNs forever (kinematic mode keeps the reference's NaN-propagating behaviour)
-    if (!(q.dist == q.dist && __builtin_fabsf(q.dist) <= 3.0e38f)) trunc = !done;
-
-    if (valid && p == 0) {
-        stream_store(P.reward + e, rw);
-        stream_store(P.done + e, (uint8_t)done);
-        if (P.trunc) stream_store(P.trunc + e, (uint8_t)trunc);
-        if (P.info) stream_store(reinterpret_cast<float4*>(P.info) + e, make_float4(r_pot, r_step, r_done, q.dist));
-    }
-
-    // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
-    // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
-    o.pot = pot;
-    const bool redraw = P.auto_reset && (done || trunc);
-    if (redraw) {
-        reset_env(P, K, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
-        if (valid) dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);   // q = r, qd = 0, new draws
-        o = s;
-        compute_pose(o, p, q);
-    }
-    if (valid) {
-        store_state(P.state, n, 2 * tile0 + lane, p, s);
-        if (!redraw) {
-#pragma unroll
-            for (int i = 0; i < kJpl; ++i) {
-                D.dyn[(long long)(kJpl * p + i) * n + e] = dq[i];
-                D.dyn[(long long)(6 + kJpl * p + i) * n + e] = dqd[i];
-            }
-        }
-    }
-
-    // -- observe() ----------------------------------------------------------------
-    if (tile_in_use) wave_lds_sync();       // previous flush done before the tile is rewritten
-    if (OBS_EM) {
-        SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-        emit_obs<false>(K, o, q, p, sink);
-        wave_lds_sync();
-        flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
-    } else {
-        SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-        emit_obs<false>(K, o, q, p, sink);
-        wave_lds_sync();
-        flush_feature_tile(tile, P.obs + tile0, n, nvalid, lane);
-    }
-}
-
-// Leading scalar arguments as in step_kernel: preloaded into SGPRs, they repeat P.state / D.dyn / P.actions /
-// P.n / P.dt / P.eps and carry max_v_to_r.
-template <bool OBS_EM, bool ACT_EM, bool RAND, int PHYS>
-__global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
-                                                         const float* __restrict__ actions_, const long long n_,
-                                                         const double dt_, const double eps_, const float max_v_to_r_,
-                                                         const KParams P, const DynParams D)
-{
-    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
-    const int lane = threadIdx.x;
-    const long long n = n_;
-    const long long base = (long long)blockIdx.x * kDynEnvsPerWg;
-    float4* hrec = reinterpret_cast<float4*>(tile);               // [3][2 * 64] records, index 2 * env + p
-    float* hq = tile + kHandRecFloats;                            // [12][64]: q then qd
-
-    // ---- phase A: one env per lane
-    {
-        const long long e = base + lane;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 k0[2] = {z4, z4}, k1[2] = {z4, z4}, k2[2] = {z4, z4};
-        float q[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qd[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
-        if (e < n) dyn_substeps_lane<ACT_EM, RAND, PHYS>(lead, D, e, k0, k1, k2, q, qd, tile);   // tile: free during phase A
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            hrec[2 * lane + p] = k0[p];
-            hrec[2 * kDynEnvsPerWg + 2 * lane + p] = k1[p];
-            hrec[4 * kDynEnvsPerWg + 2 * lane + p] = k2[p];
-        }
-#pragma unroll
-        for (int i = 0; i < kDof; ++i) {
-            hq[i * kDynEnvsPerWg + lane] = q[i];
-            hq[(kDof + i) * kDynEnvsPerWg + lane] = qd[i];
-        }
-    }
-    wave_lds_sync();
-
-    // ---- phase B: lane pairs; both tiles' hand-off records leave LDS before the tile is reused
-    const int p = lane & 1, el = lane >> 1;
-    RawState raw0, raw1;
-    float dq0[kJpl], dqd0[kJpl], dq1[kJpl], dqd1[kJpl];
-    {
-        const int r0 = lane, r1 = 2 * kEnvsPerWave + lane;        // record 2 * env + p of env el / env 32 + el
-        raw0 = {hrec[r0], hrec[2 * kDynEnvsPerWg + r0], hrec[4 * kDynEnvsPerWg + r0]};
-        raw1 = {hrec[r1], hrec[2 * kDynEnvsPerWg + r1], hrec[4 * kDynEnvsPerWg + r1]};
-#pragma unroll
-        for (int i = 0; i < kJpl; ++i) {
-            dq0[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + el];
-            dqd0[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + el];
-            dq1[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave + el];
-            dqd1[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave + el];
-        }
-    }
-    wave_lds_sync();
-    const LaneConsts K = lane_consts(p);
-    // the 36 constant obs entries of this lane's tile slots: once per kernel
-    if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K, sink); }
-    else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K, sink); }
-
-    dyn_finish_tile<OBS_EM>(P, D, K, raw0, dq0, dqd0, tile, base, lane, false);
-    if (base + kEnvsPerWave < n)
-        dyn_finish_tile<OBS_EM>(P, D, K, raw1, dq1, dqd1, tile, base + kEnvsPerWave, lane, true);
-}
-
-
-constexpr int kComFloats = 2 * kWave * 4;                  // common words of each lane's two envs between steps: float4 [2][64]
-constexpr int kRstFloats = (1 + kDof) * kDynEnvsPerWg;     // reset notes: episode flag + new r [7][64]
-
-struct DynTileRegs {      // what phase A handed over for this lane's record of one env
-    RawState raw;         // a, v, r of the lane's three joints (+ the common words on the first step)
-    float q[kJpl], qd[kJpl];
-};
-
-__device__ __forceinline__ void dyn_write_handoff(float* hand, int lane, const DynLane& L)
-{
-    float4* hrec = reinterpret_cast<float4*>(hand);               // [3][2 * 64] records, index 2 * env + p
-    float* hq = hand + kHandRecFloats;                            // [12][64]: q then qd
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        hrec[2 * lane + p] = make_float4(L.a[3 * p], L.a[3 * p + 1], L.a[3 * p + 2], L.v[3 * p]);
-        hrec[2 * kDynEnvsPerWg + 2 * lane + p] = make_float4(L.v[3 * p + 1], L.v[3 * p + 2], L.r[3 * p], L.r[3 * p + 1]);
-        hrec[4 * kDynEnvsPerWg + 2 * lane + p] = make_float4(L.r[3 * p + 2], L.cw[p][0], L.cw[p][1], L.cw[p][2]);
-    }
-#pragma unroll
-    for (int i = 0; i < kDof; ++i) {
-        hq[i * kDynEnvsPerWg + lane] = L.q[i];
-        hq[(kDof + i) * kDynEnvsPerWg + lane] = L.qd[i];
-    }
-}
-
-__device__ __forceinline__ void dyn_read_handoff(const float* hand, int env, int p, DynTileRegs& g)
-{
-    const float4* hrec = reinterpret_cast<const float4*>(hand);
-    const float* hq = hand + kHandRecFloats;
-    const int r = 2 * env + p;
-    g.raw = {hrec[r], hrec[2 * kDynEnvsPerWg + r], hrec[4 * kDynEnvsPerWg + r]};
-#pragma unroll
-    for (int i = 0; i < kJpl; ++i) {
-        g.q[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + env];
-        g.qd[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + env];
-    }
-}
-
-// One 32-env tile of phase B.  The env's common words (target | potential, step, episode) arrive with the first
-// hand-off; between the steps of a looped launch they wait in `com` (LDS), so that nothing of phase B stays in
-// registers during the sub-steps.
-template <bool OBS_EM>
-__device__ __forceinline__ void dyn_rollout_tile(const KParams& P, const DynParams& D, const LaneConsts& K, const DynTileRegs& in,
-                                                float4* com, float* tile, float* rst, long long tile0, int t, int lane,
-                                                bool tile_in_use)
-{
-    const int p = lane & 1, el = lane >> 1;
-    const long long n = P.n;
-    const long long e = tile0 + el;
-    const bool valid = e < n;               // the pair shares `valid`, so DPP partners are live
-    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
-    const bool last = t == P.T - 1;
-
-    LaneState s;
-    {
-        RawState raw = in.raw;
-        if (t > 0) { const float4 c = *com; raw.p2.y = c.y; raw.p2.z = c.z; raw.p2.w = c.w; }
-        unpack_state(raw, p, s);            // a, v, r of this lane's joints + the env's common words
-    }
-    LaneState o = s;                        // what reward / obs see: the simulated q, qd
-#pragma unroll
-    for (int i = 0; i < kJpl; ++i) {
-        o.r[i] = in.q[i];
-        // teleport = reference semantics: obs shows the env's own v (pioneer_knm_env.py:202)
-        o.v[i] = D.teleport ? s.v[i] : in.qd[i];
-    }
-    s.step += 1;                                                  // bullet_env.py:193
-    o.step = s.step;
-
-    Pose q;
-    compute_pose(o, p, q);
-
-    // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
-    const float old_pot = s.pot;
-    const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
-    const bool done = q.dist < P.done_dist;                       // :160
-    const float r_pot = pot - old_pot;
-    const float r_step = -P.penalty;
-    const float r_done = done ? P.award_done : 0.0f;
-    const float rw = (r_pot + r_step) + r_done;                   // :165
-    s.pot = pot;
-    // gym.wrappers.TimeLimit: truncated = elapsed >= max and not done
-    bool trunc = (P.max_steps > 0) && (s.step >= (uint32_t)P.max_steps) && !done;
-    // a lane whose simulation diverged (non-finite pose) is cut like a time-out, so auto-reset recovers
-    // it instead of carrying NaNs forever (kinematic mode keeps the reference's NaN-propagating behaviour)
-    if (!(q.dist == q.dist && __builtin_fabsf(q.dist) <= 3.0e38f)) trunc = !done;
-
-    if (valid && p == 0) {
-        const long long oi = (long long)t * n + e;
-        stream_store(P.reward + oi, rw);
-        stream_store(P.done + oi, (uint8_t)done);
-        if (P.trunc) stream_store(P.trunc + oi, (uint8_t)trunc);
-        if (P.info) stream_store(reinterpret_cast<float4*>(P.info) + oi, make_float4(r_pot, r_step, r_done, q.dist));
-    }
-
-    // -- in-kernel auto-reset (BulletEnv.reset as the sampler would call it) -----
-    // `done`/`trunc` are identical in both lanes of a pair, so pairs stay together
-    o.pot = pot;
-    const bool redraw = P.auto_reset && (done || trunc);
-    if (redraw) {
-        reset_env(P, K, s, p, P.env_off + (unsigned long long)e, nullptr, nullptr);
-        if (valid) {
-            dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);   // q = r, qd = 0, new draws
-            // note for the env's phase-A lane: the counter after the reset (>= 1) and the new joints
-            const int env = el + (int)(tile0 & (kDynEnvsPerWg - 1));
-            if (p == 0) rst[env] = __uint_as_float(s.episode);
-#pragma unroll
-            for (int i = 0; i < kJpl; ++i) rst[(1 + kJpl * p + i) * kDynEnvsPerWg + env] = s.r[i];
-        }
-        o = s;
-        compute_pose(o, p, q);
-    }
-    if (valid && last) {
-        store_state(P.state, n, 2 * tile0 + lane, p, s);
-        if (!redraw) {
-#pragma unroll
-            for (int i = 0; i < kJpl; ++i) {
-                D.dyn[(long long)(kJpl * p + i) * n + e] = in.q[i];
-                D.dyn[(long long)(6 + kJpl * p + i) * n + e] = in.qd[i];
-            }
-        }
-    }
-    *com = make_float4(0.f, p ? s.pot : s.tgt[0], p ? __uint_as_float(s.step) : s.tgt[1],
-                        p ? __uint_as_float(s.episode) : s.tgt[2]);
-
-    // -- observe() ----------------------------------------------------------------
-    float* obs_t = P.obs + (long long)t * n * kObsDim;
-    if (tile_in_use) wave_lds_sync();       // previous flush done before the tile is rewritten
-    if (OBS_EM) {
-        SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-        emit_obs<false>(K, o, q, p, sink);
-        wave_lds_sync();
-        flush_tile(tile, obs_t + tile0 * kObsDim, nvalid, lane);
-    } else {
-        SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-        emit_obs<false>(K, o, q, p, sink);
-        wave_lds_sync();
-        flush_feature_tile(tile, obs_t + tile0, n, nvalid, lane);
-    }
-}
-
-// pnr_rollout in dynamics mode: P.T steps in ONE launch.  Same two phases as dyn_step_kernel, but the env's
-// a, v, r, q, qd and parameters stay in its phase-A lane's registers from step to step, the pair lanes keep the
-// common words (target | potential, step, episode) in LDS between steps, and a reset travels back to the phase-A
-// lane as a small LDS note (episode counter + the new r) from which that lane re-draws the parameters itself.
-// The obs stores of step t drain under the sub-steps of step t + 1.  The hand-off has its own 9 KB here (the
-// kernel runs one wave per SIMD anyway), so a tile's values are read right before that tile is finished and
-// nothing of phase B is live during the sub-steps.
-template <bool OBS_EM, bool ACT_EM, bool RAND, int PHYS>
-__global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
-                                                         const float* __restrict__ actions_, const long long n_,
-                                                         const double dt_, const double eps_, const float max_v_to_r_,
-                                                         const KParams P, const DynParams D)
-{
-    __shared__ __attribute__((aligned(16))) float lds[kTileFloats + kComFloats + kRstFloats + kHandFloats + (PNR_DYN_LDS_MODEL ? kDynStageWords * 64 : 0)];
-    float* tile = lds;
-    float4* com = reinterpret_cast<float4*>(lds + kTileFloats);   // [2][64] common words between steps, index tile * 64 + lane
-    float* rst = lds + kTileFloats + kComFloats;                  // [7][64] reset notes, phase B -> phase A
-    float* hand = lds + kTileFloats + kComFloats + kRstFloats;    // records + q, qd planes (kHandFloats)
-    const int lane = threadIdx.x;
-    const int p = lane & 1, el = lane >> 1;
-    const long long n = n_;
-    const long long base = (long long)blockIdx.x * kDynEnvsPerWg;
-    const long long eA = base + lane;                             // phase A: this lane's env
-    const bool liveA = eA < n;
-    const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
-
-    DynLane L;
-#pragma unroll
-    for (int i = 0; i < kDof; ++i) { L.a[i] = L.v[i] = L.r[i] = L.q[i] = L.qd[i] = 0.f; L.fric[i] = L.damp[i] = 0.f; }
-#pragma unroll
-    for (int l = 0; l < kNumLinks; ++l) L.sc[l] = 1.0f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { L.cw[0][k] = 0.f; L.cw[1][k] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < kDof; ++i) L.act[i] = 0.f;
-    if (liveA) dyn_lane_load<ACT_EM, RAND>(lead, base, lane, L);
-    {   // the 36 constant obs entries of this lane's tile slots: once per kernel (nothing else writes them)
-        const LaneConsts K0 = lane_consts(p);
-        if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K0, sink); }
-        else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K0, sink); }
-    }
-
-    const int T = P.T;
-    for (int t = 0; t < T; ++t) {
-        // ---- phase A: one env per lane
-        if (liveA) dyn_lane_advance<ACT_EM, RAND, PHYS>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L,
-                                                           lds + kTileFloats + kComFloats + kRstFloats + kHandFloats);
-        dyn_write_handoff(hand, lane, L);
-        rst[lane] = 0.f;                                // no reset noted yet (episode counters are >= 1)
-        wave_lds_sync();
-
-        // ---- phase B: lane pairs
-        {
-            // everything phase B derives from the lane id (pair constants, tile and output addresses) is re-derived
-            // from an opaque copy each step: hoisted out of the t loop it would sit in registers during the sub-steps
-            int lane_b = lane;
-            asm volatile("" : "+v"(lane_b));
-            const int pb = lane_b & 1, elb = lane_b >> 1;
-            const LaneConsts Kb = lane_consts(pb);
-            {
-                DynTileRegs g;
-                dyn_read_handoff(hand, elb, pb, g);
-                dyn_rollout_tile<OBS_EM>(P, D, Kb, g, com + lane_b, tile, rst, base, t, lane_b, t > 0);
-            }
-            if (base + kEnvsPerWave < n) {
-                DynTileRegs g;
-                dyn_read_handoff(hand, kEnvsPerWave + elb, pb, g);
-                dyn_rollout_tile<OBS_EM>(P, D, Kb, g, com + kWave + lane_b, tile, rst, base + kEnvsPerWave, t, lane_b, true);
-            }
-            // ---- back to phase A: envs that were reset continue from the new draw
-            if (t + 1 < T) {
-                wave_lds_sync();
-                const uint32_t ep = __float_as_uint(rst[lane]);
-                if (liveA && ep != 0u) {
-#pragma unroll
-                    for (int j = 0; j < kDof; ++j) {
-                        L.r[j] = rst[(1 + j) * kDynEnvsPerWg + lane];
-                        L.a[j] = 0.f; L.v[j] = 0.f; L.q[j] = L.r[j]; L.qd[j] = 0.f;
-                    }
-                    if (RAND) dyn_draw_params(P, D, P.env_off + (unsigned long long)eA, ep - 1u, L.sc, L.fric, L.damp);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// reset / observe kernel.  MODE 0: reset (mask / overrides), 1: observe only.
-// OBS: 0 none, 1 feature-major direct (masked reset), 2 env-major via LDS tile
-//      (all rows written), 3 env-major direct rows (masked reset), 4 feature-major
-//      via LDS tile (all columns written).
-// ---------------------------------------------------------------------------------
-template <int MODE, int OBS, bool DYN>
-__global__ __launch_bounds__(kWave) void reset_kernel(const KParams P, const DynParams D)
-{
-    __shared__ __attribute__((aligned(16))) float tile[(OBS == 2 || OBS == 4) ? kTileFloats : 4];
-    const int lane = threadIdx.x;
-    const int p = lane & 1, el = lane >> 1;
-    const long long n = P.n;
-    const long long tile0 = (long long)blockIdx.x * kEnvsPerWave;
-    const long long e = tile0 + el;
-    const long long rec = 2 * tile0 + lane;
-    const bool valid = e < n;
-    const int nvalid = (int)((n - tile0) < kEnvsPerWave ? (n - tile0) : kEnvsPerWave);
-
-    const LaneConsts K = lane_consts(p);
-    LaneState s;
-    if (valid) load_state(P.state, n, rec, p, s);
-    else zero_state(s);
-    bool active = valid;
-    if (MODE == 0) {
-        if (valid && P.mask) active = P.mask[e] != 0;
-        if (active) {   // both lanes of a pair take the same branch
-            reset_env(P, K, s, p, P.env_off + (unsigned long long)e,
-                      P.joint_pos ? P.joint_pos + e * kDof : nullptr,
-                      P.target_pos ? P.target_pos + e * 3 : nullptr);
-            store_state(P.state, n, rec, p, s);
-            if (DYN) dyn_reset_lane(P, D, s, p, e, P.env_off + (unsigned long long)e, s.episode - 1);
-        }
-    }
-    if (DYN && !(MODE == 0 && active)) {
-        // observe the simulated joints (a freshly reset env has q = r, qd = 0 already in s)
-#pragma unroll
-        for (int i = 0; i < kJpl; ++i) {
-            const float qi = valid ? D.dyn[(long long)(kJpl * p + i) * n + e] : 0.f;
-            const float qdi = valid ? D.dyn[(long long)(6 + kJpl * p + i) * n + e] : 0.f;
-            s.r[i] = qi;
-            if (!D.teleport) s.v[i] = qdi;
-        }
-    }
-    if (OBS != 0) {
-        Pose q;
-        compute_pose(s, p, q);   // every lane takes part: the DPP exchange needs live partners
-        if (OBS == 1) {
-            SinkDirect sink{P.obs + e, n, kJpl * p, p, active};
-            emit_obs(K, s, q, p, sink);
-        } else if (OBS == 2) {
-            SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-            emit_obs(K, s, q, p, sink);
-            wave_lds_sync();
-            flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
-        } else if (OBS == 4) {
-            SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
-            emit_obs(K, s, q, p, sink);
-            wave_lds_sync();
-            flush_feature_tile(tile, P.obs + tile0, n, nvalid, lane);
-        } else {
-            SinkDirect sink{P.obs + e * kObsDim, 1, kJpl * p, p, active};
-            emit_obs(K, s, q, p, sink);
-        }
-    }
-}
-
-// canonical planar words [24][n] (include/pioneer_amd.h) <-> the engine's pair records
-__device__ __forceinline__ int word_of(int p, int plane, int comp)
-{
-    // which canonical word sits in (half p, plane, component)
-    const int k = plane * 4 + comp;            // 0..11 within the half record
-    if (k < 3) return 0 + 3 * p + k;           // a
-    if (k < 6) return 6 + 3 * p + (k - 3);     // v
-    if (k < 9) return 12 + 3 * p + (k - 6);    // r
-    return (p ? 21 : 18) + (k - 9);            // target xyz | potential, step, episode
-}
-
-__global__ void state_to_words_kernel(const float4* __restrict__ st, uint32_t* __restrict__ w, long long n)
-{
-    const long long rec = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (rec >= 2 * n) return;
-    const long long e = rec >> 1; const int p = (int)(rec & 1);
-#pragma unroll
-    for (int pl = 0; pl < kStatePlanes; ++pl) {
-        const float4 v = st[(long long)pl * 2 * n + rec];
-        w[(long long)word_of(p, pl, 0) * n + e] = __float_as_uint(v.x);
-        w[(long long)word_of(p, pl, 1) * n + e] = __float_as_uint(v.y);
-        w[(long long)word_of(p, pl, 2) * n + e] = __float_as_uint(v.z);
-        w[(long long)word_of(p, pl, 3) * n + e] = __float_as_uint(v.w);
-    }
-}
-
-__global__ void words_to_state_kernel(float4* __restrict__ st, const uint32_t* __restrict__ w, long long n)
-{
-    const long long rec = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (rec >= 2 * n) return;
-    const long long e = rec >> 1; const int p = (int)(rec & 1);
-#pragma unroll
-    for (int pl = 0; pl < kStatePlanes; ++pl) {
-        st[(long long)pl * 2 * n + rec] =
-            make_float4(__uint_as_float(w[(long long)word_of(p, pl, 0) * n + e]),
-                        __uint_as_float(w[(long long)word_of(p, pl, 1) * n + e]),
-                        __uint_as_float(w[(long long)word_of(p, pl, 2) * n + e]),
-                        __uint_as_float(w[(long long)word_of(p, pl, 3) * n + e]));
-    }
-}
-
-__global__ void diag_sincos_kernel(const float* __restrict__ x, float* __restrict__ sn, float* __restrict__ cs,
-                                   long long n, int bounded)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s, c;
-    if (bounded) sincos_bounded(x[i], s, c); else sincos_any(x[i], s, c);
-    sn[i] = s; cs[i] = c;
-}
-
-}  // namespace pnr
+#include "pnr_env_kernels.h"
 
 // =====================================================================================
 // host side
@@ -720,7 +55,7 @@ struct pnr_env_s {
     float4* state;
     float* dyn;          // dynamics-mode planar words [36][n] or null
     SceneBody* scene;    // dynamics-mode static scene bodies [kMaxScene] or null
-    int diag;            // PNR_DIAG env var at create time (timing-only ablations; 0 in production)
+    int diag;            // -DPNR_DIAG_BUILD=1 variant only: the PNR_DIAG environment variable at create time; else 0
     bool ready;          // a full reset has happened, or the state was set explicitly
     bool kin_set, dyn_set;  // pnr_set_state / pnr_set_dyn_state seen (both needed in dynamics mode)
     char err[512];
@@ -728,32 +63,24 @@ struct pnr_env_s {
 
 static thread_local char g_err[512] = "";
 
-static int fail(pnr_handle h, int code, const char* fmt, ...)
+// the one place error messages are written (pnr_host.h: shared with pnr_learn.hip, not exported)
+int pnr_failv(char* handle_err, int code, const char* fmt, va_list ap)
 {
-    char* dst = h ? h->err : g_err;
-    va_list ap;
-    va_start(ap, fmt);
+    char* dst = handle_err ? handle_err : g_err;
     vsnprintf(dst, 512, fmt, ap);
-    va_end(ap);
-    if (h) { strncpy(g_err, h->err, sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
+    if (handle_err) { strncpy(g_err, handle_err, sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
     return code;
 }
 
-#define HIP_TRY(h, call)                                                                      \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess)                                                                 \
-            return fail(h, PNR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
-    } while (0)
+static int fail(pnr_handle h, int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    const int rc = pnr_failv(h ? h->err : nullptr, code, fmt, ap);
+    va_end(ap);
+    return rc;
+}
 
-// RAII current-device switch: launches and allocations go to the handle's device.
-struct DeviceGuard {
-    int prev = -1; bool switched = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) { switched = hipSetDevice(dev) == hipSuccess; }
-    }
-    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
-};
 
 extern "C" {
 
@@ -978,7 +305,9 @@ int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, i
             if (e != hipSuccess) { (void)hipFree(h->dyn); (void)hipFree(h->state); delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(scene) failed: %s", hipGetErrorString(e)); }
         }
     }
+#if PNR_DIAG_BUILD
     { const char* e_ = getenv("PNR_DIAG"); h->diag = e_ ? atoi(e_) : 0; }
+#endif
     fill_base(h);
     h->base.seed_lo = (unsigned)seed; h->base.seed_hi = (unsigned)(seed >> 32);
     *out = h;
@@ -1015,12 +344,16 @@ static inline unsigned grid_for(long long n) { return (unsigned)((n + kEnvsPerWa
 // (pnr_rollout, T >= 8): 1 024 = ONE wave per SIMD — each wave's stores of step t drain under its own step
 // t + 1, and a second wave on the SIMD only contends for issue slots (6.5-7.2 vs 7.2-7.5 us per 65 536-env
 // step at T = 32; 768 and 1 536 are worse than either; at T = 2, 4 the 2 048 grid still wins: 8.7 / 8.1 vs
-// 10.0 / 8.6 us).  PNR_GRID_CAP / PNR_GRID_CAP_ROLLOUT override for experiments.
+// 10.0 / 8.6 us).  The -DPNR_DIAG_BUILD=1 variant reads overrides from the environment (grid-cap experiments).
 static inline unsigned step_grid_for(long long n, int T)
 {
+#if PNR_DIAG_BUILD
     static int cap = -1, cap_roll = -1;
     if (cap < 0) { const char* e_ = getenv("PNR_GRID_CAP"); cap = e_ ? atoi(e_) : 2048; if (cap < 1) cap = 2048; }
     if (cap_roll < 0) { const char* e_ = getenv("PNR_GRID_CAP_ROLLOUT"); cap_roll = e_ ? atoi(e_) : 1024; if (cap_roll < 1) cap_roll = 1024; }
+#else
+    constexpr int cap = 2048, cap_roll = 1024;
+#endif
     const unsigned tiles = grid_for(n);
     const unsigned c = (unsigned)(T >= 8 ? cap_roll : cap);
     return tiles < c ? tiles : c;
@@ -1158,362 +491,6 @@ int pnr_diag_sincos(const float* x, float* sin_out, float* cos_out, int64_t n, i
     return PNR_OK;
 }
 
-int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, const float* head_value, const float* actions,
-                 const float* logp_old, const float* mean_old, const float* log_std_old, const float* adv,
-                 const float* value_target, const float* value_old, const float* kl_coeff, const float* entropy_coeff,
-                 float clip_param, float vf_clip_param, float vf_loss_coeff, float* grad_head_policy,
-                 float* grad_head_value, float* partial_sums, int64_t partial_rows, float* means, void* stream)
-{
-    if (batch <= 0 || !head_policy || !head_value || !actions || !logp_old || !mean_old || !log_std_old || !adv ||
-        !value_target || !value_old || !kl_coeff || !entropy_coeff || !grad_head_policy || !grad_head_value || !partial_sums)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_loss: null argument or empty batch");
-    const long long blocks = (batch + kPpoBlock - 1) / kPpoBlock;
-    if (partial_rows < blocks)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_loss: partial_sums has %lld rows, the launch needs %lld",
-                    (long long)partial_rows, blocks);
-    PpoLossParams P;
-    P.head_p = head_policy; P.head_v = head_value; P.actions = actions; P.logp_old = logp_old; P.mean_old = mean_old;
-    P.idx = reinterpret_cast<const long long*>(idx);
-    P.ls_old = log_std_old; P.adv = adv; P.vtarg = value_target; P.v_old = value_old; P.kl_coeff = kl_coeff;
-    P.ent_coeff = entropy_coeff; P.g_head_p = grad_head_policy; P.g_head_v = grad_head_value; P.partials = partial_sums;
-    P.B = batch; P.clip = clip_param; P.vf_clip = vf_clip_param; P.vf_coeff = vf_loss_coeff;
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3((unsigned)blocks), dim3(kPpoBlock), 0, (hipStream_t)stream, P);
-    if (means)
-        hipLaunchKernelGGL(ppo_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial_sums, (long long)blocks,
-                           (long long)batch, means, (float*)nullptr);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-// ---- the host driver's MLPs (pnr_mlp.h) ------------------------------------------------------------------------
-// 32 slices x 4 roles x 2 nets = 256 workgroups = one per CU, one round; 64 slices (two rounds) wrote and re-read twice the
-// slab bytes for the same time in the multiply loop
-constexpr long long kMaxSlices = 32;
-static inline void mlp_slicing(long long B, long long* slices, long long* slice_rows)
-{
-    long long want = (B + kWgChunk - 1) / kWgChunk;          // at most one slice per 64-sample chunk ...
-    if (want > kMaxSlices) want = kMaxSlices;                // ... and few enough that slices x 4 roles x 2 nets fill the CUs ONCE
-    if (want < 1) want = 1;
-    long long rows = (B + want - 1) / want;
-    rows = (rows + kWgChunk - 1) / kWgChunk * kWgChunk;
-    *slice_rows = rows;
-    *slices = (B + rows - 1) / rows;
-}
-
-int64_t pnr_mlp_slab_floats(int64_t batch)
-{
-    if (batch < 1) return 0;
-    long long slices, rows;
-    mlp_slicing(batch, &slices, &rows);
-    return (int64_t)(slices * kMlpNets * kGradElems);
-}
-
-int64_t pnr_mlp_pack_elems(void) { return (int64_t)kMlpNets * kPackElems; }
-int64_t pnr_mlp_bias_elems(void) { return (int64_t)kMlpNets * kBiasElems; }
-
-int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value, void* wpack, float* bias, void* stream)
-{
-    if (!params || !wpack || !bias) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: null argument");
-    if (n3_policy < 1 || n3_policy > kMlpHead || n3_value < 1 || n3_value > kMlpHead)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: head widths must be in 1..16");
-    MlpPackParams P;
-    for (int n = 0; n < kMlpNets; ++n) {
-        for (int k = 0; k < 6; ++k)
-            if (!params[6 * n + k]) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: null parameter %d of net %d", k, n);
-        P.net[n] = {params[6 * n + 0], params[6 * n + 1], params[6 * n + 2], params[6 * n + 3], params[6 * n + 4], params[6 * n + 5],
-                    n == 0 ? n3_policy : n3_value};
-    }
-    P.wpack = static_cast<__bf16*>(wpack); P.bias = bias;
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3((kPackElems + kBiasElems + 255) / 256, kMlpNets), dim3(256), 0, (hipStream_t)stream, P);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const float* f_loc, const float* f_inv,
-                    const float* f_lo, const float* f_hi, const void* wpack, const float* bias, float* head,
-                    void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, void* stream)
-{
-    if (batch < 1 || !obs || !wpack || !bias || !head) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: null argument or empty batch");
-    if (first_net < 0 || n_nets < 1 || first_net + n_nets > kMlpNets) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: bad net range");
-    if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: the four filter vectors come together or not at all");
-    if ((h1 == nullptr) != (h2 == nullptr)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: h1 and h2 come together");
-    MlpFwdParams P = {};
-    P.obs = obs; P.idx = reinterpret_cast<const long long*>(idx); P.f_loc = f_loc; P.f_inv = f_inv; P.f_lo = f_lo; P.f_hi = f_hi;
-    P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
-    P.xs = static_cast<__bf16*>(xs); P.h1 = static_cast<__bf16*>(h1); P.h2 = static_cast<__bf16*>(h2);
-    P.B = batch; P.first_net = first_net; P.n_nets = n_nets;
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kMlpThreads), 0,
-                       (hipStream_t)stream, P);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int64_t pnr_ppo_gae_scratch(int64_t n) { return n < 1 ? 0 : ((n + 63) / 64) * 8; }
-
-int pnr_ppo_gae(int32_t T, int64_t n, const float* reward, const float* values, const float* last_value, const uint8_t* done,
-                const uint8_t* truncated, const float* actions, const float* mean, const float* log_std, double gamma,
-                double lambda, float* logp, float* adv, float* value_target, float* terminals, const pnr_rollout_stats* stats,
-                void* stream)
-{
-    if (T < 1 || n < 1 || !reward || !values || !last_value || !done || !adv || !value_target)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: null argument or empty rollout");
-    if (actions && (!mean || !log_std || !logp)) return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: actions need mean, log_std and logp");
-    const long long blocks = (n + 63) / 64;
-    if (stats) {
-        if (!stats->ep_ret || !stats->ep_len || !stats->scratch || !stats->w_sum || !stats->w_len || !stats->w_cnt || !stats->w_max ||
-            !stats->w_min || !stats->adv_stats)
-            return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: null pointer in pnr_rollout_stats");
-        if (stats->scratch_doubles < blocks * 8)
-            return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_gae: scratch holds %lld doubles, the launch needs %lld",
-                        (long long)stats->scratch_doubles, blocks * 8);
-    }
-    GaeParams P;
-    P.reward = reward; P.values = values; P.last_value = last_value; P.done = done; P.trunc = truncated;
-    P.actions = actions; P.mean = mean; P.log_std = log_std; P.logp = logp; P.adv = adv; P.vtarg = value_target;
-    P.terminals = terminals; P.N = n; P.T = T;
-    P.ep_ret = stats ? stats->ep_ret : nullptr; P.ep_len = stats ? stats->ep_len : nullptr; P.partials = stats ? stats->scratch : nullptr;
-    P.gamma = (float)gamma; P.gamma_lam = (float)(gamma * lambda);      // the host formula's Python-float product, then float32
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gae_logp_kernel, dim3((unsigned)blocks, (unsigned)(1 + ((actions || terminals) ? T : 0))), dim3(64), 0, st, P);
-    if (stats)
-        hipLaunchKernelGGL(gae_finish_kernel, dim3(1), dim3(64), 0, st, stats->scratch, blocks, (long long)T * n, stats->w_sum, stats->w_len,
-                           stats->w_cnt, stats->w_max, stats->w_min, stats->adv_stats);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int64_t pnr_filter_moments_scratch(int64_t rows) { return rows < 1 ? 0 : ((rows + kFmRows - 1) / kFmRows) * 2 * kFmCols; }
-
-int pnr_filter_moments(int64_t rows, const float* obs, const float* pivot, float* scratch, int64_t scratch_floats, double* dsum,
-                       double* dsq, double* dn, void* stream)
-{
-    if (rows < 1 || !obs || !pivot || !scratch || !dsum || !dsq || !dn)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_filter_moments: null argument or no rows");
-    const long long blocks = (rows + kFmRows - 1) / kFmRows;
-    if (scratch_floats < blocks * 2 * kFmCols)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_filter_moments: scratch holds %lld floats, the launch needs %lld",
-                    (long long)scratch_floats, blocks * 2 * kFmCols);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(filter_moments_kernel, dim3((unsigned)blocks), dim3(kFmThreads), 0, st, obs, (long long)rows, pivot, scratch);
-    hipLaunchKernelGGL(filter_moments_finish_kernel, dim3(kFmCols, 2), dim3(256), 0, st, scratch, blocks, (long long)rows, dsum, dsq, dn);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_filter_merge(double* dn, double* dsum, double* dsq, const float* pivot, double* n, double* mean, double* m2, void* stream)
-{
-    if (!dn || !dsum || !dsq || !pivot || !n || !mean || !m2) return fail(nullptr, PNR_ERR_INVALID, "pnr_filter_merge: null argument");
-    hipLaunchKernelGGL(filter_merge_kernel, dim3(1), dim3(kFmThreads), 0, (hipStream_t)stream, dn, dsum, dsq, pivot, n, mean, m2);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
-{
-    if (n < 1 || !out) return fail(nullptr, PNR_ERR_INVALID, "pnr_permutation: null argument or n < 1");
-    if (n > (1ll << 40)) return fail(nullptr, PNR_ERR_INVALID, "pnr_permutation: n above 2^40");
-    int bits = 1;
-    while ((1ll << bits) < n) ++bits;                   // 2^bits >= n
-    const int half = (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
-    hipLaunchKernelGGL(permutation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<long long*>(out), (long long)n, half, (unsigned long long)seed, (unsigned long long)stream_id);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
-                const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
-                float* log_std, float* values, float* actions, float* env_actions, void* xs_out, void* stream)
-{
-    if (batch < 1 || !obs || !wpack || !bias || !noise || !mean || !log_std || !values || !actions)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: null argument or empty batch");
-    if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: the four filter vectors come together or not at all");
-    if (a_max && (!env_actions || env_actions == actions))
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: clipping (a_max) needs its own env_actions buffer");
-    MlpFwdParams P = {};
-    P.obs = obs; P.f_loc = f_loc; P.f_inv = f_inv; P.f_lo = f_lo; P.f_hi = f_hi;
-    P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
-    P.B = batch; P.first_net = 0; P.n_nets = kMlpNets;
-    P.noise = noise; P.a_max = a_max; P.mean = mean; P.log_std = log_std; P.values = values; P.actions = actions;
-    P.env_actions = a_max ? env_actions : actions;
-    P.xs = static_cast<__bf16*>(xs_out);                     // the nets' input as they saw it, for the learner (or null)
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0,
-                       (hipStream_t)stream, P);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
-                     void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
-                     int32_t n3_value, int32_t accumulate, const float* scale, void* stream)
-{
-    if (batch < 1 || !g_head || !wpack || !xs || !h1 || !h2 || !dz1 || !dz2 || !slabs || !grads)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: null argument or empty batch");
-    long long slices, rows;
-    mlp_slicing(batch, &slices, &rows);
-    if (slab_floats < slices * kMlpNets * kGradElems)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: slabs hold %lld floats, the launch needs %lld",
-                    (long long)slab_floats, slices * kMlpNets * kGradElems);
-    hipStream_t st = (hipStream_t)stream;
-    MlpBwdParams Bp;
-    Bp.g_head = g_head; Bp.wpack = static_cast<const __bf16*>(wpack); Bp.h1 = static_cast<const __bf16*>(h1);
-    Bp.h2 = static_cast<const __bf16*>(h2); Bp.dz1 = static_cast<__bf16*>(dz1); Bp.dz2 = static_cast<__bf16*>(dz2); Bp.B = batch;
-    hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0, st, Bp);
-    MlpWgradParams Wp;
-    Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
-    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kMlpThreads), 0, st, Wp);
-    MlpReduceParams Rp;
-    Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate; Rp.scale = scale;
-    for (int n = 0; n < kMlpNets; ++n) {
-        for (int k = 0; k < 6; ++k)
-            if (!grads[6 * n + k]) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_backward: null gradient %d of net %d", k, n);
-        Rp.gw1[n] = grads[6 * n + 0]; Rp.gb1[n] = grads[6 * n + 1]; Rp.gw2[n] = grads[6 * n + 2];
-        Rp.gb2[n] = grads[6 * n + 3]; Rp.gw3[n] = grads[6 * n + 4]; Rp.gb3[n] = grads[6 * n + 5];
-    }
-    Rp.n3[0] = n3_policy; Rp.n3[1] = n3_value;
-    hipLaunchKernelGGL(mlp_reduce_kernel, dim3((kGradElems + 255) / 256, kMlpNets), dim3(256), 0, st, Rp);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int64_t pnr_mlp_grad_floats(void) { return (int64_t)kMlpNets * kGradElems; }
-
-static int mlp_step_check(const pnr_mlp_step* s, const char* who)
-{
-    if (!s) return fail(nullptr, PNR_ERR_INVALID, "%s: null argument block", who);
-    if (s->struct_size != sizeof(pnr_mlp_step))
-        return fail(nullptr, PNR_ERR_INVALID, "%s: pnr_mlp_step size mismatch (got %u, want %zu)", who, s->struct_size, sizeof(pnr_mlp_step));
-    for (int k = 0; k < 12; ++k)
-        if (!s->params[k]) return fail(nullptr, PNR_ERR_INVALID, "%s: null parameter %d", who, k);
-    if (!s->wpack || !s->bias || !s->adam_m || !s->adam_v || !s->adam_step)
-        return fail(nullptr, PNR_ERR_INVALID, "%s: null weight / optimiser buffer", who);
-    if (s->n3_policy < 1 || s->n3_policy > kMlpHead || s->n3_value < 1 || s->n3_value > kMlpHead)
-        return fail(nullptr, PNR_ERR_INVALID, "%s: head widths must be in 1..16", who);
-    return PNR_OK;
-}
-
-// loss_rows > 0: the launch also sums the update's loss means (rows of the fused kernel in s->partials)
-static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices, float scale, hipStream_t st, long long loss_rows = 0)
-{
-    MlpAdamParams A;
-    A.partials = loss_rows > 0 ? s->partials : nullptr; A.loss_rows = loss_rows; A.batch = s->batch; A.means = s->means;
-    A.kl_coeff = s->kl_coeff; A.ent_coeff = s->entropy_coeff; A.vf_coeff = s->vf_loss_coeff;
-    A.grad = grad; A.slices = slices; A.grad_scale = scale;
-    for (int n = 0; n < kMlpNets; ++n) {
-        A.w1[n] = s->params[6 * n + 0]; A.b1[n] = s->params[6 * n + 1]; A.w2[n] = s->params[6 * n + 2];
-        A.b2[n] = s->params[6 * n + 3]; A.w3[n] = s->params[6 * n + 4]; A.b3[n] = s->params[6 * n + 5];
-    }
-    A.n3[0] = s->n3_policy; A.n3[1] = s->n3_value;
-    A.m = s->adam_m; A.v = s->adam_v; A.step = s->adam_step;
-    A.lr = s->lr; A.beta1 = s->beta1; A.beta2 = s->beta2; A.eps = s->eps;
-    A.wpack = static_cast<__bf16*>(s->wpack); A.bias = s->bias;
-    hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, kMlpNets), dim3(256), 0, st, A);
-}
-
-int pnr_ppo_pack_record(int64_t rows, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
-                        const float* adv, const float* value_target, const float* value_old, const float* adv_mu, const float* adv_den,
-                        float* record_rows, void* stream)
-{
-    if (rows < 1 || !actions || !logp_old || !mean_old || !log_std_old || !adv || !value_target || !value_old || !record_rows)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_pack_record: null argument or no rows");
-    if ((adv_mu == nullptr) != (adv_den == nullptr))
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_pack_record: adv_mu and adv_den come together");
-    RecordPackParams R;
-    R.actions = actions; R.logp = logp_old; R.mean = mean_old; R.log_std = log_std_old; R.adv = adv; R.vtarg = value_target;
-    R.values = value_old; R.adv_mu = adv_mu; R.adv_den = adv_den; R.aos = record_rows; R.rows = rows;
-    hipLaunchKernelGGL(record_pack_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo,
-                   const float* f_hi, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
-                   const float* adv, const float* value_target, const float* value_old, void* xs_out, float* actions_out,
-                   float* logp_out, float* mean_out, float* log_std_out, float* adv_out, float* value_target_out,
-                   float* value_old_out, const float* record_rows, const void* xs_rows, void* stream)
-{
-    const bool soa = actions && logp_old && mean_old && log_std_old && adv && value_target && value_old;
-    if (batch < 1 || !(obs || xs_rows) || !(soa || record_rows) || !xs_out ||
-        !actions_out || !logp_out || !mean_out || !log_std_out || !adv_out || !value_target_out || !value_old_out)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_gather: null argument or empty batch");
-    if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_gather: the four filter vectors come together or not at all");
-    MlpGatherParams G;
-    G.obs = obs; G.idx = reinterpret_cast<const long long*>(idx); G.f_loc = f_loc; G.f_inv = f_inv; G.f_lo = f_lo; G.f_hi = f_hi;
-    G.actions = actions; G.logp = logp_old; G.mean = mean_old; G.log_std = log_std_old; G.adv = adv; G.vtarg = value_target;
-    G.values = value_old; G.rec_aos = record_rows; G.xs_src = static_cast<const __bf16*>(xs_rows); G.xs_out = static_cast<__bf16*>(xs_out); G.actions_out = actions_out; G.logp_out = logp_out;
-    G.mean_out = mean_out; G.log_std_out = log_std_out; G.adv_out = adv_out; G.vtarg_out = value_target_out; G.values_out = value_old_out;
-    G.B = batch;
-    hipLaunchKernelGGL(mlp_gather_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(kMlpThreads), 0, (hipStream_t)stream, G);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
-{
-    int rc = mlp_step_check(s, "pnr_mlp_train_step");
-    if (rc) return rc;
-    const long long B = s->batch;
-    if (B < 1 || (!s->obs && !s->xs_in) || !s->actions || !s->logp_old || !s->mean_old || !s->log_std_old || !s->adv || !s->value_target ||
-        !s->value_old || !s->kl_coeff || !s->entropy_coeff || !s->head || !s->g_head || !s->xs || !s->h1 || !s->h2 || !s->dz1 ||
-        !s->dz2 || !s->partials || !s->slabs || !s->means)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: null argument or empty batch");
-    if ((s->f_loc || s->f_inv || s->f_lo || s->f_hi) && !(s->f_loc && s->f_inv && s->f_lo && s->f_hi))
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: the four filter vectors come together or not at all");
-    long long slices, rows;
-    mlp_slicing(B, &slices, &rows);
-    if (s->slab_floats < slices * kMlpNets * kGradElems)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: slabs hold %lld floats, the launch needs %lld",
-                    (long long)s->slab_floats, slices * kMlpNets * kGradElems);
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), kMlpNets), thr(kMlpThreads);
-    const long long prow = (long long)tiles.x * kMlpNets;       // one row of loss sums per workgroup of the fused kernel
-    if (s->partial_rows < prow)
-        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: partials hold %lld rows, the launch needs %lld",
-                    (long long)s->partial_rows, prow);
-
-    // forward + loss + backward-data of each 64-sample tile in ONE launch (mlp_forward_kernel<true>), then the means
-    MlpFwdParams F = {};
-    F.obs = s->obs; F.idx = reinterpret_cast<const long long*>(s->idx); F.f_loc = s->f_loc; F.f_inv = s->f_inv; F.f_lo = s->f_lo; F.f_hi = s->f_hi;
-    F.wpack = static_cast<const __bf16*>(s->wpack); F.bias = s->bias; F.head = nullptr;
-    F.xs_in = static_cast<const __bf16*>(s->xs_in);
-    if (F.xs_in) { F.idx = nullptr; F.f_loc = F.f_inv = F.f_lo = F.f_hi = nullptr; }       // everything was applied by pnr_mlp_gather
-    F.xs = F.xs_in ? nullptr : static_cast<__bf16*>(s->xs); F.h1 = static_cast<__bf16*>(s->h1); F.h2 = static_cast<__bf16*>(s->h2);
-    F.B = B; F.first_net = 0; F.n_nets = kMlpNets;
-    F.rec_actions = s->actions; F.rec_logp = s->logp_old; F.rec_mean = s->mean_old; F.rec_log_std = s->log_std_old;
-    F.rec_adv = s->adv; F.rec_vtarg = s->value_target; F.rec_values = s->value_old;
-    F.kl_coeff = s->kl_coeff; F.ent_coeff = s->entropy_coeff;
-    F.clip = s->clip_param; F.vf_clip = s->vf_clip_param; F.vf_coeff = s->vf_loss_coeff;
-    F.g_head = s->g_head; F.partials = s->partials; F.adam_step = s->adam_step;
-    F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
-    hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, thr, 0, st, F);
-    if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
-        hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
-                           s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
-    MlpWgradParams Wp;
-    Wp.g_head = s->g_head; Wp.xs = F.xs_in ? F.xs_in : F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
-    Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), thr, 0, st, Wp);
-    if (s->flat_grad)
-        hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((kMlpNets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad);
-    else
-        mlp_launch_adam(s, s->slabs, (int)slices, 1.0f, st, prow);      // + the loss means, in the same launch
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
-
-int pnr_mlp_adam(const pnr_mlp_step* s, const float* flat_grad, float grad_scale, void* stream)
-{
-    int rc = mlp_step_check(s, "pnr_mlp_adam");
-    if (rc) return rc;
-    if (!flat_grad) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_adam: null gradient");
-    mlp_launch_adam(s, flat_grad, 1, grad_scale, (hipStream_t)stream);
-    HIP_TRY(nullptr, hipGetLastError());
-    return PNR_OK;
-}
 
 int pnr_get_state(pnr_handle h, uint32_t* words_out, void* stream)
 {
@@ -1542,8 +519,8 @@ int pnr_get_dyn_state(pnr_handle h, float* words_out, void* stream)
     if (!h || !words_out) return fail(h, PNR_ERR_INVALID, "pnr_get_dyn_state: null argument");
     if (!h->dyn) return fail(h, PNR_ERR_UNSUPPORTED, "handle is not in dynamics mode");
     DeviceGuard g(h->device);
-    HIP_TRY(h, hipMemcpyAsync(words_out, h->dyn, sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)h->n,
-                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const size_t bytes = sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)h->n;
+    HIP_TRY(h, hipMemcpyAsync(words_out, h->dyn, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PNR_OK;
 }
 
@@ -1554,8 +531,8 @@ int pnr_set_dyn_state(pnr_handle h, const float* words_in, void* stream)
     DeviceGuard g(h->device);
     h->dyn_set = true;
     if (h->kin_set) h->ready = true;
-    HIP_TRY(h, hipMemcpyAsync(h->dyn, words_in, sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)h->n,
-                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const size_t bytes = sizeof(float) * PNR_DYN_STATE_WORDS * (size_t)h->n;
+    HIP_TRY(h, hipMemcpyAsync(h->dyn, words_in, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PNR_OK;
 }
 

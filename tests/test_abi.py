@@ -133,6 +133,17 @@ def test_product_never_imports_oracle():
                 assert "pnr_oracle.h" not in text and "libpnr_oracle" not in text, f
 
 
+def test_product_library_has_no_ablation_switches(hip_lib):
+    """The timing-only ablations (PNR_DIAG, PNR_GRID_CAP*: wrong outputs when set) exist only in a -DPNR_DIAG_BUILD=1 variant:
+    the product library must not read the environment, so it may not even hold such a string."""
+    from pioneer_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    hits = sorted(set(re.findall(rb"PNR_[A-Z_]{3,}", blob)))
+    assert hits == [], hits
+    assert b"getenv" not in blob
+    assert hip_lib.pnr_abi_version() == _lib.ABI_VERSION == 2
+
+
 def test_missing_library_raises(monkeypatch, tmp_path):
     from pioneer_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
