@@ -8,6 +8,13 @@ Pioneer-arm envs IN TOTAL.  At N=1 they all live on one GPU; at N>1 the env axis
 contiguous blocks over the ranks (65 536 / N per GPU, global env ids, no data-path collective — envs
 are independent), so scaling is "strong" and `value` = 65 536 x K / (max over ranks of the wall time).
 
+Timed region: after W warm-up steps, blocks of EXACTLY K steps are enqueued back to back (`repeats` of them, until the series
+lasts >= 60 ms) between barrier + torch.cuda.synchronize() on both sides; `ms_per_step` = max-over-ranks wall time of the series /
+(repeats x K), and HIP events recorded on the launch stream between consecutive blocks give the median block (the roofline's
+duration) and the spread.  `--split 2 --graph 1` steps the batch as TWO handles of n/2 envs (global env ids: the same
+trajectories bit for bit, tests/test_gpu_parity.py) whose launches are independent, each block replayed from a hipGraph; by
+default that form is the `split_streams` leg and the headline is one eager pnr_step launch per step.
+
 Launch: `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no torchrun environment the
 script starts its own N ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
 --master-addr 127.0.0.1 --master-port P bench.py ...` as a child, before anything touches the GPU) and
@@ -39,8 +46,10 @@ BYTES_PER_ENV_STEP = 750   # 24 action + 92 state in + 80 stat
 STEP_IO_BYTES = 24 + 548 + 6   # per env-step regardless of fusion
 STATE_BYTES = 92 + 80          # per env per LAUNCH (a fused rollout keeps state in registers)
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MIN_BLOCK_S = 0.05         # a timed K-step block shorter than this is repeated and the median reported
-REPEATS = 5
+MIN_SERIES_S = 0.06        # the timed K-step block is repeated back to back until the series is at least this long ...
+MIN_REPEATS = 5            # ... and at least this often; `ms_per_step` = series wall time / (repeats x K)
+MAX_REPEATS = 20000
+DYN_COUNTERS = "r03_dyn_sq_counters.json"      # tools/dyn_counters_summary.py (VALU instructions per launch of the dynamics kernel)
 
 
 def parse_args(argv=None):
@@ -60,7 +69,13 @@ def parse_args(argv=None):
                     help="N>1: also time this many envs PER GPU, reported as \"weak_scaling\" (0 = skip)")
     ap.add_argument("--dynamic-leg", type=int, default=1,
                     help="also time dynamics mode with per-env randomisation (BASELINE config[4]) as \"dynamics_randomized\"")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the per-step launches from a hipGraph")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: each timed K-step block is ONE hipGraph replay; 0: eager launches; -1 (default): 0")
+    ap.add_argument("--split", type=int, default=-1,
+                    help="main leg: step the rank's envs as this many handles (contiguous blocks, global env ids: same trajectories, "
+                         "tests/test_gpu_parity.py) whose launches are independent and overlap; -1 (default): 1 (the two-handle form is "
+                         "reported as the `split_streams` leg)")
+    ap.add_argument("--split-leg", type=int, default=1, help="also report the two-handle / two-stream form of the main batch as \"split_streams\"")
     ap.add_argument("--fused-leg", type=int, default=32,
                     help="also report the fused pnr_rollout rate with this many steps per launch (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -272,36 +287,13 @@ def run_rank(args):
     total_envs = args.envs
     env_start, n = shard_range(total_envs, world, rank)      # this rank's block of the global env axis
     T = max(1, args.fused)
-    env = PioneerVectorEnv(n, device=dev, seed=0, env_id_offset=env_start,
-                           simulation_config=SimulationConfig(gravity=args.gravity),
-                           engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
-                                                      obs_layout=args.obs_layout,
-                                                      action_layout=args.action_layout, mode=args.mode,
-                                                      randomize=args.randomize))
-    env.reset()
-
-    # synthetic inputs, resident in HBM before the timed region
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    amax = torch.from_numpy(env.a_max).to(dev)
-    n_act = max(16, T, args.fused_leg if (T == 1 and args.mode == "kinematic") else 0)
-    if args.action_layout == "env_major":
-        acts = (torch.rand(n_act, n, 6, generator=g, device=dev) * 2 - 1) * amax
-    else:
-        acts = (torch.rand(n_act, 6, n, generator=g, device=dev) * 2 - 1) * amax[:, None]
-    ring = max(args.ring, T)
-    ring -= ring % T
-    if T == 1 and args.fused_leg > 1 and args.mode == "kinematic":
-        ring = max(ring, args.fused_leg)
-        ring -= ring % args.fused_leg
-    obs = torch.empty((ring,) + tuple(env.obs_shape), dtype=torch.float32, device=dev)
-    rew = torch.empty((ring, n), dtype=torch.float32, device=dev)
-    done = torch.empty((ring, n), dtype=torch.uint8, device=dev)
-    trunc = torch.empty((ring, n), dtype=torch.uint8, device=dev)
-
-    lib, h = env.lib, env._h
     stream = torch.cuda.current_stream(dev)
-    sp = C.c_void_p(stream.cuda_stream)
-    P = lambda t, i: C.c_void_p(t[i].data_ptr())  # noqa: E731
+    from pioneer_amd.config import PioneerKinematicConfig, to_c_config
+    kc = _lib.PnrConstants()
+    _lib.check(_lib.load_library().pnr_get_constants(to_c_config(PioneerKinematicConfig(), SimulationConfig(), EngineConfig()), kc))
+    amax = torch.tensor(list(kc.a_max[:]), dtype=torch.float32, device=dev)      # action_space.high, pioneer_knm_env.py:58, :72
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    V = C.c_void_p
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -316,88 +308,219 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed_blocks(run, K):
-        """EXACTLY K steps between barrier + synchronize on both sides, wall time = max over ranks.  A block
-        shorter than MIN_BLOCK_S is repeated (REPEATS blocks in all) and the MEDIAN block is reported.
-        Returns (median wall s, median HIP-event ms of this rank, repeats, all wall times)."""
-        walls, evs = [], []
-        reps = 1
-        while len(walls) < reps:
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
-            barrier()
-            t0 = time.perf_counter()
-            ev0.record(stream)       # torch's current stream == the stream pnr_step launches on
-            run(K)
-            ev1.record(stream)
-            barrier()
-            walls.append(max_over_ranks(time.perf_counter() - t0))
-            evs.append(ev0.elapsed_time(ev1))
-            if len(walls) == 1 and walls[0] < MIN_BLOCK_S:     # the same decision on every rank: walls[] is all-reduced
-                reps = REPEATS
-        return statistics.median(walls), statistics.median(evs), reps, walls
+    def looked_up(path, key_path):
+        """A counter value taken in an EARLIER rocprofv3 --pmc pass (profiles/): returned only while the sources of the env
+        kernels are the ones that pass ran on (`csrc_sha16`, pioneer_amd._lib.source_fingerprint); else (None, why)."""
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", path)))
+        except Exception as exc:
+            return None, f"profiles/{path}: {type(exc).__name__}"
+        have, want = doc.get("csrc_sha16"), _lib.source_fingerprint()
+        if have != want:
+            return None, f"stale: kernel changed since the counter pass (profiles/{path} was taken on sources {have}, this build is {want})"
+        node = doc
+        for k in key_path:
+            if not isinstance(node, dict) or k not in node:
+                return None, f"profiles/{path} has no entry {'/'.join(key_path)}"
+            node = node[k]
+        return node, f"profiles/{path} (rocprofv3 --pmc passes on these sources, {want}; looked up, NOT measured in this run)"
 
-    def timed(T, K, W):
-        """K env-steps (after W warm-up steps) with T steps per kernel launch."""
-        if T == 1:
-            calls = [(P(acts, i % n_act), P(obs, i % ring), P(rew, i % ring), P(done, i % ring), P(trunc, i % ring))
-                     for i in range(math.lcm(n_act, ring))]
+    def dyn_valu_roofline(avg_launch_ms, envs):
+        cnt, src = looked_up(DYN_COUNTERS, ["kernels", "dyn_step_kernel<1,1,1,0>", "valu_roofline"])
+        if cnt is None:
+            return {"bound": "valu", "achieved": None, "frac": None, "source": src}
+        instr = cnt["valu_wave_instructions_per_dispatch"] * (envs / 65536.0)
+        simds, clock = 256 * 4, 2.4e9
+        ach = instr / (avg_launch_ms * 1e-3)
+        return {"bound": "valu", "achieved": ach / 1e9, "peak": simds * clock / 2 / 1e9, "unit": "G wave-instructions/s",
+                "frac": ach / (simds * clock / 2), "frac_of_single_wave_issue": cnt["frac_of_single_wave_issue"],
+                "source": "VALU wave-instructions per 65 536-env launch from " + src + "; duration = this run's HIP events; peak = one "
+                          "wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz; one wave per SIMD can issue one per 4"}
 
-            def run_eager(k, spx=sp):
-                m = len(calls)
-                for i in range(k):
-                    a, o, r, d, tr = calls[i % m]
-                    rc = lib.pnr_step(h, a, o, r, d, tr, None, spx)
+    def timed_series(block, K):
+        """The contract's timed region: EXACTLY K steps per block, barrier + synchronize on both sides of the series, wall
+        time = max over ranks.  A K-step block is short (20 steps = 0.2 ms), so the block is repeated back to back —
+        `repeats` times, until the series lasts MIN_SERIES_S — with a HIP event on the launch stream between consecutive
+        blocks: `ms_per_step` = series wall time / (repeats x K), and the per-block event times give the median block
+        (the roofline's duration) and the spread.  Returns a dict."""
+        barrier()
+        t0 = time.perf_counter()
+        block(K)
+        torch.cuda.synchronize(dev)
+        est = max_over_ranks(time.perf_counter() - t0)           # the same decision on every rank
+        reps = int(min(MAX_REPEATS, max(MIN_REPEATS, math.ceil(MIN_SERIES_S / max(est, 1e-7)))))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        evs[0].record(stream)            # torch's current stream == the stream the launches (or their fork / join) are ordered on
+        for r in range(reps):
+            block(K)
+            evs[r + 1].record(stream)
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        bl = sorted(evs[r].elapsed_time(evs[r + 1]) for r in range(reps))
+        return {"wall_s": wall, "repeats": reps, "block_s": wall / reps, "block_ev_ms": statistics.median(bl),
+                "block_ev_ms_p10_p90": [bl[int(0.1 * (reps - 1))], bl[int(0.9 * (reps - 1))]],
+                "block_ev_spread": (bl[int(0.9 * (reps - 1))] - bl[int(0.1 * (reps - 1))]) / statistics.median(bl)}
+
+    class StepLeg:
+        """nl envs of this rank (global ids from id_off) stepped by pnr_step / pnr_rollout into an obs ring, as `parts`
+        handles over contiguous blocks of the env axis.  parts > 1: each handle's launches go to a stream of its own
+        (forked from and joined to the launch stream per block), so launch t of one part does not wait for launch t of the
+        other; graph=1: a K-step block is captured once in a hipGraph and replayed."""
+
+        def __init__(self, nl, id_off, parts=1, graph=0, Tl=1, ring=32, n_act=16, sim=None, **engine_kw):
+            self.nl, self.parts, self.graph, self.T = nl, parts, graph, Tl
+            eng = dict(max_episode_steps=500, auto_reset=True, obs_layout=args.obs_layout, action_layout=args.action_layout)
+            eng.update(engine_kw)
+            if parts > 1 and (args.obs_layout != "env_major" or args.action_layout != "env_major"):
+                raise SystemExit("--split needs env-major observations and actions (a part's rows are one contiguous span)")
+            self.bounds = [shard_range(nl, parts, i) for i in range(parts)]
+            self.envs = [PioneerVectorEnv(c, device=dev, seed=0, env_id_offset=id_off + o, simulation_config=sim,
+                                          engine_config=EngineConfig(**eng)) for o, c in self.bounds]
+            for e in self.envs:
+                e.reset()
+            e0 = self.envs[0]
+            self.lib = e0.lib
+            fm_o, fm_a = e0.feature_major_obs, e0.feature_major_act
+            n_act = max(n_act, Tl)
+            ring = max(ring, Tl)
+            ring -= ring % Tl
+            self.ring, self.n_act = ring, n_act
+            self.acts = (torch.rand((n_act, 6, nl) if fm_a else (n_act, nl, 6), generator=g, device=dev) * 2 - 1) * \
+                (amax[:, None] if fm_a else amax)
+            self.obs = torch.empty((ring, 137, nl) if fm_o else (ring, nl, 137), dtype=torch.float32, device=dev)
+            self.rew = torch.empty((ring, nl), dtype=torch.float32, device=dev)
+            self.done = torch.empty((ring, nl), dtype=torch.uint8, device=dev)
+            self.trunc = torch.empty((ring, nl), dtype=torch.uint8, device=dev)
+            self.streams = [stream] if parts == 1 else [torch.cuda.Stream(dev) for _ in range(parts)]
+            self._graphs = {}
+            # per part: the argument tuples of one pass over the ring
+            self.calls = []
+            for o, c in self.bounds:
+                if Tl == 1:
+                    rows = [(V(self.acts[i % n_act, o:].data_ptr()) if not fm_a else V(self.acts[i % n_act].data_ptr()),
+                             V(self.obs[i % ring, o:].data_ptr()) if not fm_o else V(self.obs[i % ring].data_ptr()),
+                             V(self.rew[i % ring, o:].data_ptr()), V(self.done[i % ring, o:].data_ptr()),
+                             V(self.trunc[i % ring, o:].data_ptr())) for i in range(math.lcm(n_act, ring))]
+                else:
+                    nslots = ring // Tl
+                    # operand shapes must cover what one launch touches: Tl action slices, Tl output slices per slot
+                    assert self.acts.shape[0] >= Tl and nslots >= 1 and nslots * Tl <= self.obs.shape[0] == self.rew.shape[0], \
+                        (self.acts.shape, self.obs.shape, Tl)
+                    rows = [(V(self.acts[0].data_ptr()), V(self.obs[sl * Tl].data_ptr()), V(self.rew[sl * Tl].data_ptr()),
+                             V(self.done[sl * Tl].data_ptr()), V(self.trunc[sl * Tl].data_ptr())) for sl in range(nslots)]
+                self.calls.append(rows)
+
+        def _launch(self, K, sps):
+            """K steps of every part, enqueued (launches interleaved over the parts)."""
+            lib, Tl = self.lib, self.T
+            m = len(self.calls[0])
+            hs = [e._h for e in self.envs]
+            for i in range(K // Tl):
+                for pi in range(self.parts):
+                    a, o, r, d, tr = self.calls[pi][i % m]
+                    rc = lib.pnr_step(hs[pi], a, o, r, d, tr, None, sps[pi]) if Tl == 1 else \
+                        lib.pnr_rollout(hs[pi], Tl, a, o, r, d, tr, sps[pi])
                     if rc:
-                        _lib.check(rc, h)
+                        _lib.check(rc, hs[pi])
 
-            run = run_eager
-            if args.graph:
-                # the step loop is launch-bound on the host: capture one pass over the obs ring
-                # (len(calls) launches of pnr_step) in a hipGraph and replay it
-                m = len(calls)
-                run_eager(m)
+        def _fork_launch_join(self, K, main):
+            if self.parts == 1:
+                self._launch(K, [V(main.cuda_stream)])
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            for st in self.streams:
+                st.wait_event(ev)
+            self._launch(K, [V(st.cuda_stream) for st in self.streams])
+            for st in self.streams:
+                e2 = torch.cuda.Event()
+                e2.record(st)
+                main.wait_event(e2)
+
+        def block(self, K):
+            """Enqueue exactly K steps, ordered after everything on the launch stream and before whatever follows on it."""
+            assert K % self.T == 0
+            if not self.graph:
+                self._fork_launch_join(K, stream)
+                return
+            gr = self._graphs.get(K)
+            if gr is None:
                 torch.cuda.synchronize(dev)
-                g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_):
-                    run_eager(m, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                gr = torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream(dev)
+                with torch.cuda.stream(cap):
+                    gr.capture_begin()
+                    self._fork_launch_join(K, torch.cuda.current_stream(dev))
+                    gr.capture_end()
+                self._graphs[K] = gr
+            gr.replay()
 
-                def run(k):   # noqa: F811
-                    assert k % m == 0, f"--steps/--warmup must be multiples of {m} with --graph"
-                    for _ in range(k // m):
-                        g_.replay()
-                K -= K % m
-                W = max(m, W - W % m)
-        else:
-            nslots = ring // T
-            # operand shapes must cover what one launch touches: T action slices, T output slices per slot
-            assert acts.shape[0] >= T and nslots >= 1 and nslots * T <= obs.shape[0] == rew.shape[0] == done.shape[0] == trunc.shape[0], \
-                (acts.shape, obs.shape, T)
-            calls = [(P(acts, 0), P(obs, s * T), P(rew, s * T), P(done, s * T), P(trunc, s * T)) for s in range(nslots)]
-            K -= K % T
-            W -= W % T
+        def close(self):
+            self._graphs.clear()
+            for e in self.envs:
+                e.close()
 
-            def run(k):
-                for i in range(k // T):
-                    a, o, r, d, tr = calls[i % nslots]
-                    rc = lib.pnr_rollout(h, T, a, o, r, d, tr, sp)
-                    if rc:
-                        _lib.check(rc, h)
-        run(W)
-        el, ev_ms, reps, walls = timed_blocks(run, K)
-        return el, ev_ms, K, W, reps, walls
+    def run_leg(leg, K, W):
+        K -= K % leg.T
+        W -= W % leg.T
+        if W > 0:
+            leg.block(W)
+        return timed_series(leg.block, K), K, W
 
-    elapsed, ev_ms, K, W, repeats, walls = timed(T, args.steps, args.warmup)
+    split = args.split
+    if split < 0:
+        split = 1
+    use_graph = args.graph if args.graph >= 0 else 0
+    simc = SimulationConfig(gravity=args.gravity)
+    main_leg = StepLeg(n, env_start, parts=split, graph=use_graph, Tl=T, ring=args.ring, sim=simc, mode=args.mode, randomize=args.randomize)
+    ts, K, W = run_leg(main_leg, args.steps, args.warmup)
+    elapsed, repeats = ts["block_s"], ts["repeats"]
     value = float(total_envs) * K / elapsed
+    single = None
+    if split > 1 or use_graph:
+        # the same batch as ONE eager launch per step: the form whose kernel duration rocprofv3 can check directly
+        main_leg.close()
+        sl = StepLeg(n, env_start, parts=1, graph=0, Tl=T, ring=args.ring, sim=simc, mode=args.mode, randomize=args.randomize)
+        s1, K1, _ = run_leg(sl, args.steps, args.warmup)
+        lms = s1["block_ev_ms"] / (K1 // T)
+        ab = n * (STEP_IO_BYTES * T + STATE_BYTES)
+        single = {"value": float(total_envs) * K1 / s1["block_s"], "unit": "env-steps/s", "repeats": s1["repeats"], "ms_per_step": s1["block_s"] / K1 * 1e3,
+                  "avg_launch_ms": lms, "achieved_GBps": ab / (lms * 1e-3) / 1e9, "frac": ab / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  "note": "one handle, one eager pnr_step launch per step: avg_launch_ms is the kernel duration a rocprofv3 --kernel-trace of "
+                          "`bench.py --split 1` shows (profiles/)"}
+        sl.close()
+    else:
+        main_leg.close()
+
+    # VERDICT r02 #3: the same batch as TWO handles of n/2 envs whose launches are independent (two streams, captured per
+    # 32-step block in a hipGraph), meant to run launch t of one half under the dependent-launch boundary of the other
+    split_leg = None
+    if split == 1 and T == 1 and args.mode == "kinematic" and args.split_leg and n >= 2 * 4096 and \
+            args.obs_layout == "env_major" and args.action_layout == "env_major":
+        sl = StepLeg(n, env_start, parts=2, graph=1, Tl=1, ring=args.ring, sim=simc)
+        s2, K2, _ = run_leg(sl, 32, 64)
+        sl.close()
+        ms2 = s2["block_ev_ms"] / K2
+        ab = n * BYTES_PER_ENV_STEP
+        split_leg = {"value": float(total_envs) * K2 / s2["block_s"], "unit": "env-steps/s", "handles_per_gpu": 2, "steps_per_graph_replay": K2,
+                     "repeats": s2["repeats"], "ms_per_step": s2["block_s"] / K2 * 1e3, "avg_step_ms": ms2,
+                     "achieved_GBps": ab / (ms2 * 1e-3) / 1e9, "frac": ab / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "note": "two handles of n/2 envs (global env ids: bit-identical outputs, test_split_batch_on_two_streams_equals_one_launch_"
+                             "bit_for_bit), launches on two streams inside 32-step hipGraph replays; avg_step_ms = both launches of a step. "
+                             "Not the headline: the gain over one launch per step is 0-7 % by graph size and box (DESIGN.md section 3)"}
 
     fused = None
     if T == 1 and args.fused_leg > 1 and args.mode == "kinematic":
-        Tf = min(args.fused_leg, ring)
-        fel, fev, fK, _, freps, _ = timed(Tf, max(Tf, args.steps), max(Tf, args.warmup))
-        fl_ms = fev / (fK // Tf)
+        Tf = args.fused_leg
+        fl = StepLeg(n, env_start, parts=1, graph=0, Tl=Tf, ring=max(args.ring, Tf), n_act=Tf, sim=simc)
+        fs, fK, _ = run_leg(fl, max(Tf, args.steps), max(Tf, args.warmup))
+        fl.close()
+        fl_ms = fs["block_ev_ms"] / (fK // Tf)
         fb = n * (STEP_IO_BYTES * Tf + STATE_BYTES)
-        fused = {"value": float(total_envs) * fK / fel, "unit": "env-steps/s", "steps_per_launch": Tf, "steps": fK,
-                 "repeats": freps, "ms_per_step": fel / fK * 1e3, "avg_launch_ms": fl_ms,
+        fused = {"value": float(total_envs) * fK / fs["block_s"], "unit": "env-steps/s", "steps_per_launch": Tf, "steps": fK,
+                 "repeats": fs["repeats"], "ms_per_step": fs["block_s"] / fK * 1e3, "avg_launch_ms": fl_ms,
                  "algorithmic_bytes_per_launch": fb, "achieved_GBps": fb / (fl_ms * 1e-3) / 1e9,
                  "frac": fb / (fl_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  "note": "pnr_rollout: same kernel, T steps per launch with open-loop actions; state stays in registers"}
@@ -405,50 +528,24 @@ def run_rank(args):
     def side_leg(nl, id_off, k, warm, note, bytes_per_env_step=BYTES_PER_ENV_STEP, sim=None, rollout_T=0, **engine_kw):
         """pnr_step on a separate env batch of nl envs per GPU: wall time is the max over ranks between
         barriers, avg_launch_ms is rank 0's HIP-event timing."""
-        lenv = PioneerVectorEnv(nl, device=dev, seed=0, env_id_offset=id_off, simulation_config=sim,
-                                engine_config=EngineConfig(max_episode_steps=500, auto_reset=True,
-                                                           obs_layout=args.obs_layout, action_layout=args.action_layout,
-                                                           **engine_kw))
-        lenv.reset()
         lring = 8 if nl >= 131072 else 32
-        lacts = (torch.rand((4,) + tuple(lenv.action_shape), generator=g, device=dev) * 2 - 1) * \
-            (amax if args.action_layout == "env_major" else amax[:, None])
-        lobs = torch.empty((lring,) + tuple(lenv.obs_shape), dtype=torch.float32, device=dev)
-        lrew = torch.empty((lring, nl), dtype=torch.float32, device=dev)
-        ldone = torch.empty((lring, nl), dtype=torch.uint8, device=dev)
-        ltr = torch.empty((lring, nl), dtype=torch.uint8, device=dev)
-        lh = lenv._h
-        lcalls = [(P(lacts, i % 4), P(lobs, i % lring), P(lrew, i % lring), P(ldone, i % lring), P(ltr, i % lring))
-                  for i in range(lring)]
-
-        def lrun(kk):
-            for i in range(kk):
-                a, o, r, d, tr = lcalls[i % lring]
-                rc = lib.pnr_step(lh, a, o, r, d, tr, None, sp)
-                if rc:
-                    _lib.check(rc, lh)
-        lrun(warm)
-        el, lev, lreps, _ = timed_blocks(lrun, k)
-        lms = lev / k
+        leg = StepLeg(nl, id_off, parts=1, graph=0, Tl=1, ring=lring, n_act=4, sim=sim, **engine_kw)
+        st, k, _ = run_leg(leg, k, warm)
+        lms = st["block_ev_ms"] / k
         roll = None
         if rollout_T > 1 and lring >= rollout_T:
             # the same steps as ONE pnr_rollout launch per rollout_T steps (open-loop actions)
-            racts = (torch.rand((rollout_T,) + tuple(lenv.action_shape), generator=g, device=dev) * 2 - 1) * \
-                (amax if args.action_layout == "env_major" else amax[:, None])
-            rcall = lambda: _lib.check(lib.pnr_rollout(lh, rollout_T, P(racts, 0), P(lobs, 0), P(lrew, 0), P(ldone, 0), P(ltr, 0), sp), lh)  # noqa: E731
-            for _ in range(3):
-                rcall()
-            reps = max(4, k // rollout_T)
-            rel, _, rreps, _ = timed_blocks(lambda kk: [rcall() for _ in range(kk)], reps)
-            roll = {"steps_per_launch": rollout_T, "steps": reps * rollout_T, "repeats": rreps,
-                    "ms_per_step": rel / (reps * rollout_T) * 1e3,
-                    "value": float(nl) * world * reps * rollout_T / rel, "unit": "env-steps/s"}
-        lenv.close()
+            leg.close()
+            leg = StepLeg(nl, id_off, parts=1, graph=0, Tl=rollout_T, ring=lring, n_act=rollout_T, sim=sim, **engine_kw)
+            rs, rk, _ = run_leg(leg, max(4 * rollout_T, k - k % rollout_T), 3 * rollout_T)
+            roll = {"steps_per_launch": rollout_T, "steps": rk, "repeats": rs["repeats"], "ms_per_step": rs["block_s"] / rk * 1e3,
+                    "value": float(nl) * world * rk / rs["block_s"], "unit": "env-steps/s"}
+        leg.close()
         if roll:
             note = note + "; `rollout`: pnr_rollout, the steps looped inside one launch"
-        return {**({"rollout": roll} if roll else {}), "envs_per_gpu": nl, "steps": k, "repeats": lreps,
-                "avg_launch_ms": lms, "ms_per_step": el / k * 1e3,
-                "value": float(nl) * world * k / el, "unit": "env-steps/s",
+        return {**({"rollout": roll} if roll else {}), "envs_per_gpu": nl, "steps": k, "repeats": st["repeats"],
+                "avg_launch_ms": lms, "ms_per_step": st["block_s"] / k * 1e3,
+                "value": float(nl) * world * k / st["block_s"], "unit": "env-steps/s",
                 "env_steps_per_s_per_gpu": nl / (lms * 1e-3),
                 "achieved_GBps": bytes_per_env_step * nl / (lms * 1e-3) / 1e9,
                 "frac": bytes_per_env_step * nl / (lms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "note": note}
@@ -475,19 +572,7 @@ def run_rank(args):
         dynamic["total_envs"] = total_envs
         dynamic["value"] = float(total_envs) / (dynamic["ms_per_step"] * 1e-3)
         # the kernel is VALU-issue-bound, not HBM-bound: instructions from the committed SQ-counter pass, time from this run
-        try:
-            cnt = json.load(open(os.path.join(ROOT, "profiles", "r02_e_dyn_sq_counters.json")))["kernels"]["dyn_step_kernel<1,1,1,0>"]
-            instr = cnt["valu_roofline"]["valu_wave_instructions_per_dispatch"] * (dcnt / 65536.0)
-            simds, clock = 256 * 4, 2.4e9
-            ach = instr / (dynamic["avg_launch_ms"] * 1e-3)
-            dynamic["roofline"] = {"bound": "valu", "achieved": ach / 1e9, "peak": simds * clock / 2 / 1e9, "unit": "G wave-instructions/s",
-                                   "frac": ach / (simds * clock / 2),
-                                   "frac_of_single_wave_issue": cnt["valu_roofline"]["frac_of_single_wave_issue"],
-                                   "source": "VALU wave-instructions per 65 536-env launch from profiles/r02_e_dyn_sq_counters.json (rocprofv3 --pmc "
-                                             "SQ_INSTS_VALU, not this run), duration = this run's HIP events; peak = one wave64 VALU instruction "
-                                             "per 2 cycles per SIMD at 2.4 GHz; one wave per SIMD can issue one per 4"}
-        except Exception:
-            pass
+        dynamic["roofline"] = dyn_valu_roofline(dynamic["avg_launch_ms"], dcnt)
         if "rollout" in dynamic:
             dynamic["rollout"]["value"] = float(total_envs) / (dynamic["rollout"]["ms_per_step"] * 1e-3)
     id_base += total_envs
@@ -508,7 +593,7 @@ def run_rank(args):
         penv = PioneerVectorEnv(cnt, device=dev, seed=0, env_id_offset=start,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=args.mode))
         mbs = max(1, min(global_mbs // world, 32 * cnt))      # this rank's share of every global minibatch
-        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, amp_bf16=True)
+        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs)
         tr = PPOTrainer(penv, pcfg, use_graph=True)
         tr.train(); tr.train()                       # warm-up: eager iteration, then the graph-captured one
         barrier()
@@ -518,9 +603,10 @@ def run_rank(args):
         tp = max_over_ranks(time.perf_counter() - tp)
         graphed = {"sampling": tr._graph is not None,
                    "learner": ("hip kernels: pnr_mlp_train_step, 3 launches per update, no graph needed" if tr.learner.hip
-                               else ("graph" if tr.learner._graph is not None else "eager")),
-                   "learner_split_around_allreduce": bool(tr.learner._split) or (tr.learner.hip and world > 1)}
+                               else "torch autograd, eager"),
+                   "learner_split_around_allreduce": bool(tr.learner.hip and world > 1)}
         finite = all(math.isfinite(float(r[k])) for r in rs for k in ("kl", "total_loss"))
+        hip_learner = bool(tr.learner.hip)
         penv.close()
         del tr
         torch.cuda.empty_cache()
@@ -529,8 +615,10 @@ def run_rank(args):
                 "num_sgd_iter": 4, "sgd_minibatch_size": mbs * world, "sgd_minibatch_size_per_rank": mbs,
                 "sgd_updates_per_iter": 4 * ((32 * cnt) // mbs), "mlp_dtype": "bf16",
                 "hip_graph": graphed, "iters": iters, "losses_finite": finite,
-                "grad_allreduce": ({"backend": backend, "world_size": world, "bytes": 4 * 205581,
-                                    "per": "minibatch, one flat bucket"} if world > 1 else None),
+                "grad_allreduce": ({"backend": backend, "world_size": world,
+                                    "bytes": 4 * (int(_lib.load_library().pnr_mlp_grad_floats()) if hip_learner else 205581),
+                                    "per": "minibatch, one flat bucket" + (" (the kernels' padded layout)" if hip_learner else "")}
+                                   if world > 1 else None),
                 "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                 "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
 
@@ -538,23 +626,15 @@ def run_rank(args):
         if rank != 0:
             return
         launches = K // T
-        launch_ms = ev_ms / launches
-        # per launch: T steps of action/obs/reward/flags traffic + ONE state read and write
+        step_ms = ts["block_ev_ms"] / launches            # per pass over the rank's batch (all parts), median block, HIP events
+        # per pass: T steps of action/obs/reward/flags traffic + ONE state read and write per env
         algo_bytes = n * (STEP_IO_BYTES * T + STATE_BYTES)
-        achieved = algo_bytes / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            try:
-                rec = json.load(open(prof))
-                key = f"{args.mode}:{args.obs_layout}:{n}:{T}"
-                if key in rec:
-                    traffic = rec[key].get("hbm_bytes_per_launch")
-                    traffic_source = ("profiles/pmc_traffic.json (" + str(rec[key].get("profile", "earlier rocprofv3 --pmc passes")) +
-                                      "; looked up, NOT measured in this run)")
-            except Exception:
-                traffic = None
+        achieved = algo_bytes / (step_ms * 1e-3) / 1e9
+        traffic, traffic_source = looked_up("pmc_traffic.json", [f"{args.mode}:{args.obs_layout}:{n}:{T}", "hbm_bytes_per_launch"])
         kname = "pnr::step_kernel" if args.mode == "kinematic" else "pnr::dyn_step_kernel"
+        variant = ("one pnr_step launch per step" if T == 1 else f"one pnr_rollout launch per {T} steps") if split == 1 else \
+            (f"{split} handles of {n // split} envs (contiguous blocks, global env ids), their pnr_step launches independent of each other")
+        variant += "; each timed block is one hipGraph replay" if use_graph else "; eager launches"
         out = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "repeats": repeats, "ms_per_step": elapsed / K * 1e3,
@@ -565,15 +645,27 @@ def run_rank(args):
                        "envs_per_gpu": n, "total_envs": total_envs, "mode": args.mode,
                        "randomize": bool(args.randomize), "gravity": args.gravity,
                        "obs_layout": args.obs_layout, "action_layout": args.action_layout,
-                       "steps_per_launch": T, "hip_graph": bool(args.graph and T == 1), "obs_ring_slices": ring,
-                       "parallelism": f"env-shard x{world}", "block_wall_s": walls},
+                       "steps_per_launch": T, "variant": variant, "handles_per_gpu": split, "hip_graph": bool(use_graph),
+                       "obs_ring_slices": main_leg.ring, "parallelism": f"env-shard x{world}",
+                       "timed_region": f"{repeats} back-to-back blocks of exactly {K} steps between barrier + synchronize; "
+                                       "ms_per_step = wall / (repeats x steps)",
+                       "series_wall_s": ts["wall_s"], "block_event_ms_median": ts["block_ev_ms"],
+                       "block_event_ms_p10_p90": ts["block_ev_ms_p10_p90"], "block_event_spread_p10_p90": ts["block_ev_spread"]},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "avg_launch_ms": launch_ms,
-                         "timing": "HIP events on the launch stream around the timed K-step block / launches (rank 0; median block)"},
+                         "algorithmic_bytes_per_launch": algo_bytes // split, "launches_per_step": split,
+                         "algorithmic_bytes_per_step": algo_bytes,
+                         "avg_launch_ms": step_ms,
+                         "timing": "HIP events on the launch stream between consecutive K-step blocks (rank 0; median block) / steps per block"
+                                   + ("; the step's launches overlap, so avg_launch_ms is the time per STEP (all its launches) and the kernel "
+                                      "durations of a rocprofv3 trace (which serialises dispatches) do not add up to it: `single_launch` is the "
+                                      "same batch as one launch per step, whose duration the trace shows" if split > 1 else "")},
         }
+        if single:
+            out["roofline"]["single_launch"] = single
+        if split_leg:
+            out["split_streams"] = split_leg
         if fused:
             out["fused_rollout"] = fused
         if large:
@@ -632,7 +724,6 @@ def run_rank(args):
                 rc = 5
     emit(ppo_loop, ppo_large)
 
-    env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

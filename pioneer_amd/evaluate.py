@@ -14,7 +14,7 @@ from .ppo import ActorCritic, MeanStdFilter, NoFilter, PPOConfig
 def load_policy(checkpoint: str, device):
     """(model, obs filter, PPOConfig) from a PPOTrainer.save() file."""
     ck = torch.load(checkpoint, map_location=device, weights_only=True)
-    cfg = PPOConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in ck["cfg"].items()})
+    cfg = PPOConfig.from_dict(ck["cfg"])
     model = ActorCritic(cfg).to(device)
     model.load_state_dict(ck["model"])
     model.eval()
@@ -46,7 +46,7 @@ def evaluate(checkpoint: str, episodes: int = 3, max_episode_steps: int = 500, g
         total, steps, done, info = 0.0, 0, False, {}
         while not done:
             x = filt(torch.as_tensor(obs, dtype=torch.float32, device=device).unsqueeze(0))
-            mean, log_std, _ = model(x, cfg.amp_bf16)
+            mean, log_std, _ = model(x)          # one env: the float32 master weights through torch
             act = mean if deterministic else mean + torch.exp(log_std) * torch.randn(mean.shape, generator=gen, device=device)
             if cfg.clip_actions:
                 act = torch.maximum(torch.minimum(act, a_max), -a_max)

@@ -46,10 +46,12 @@ def train(results_dir: str,
     # the engine's own options: as given, or — dynamics mode — the inertia-scaled motor (omega = 20 rad/s, zeta = 1 on every
     # joint: with plain torque gains PPO does not learn the task); TimeLimit(500) and auto-reset as
     # the reference's prepare_env wraps it (pioneer_knm_train.py:27)
-    import dataclasses
-    engine = engine_config or (EngineConfig(mode="dynamic", pd_kp=400.0, pd_kd=40.0, pd_inertia_scaled=True) if mode == "dynamic"
-                               else EngineConfig())
-    engine = dataclasses.replace(engine, max_episode_steps=500, auto_reset=True)
+    # A caller's engine_config is used AS GIVEN (its max_episode_steps / auto_reset included; auto_reset must be on: the
+    # sampler never resets by hand); the defaults built here carry TimeLimit(500) and auto-reset.
+    engine = engine_config or (EngineConfig(mode="dynamic", pd_kp=400.0, pd_kd=40.0, pd_inertia_scaled=True, max_episode_steps=500,
+                                            auto_reset=True) if mode == "dynamic" else EngineConfig(max_episode_steps=500, auto_reset=True))
+    if not engine.auto_reset:
+        raise AssertionError("train(): engine_config.auto_reset must be True (the sampler relies on the in-kernel auto-reset)")
     mode = engine.mode
     rank, local_rank, world = pdist.world_info()
     if os.environ.get("PNR_DIST_BACKEND") == "gloo":        # rehearsal: ranks may share the visible GPUs
@@ -74,7 +76,7 @@ def train(results_dir: str,
         # The entropy schedule keeps the reference's LENGTH IN ITERATIONS: 1 M timesteps of 8 000-sample batches
         # = 125 iterations there (pioneer_knm_train.py:37-40, :62); left at 1 M timesteps it would be over after
         # 8 of these 131 072-sample iterations (2 at 16 384 envs).
-        cfg = ppo_config or PPOConfig(num_sgd_iter=4, sgd_minibatch_size=max(1, 32768 // world), amp_bf16=True,   # 32 768 samples per GLOBAL minibatch
+        cfg = ppo_config or PPOConfig(num_sgd_iter=4, sgd_minibatch_size=max(1, 32768 // world),   # 32 768 samples per GLOBAL minibatch
                                       entropy_decay_steps=125 * 32 * total_envs)
         ent_rng = np.random.RandomState(cfg.seed + 7919 * trial)
         cfg = PPOConfig(**{**cfg.__dict__, "entropy_coeff_start": sample_entropy_start(ent_rng),
@@ -96,6 +98,10 @@ def train(results_dir: str,
         if rank == 0:
             with open(os.path.join(tdir, "params.json"), "w") as f:
                 json.dump({"env": "Pioneer-v1", "env_config": ENV_CONFIG, "mode": mode, "num_envs": total_envs,
+                           "max_episode_steps": engine.max_episode_steps,
+                           # deliberate deviation when no PPOConfig is given: the reference's entropy schedule ends after 1 M
+                           # timesteps = 125 of ITS iterations; the default here keeps the 125 iterations (see above)
+                           "entropy_decay_steps_reference": 1_000_000,
                            **{k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()}}, f, indent=2)
         t0 = time.time()
         for it in range(1, training_iterations + 1):

@@ -1,15 +1,21 @@
 """Thin PyTorch-ROCm PPO host driver.
 
 Replaces what RLlib's PPOTrainer + rollout workers do for pioneer/launch/pioneer_knm_train.py:
-the sampling loop calls ``env.vector_step`` with device-resident tensors (no Ray object store,
-no host copies), the learner is data-parallel over GPUs with ONE flat gradient all-reduce per
-minibatch (RCCL over xGMI).  Hyper-parameter names and defaults follow the reference's config
-dict (pioneer_knm_train.py:45-67) and the RLlib-0.8.x PPO defaults it did not override
-(SURVEY.md Appendix D).  Works on CPU tensors too (gloo tests use synthetic rollouts).
+the sampling loop steps the env with device-resident tensors (no Ray object store, no host copies),
+the learner is data-parallel over GPUs with the gradients all-reduced per minibatch (RCCL over xGMI).
+Hyper-parameter names and defaults follow the reference's config dict (pioneer_knm_train.py:45-67) and
+the RLlib-0.8.x PPO defaults it did not override.
+
+On a HIP device the nets of the reference (137 -> 256 -> 256 tanh, separate value net) run on the
+hand-written kernels of csrc/pnr_mlp.h / pnr_ppo.h (bf16 MFMA operands, float32 accumulation, float32
+master weights and Adam moments): that is what ``PPOConfig()`` selects (``hip_kernels=True``).  The
+torch formulation below (float32 autograd, ``torch.optim.Adam``) is what CPU tensors use (the gloo
+tests, synthetic rollouts) and the numerical reference the kernels are tested against; on a GPU it
+only runs when asked for (``hip_kernels=False``) or for nets of another shape, eagerly.
 """
 import math
 import time
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -17,11 +23,6 @@ import torch
 import torch.nn as nn
 
 from . import dist as pdist
-
-# Output rows of the two head GEMMs (12 and 1 wide) are padded to a multiple of this (zero rows, sliced off).
-# PNR_PPO_HEAD_PAD=1 runs them at their natural widths: only tools/graph_nan_repro.py sets it.
-import os as _os
-_HEAD_PAD = max(1, int(_os.environ.get("PNR_PPO_HEAD_PAD", "16")))
 
 
 @dataclass
@@ -45,7 +46,7 @@ class PPOConfig:
     vf_loss_coeff: float = 1.0
     vf_clip_param: float = 10.0
     clip_actions: bool = True
-    grad_clip: Optional[float] = None
+    grad_clip: Optional[float] = None     # torch formulation only
     # entropy_coeff_schedule [(0, x), (decay_steps, 0)] (pioneer_knm_train.py:32-41, :63)
     entropy_coeff_start: float = 1e-2
     entropy_decay_steps: int = 1_000_000
@@ -53,8 +54,21 @@ class PPOConfig:
     observation_filter: str = "MeanStdFilter"
     filter_clip: float = 10.0
     seed: int = 0
-    # engine options (no reference counterpart)
-    amp_bf16: bool = False                # run the MLP GEMMs in bf16 (MFMA) under autocast; losses stay fp32
+    # engine option (no reference counterpart): on a HIP device, run the reference-shaped nets, the loss, Adam, GAE and the
+    # shuffle on the hand-written kernels (bf16 MFMA operands); False = the float32 torch formulation
+    hip_kernels: bool = True
+
+    @classmethod
+    def from_dict(cls, d: Dict) -> "PPOConfig":
+        """From a checkpoint's / params.json's dict: lists back to tuples, r01 / r02's `amp_bf16` read as `hip_kernels`."""
+        d = dict(d)
+        if "amp_bf16" in d:
+            d.setdefault("hip_kernels", bool(d.pop("amp_bf16")))
+        return cls(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k in cls.__dataclass_fields__})
+
+    def wants_hip(self, device) -> bool:
+        return (bool(self.hip_kernels) and torch.device(device).type == "cuda" and self.obs_dim == 137 and self.act_dim == 6
+                and tuple(self.fcnet_hiddens) == (256, 256) and not self.grad_clip)
 
 
 def sample_entropy_start(rng: np.random.RandomState, min_start: float = 1e-3, max_start: float = 1e-1,
@@ -214,69 +228,11 @@ def _mlp(sizes: Sequence[int], out_dim: int, out_gain: float) -> nn.Sequential:
     layers.append(head)
     return nn.Sequential(*layers)
 
-
-_ONES_CACHE: Dict[Tuple, torch.Tensor] = {}
-
-
-def _ones_rows(S: int, k: int, dtype, device) -> torch.Tensor:
-    key = (S, k, dtype, str(device))
-    if key not in _ONES_CACHE:
-        _ONES_CACHE[key] = torch.ones((S, 8, k), dtype=dtype, device=device)
-    return _ONES_CACHE[key]
-
-
-class _LinearSplitK(torch.autograd.Function):
-    """y = x W^T + b with a split-K weight gradient.
-
-    For the PPO minibatches dW = dy^T x has a tiny output (<= 256 x 256) and K = the minibatch size
-    (131 072): the BLAS library runs it as <= 16 workgroups on a 256-CU chip (368 us per call, a third
-    of the learn phase in rocprof).  Slicing the batch axis into S chunks turns it into one batched
-    GEMM with S x more workgroups plus a small sum."""
-
-    @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.bfloat16)   # casts only when autocast is on
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        return nn.functional.linear(x, weight, bias)
-
-    @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dy.to(weight.dtype) @ weight if ctx.needs_input_grad[0] else None
-        B = x.shape[0]
-        S = 1
-        # measured on MI355X at B = 131 072 (tools/gemm_probe.py): bf16 42 us at S = 64 (plain 360 us),
-        # fp32 95 us at S = 32 (plain 320 us)
-        for cand in ((64, 32, 16, 8, 4, 2) if dy.dtype == torch.bfloat16 else (32, 16, 8, 4, 2)):
-            if B % cand == 0 and B // cand >= 512:
-                S = cand
-                break
-        x2 = x.reshape(B, -1).to(dy.dtype)
-        if S > 1:
-            out = dy.shape[1]
-            # a bf16 batched GEMM with a single output row (the value head) takes ~11 ms of HOST time per
-            # call in the BLAS library (tools/gemm_probe2.py): pad tiny heads to 8 rows and slice
-            dyp = nn.functional.pad(dy, (0, 8 - out)) if out < 8 else dy
-            dw = torch.bmm(dyp.view(S, B // S, -1).transpose(1, 2), x2.view(S, B // S, -1)).sum(0, dtype=torch.float32)[:out]
-        else:
-            dw = (dy.t() @ x2).float()
-        if S > 1 and dy.is_cuda:
-            # the bias gradient as a GEMM too (eight rows of ones against the same slices): a torch column-sum over
-            # B rows takes the multi-block reduction path, which returned wrong sums from the second hipGraph replay
-            # on (tools/graph_reduce_probe.py); GEMMs replay exactly (profiles/r02_nan_repro_C_blas_backward.json)
-            ones = _ones_rows(S, B // S, dy.dtype, dy.device)
-            db = torch.bmm(ones, dy.view(S, B // S, -1)).sum(0, dtype=torch.float32)[0]
-        else:
-            db = dy.sum(0, dtype=torch.float32)      # one reduction with a float32 accumulator, no cast pass
-        return dx, dw.to(weight.dtype), db.to(weight.dtype)
-
-
 class ActorCritic(nn.Module):
     """Separate policy and value MLPs [137 -> 256 -> 256 -> 12 | 1], tanh (RLlib FullyConnectedNetwork
     with vf_share_layers False).  The policy head emits the Gaussian's 6 means and 6 log-stds:
-    104 204 + 101 377 = 205 581 parameters."""
+    104 204 + 101 377 = 205 581 parameters.  These float32 tensors are the master weights; on a
+    HIP device the kernels read packed bf16 copies of them (pioneer_amd.mlp.HipMLP)."""
 
     def __init__(self, cfg: PPOConfig):
         super().__init__()
@@ -285,90 +241,8 @@ class ActorCritic(nn.Module):
         self.value = _mlp(sizes, 1, 1.0)
         self.act_dim = cfg.act_dim
 
-    def dist_params(self, obs):
-        out = self.policy(obs)
-        mean, log_std = out[..., :self.act_dim], out[..., self.act_dim:]
-        return mean, torch.clamp(log_std, -20.0, 2.0)
-
-    @staticmethod
-    def _run(net: nn.Sequential, x_pad, pad: int, full: bool = False):
-        """First layer on a K padded to a multiple of 16 (137 -> 144): the BLAS library's kernels for an
-        unaligned K = 137 run at ~3 TFLOP/s (391 us for a 16384 x 137 x 256 GEMM); the zero columns are
-        appended to input and weight on the fly, so the parameters are the reference's."""
-        first = net[0]
-        h = _LinearSplitK.apply(x_pad, nn.functional.pad(first.weight, (0, pad)), first.bias)
-        layers = list(net)[1:]
-        for layer in layers[:-1]:
-            h = _LinearSplitK.apply(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(h)
-        # the heads (12 and 1 output rows) run as 16-row GEMMs (zero rows): aligned kernels, and the fused loss
-        # kernel consumes rows of 16.  (r01 blamed these widths for NaNs under graph replay; the cause was a torch
-        # reduction inside the captured loop, see PPOTrainer._collect_tail.)
-        head = layers[-1]
-        rp = (-head.out_features) % _HEAD_PAD
-        out = _LinearSplitK.apply(h, nn.functional.pad(head.weight, (0, 0, 0, rp)), nn.functional.pad(head.bias, (0, rp)))
-        return out if full else out[:, :head.out_features]
-
-    def forward_heads(self, obs, amp_bf16: bool = False):
-        """The two nets' raw head outputs as float32 rows of 16 (policy: means 0..5, unclamped log-stds
-        6..11; value: column 0) — the layout pnr_ppo_loss consumes."""
-        pad = (-obs.shape[-1]) % 16
-        x = nn.functional.pad(obs, (0, pad)) if pad else obs
-        if amp_bf16 and obs.is_cuda:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                hp, hv = self._run(self.policy, x, pad, True), self._run(self.value, x, pad, True)
-        else:
-            hp, hv = self._run(self.policy, x, pad, True), self._run(self.value, x, pad, True)
-        return hp.float(), hv.float()
-
-    # -- no-grad inference on cached weights (the sampling loop) ----------------------------------
-    # The rollout runs the nets T times on unchanged parameters: the K-padded, compute-dtype copies of the
-    # weights are made once per rollout (in place, so a captured hipGraph keeps using them) instead of
-    # ~14 pad / cast kernels per net and step.  Same GEMMs on the same values as forward().
-    def refresh_inference_cache(self, amp_bf16: bool) -> None:
-        dt = torch.bfloat16 if (amp_bf16 and next(self.parameters()).is_cuda) else torch.float32
-        cache = getattr(self, "_icache", None)
-        if cache is None or cache["dtype"] != dt:
-            cache = {"dtype": dt, "nets": []}
-            for net in (self.policy, self.value):
-                lins = [l for l in net if isinstance(l, nn.Linear)]
-                pad = (-lins[0].in_features) % 16
-                dev = lins[0].weight.device
-                # every cached matrix is [rows padded to 16, K padded to 16]: the zero rows / columns cost nothing
-                # and keep the BLAS library on its aligned kernels (the 1-row value head is the odd one out)
-                p16 = lambda n: n + (-n) % (_HEAD_PAD if n < 16 else 16)      # noqa: E731
-                ws = [torch.zeros((p16(l.out_features), l.in_features + (pad if i == 0 else 0)), dtype=dt, device=dev)
-                      for i, l in enumerate(lins)]
-                bs = [torch.zeros(p16(l.out_features), dtype=dt, device=dev) for l in lins]
-                cache["nets"].append((lins, ws, bs))
-            self._icache = cache
-        with torch.no_grad():
-            for lins, ws, bs in cache["nets"]:
-                for l, w, b in zip(lins, ws, bs):
-                    w[:l.out_features, :l.in_features].copy_(l.weight)
-                    b[:l.out_features].copy_(l.bias)
-
-    @torch.no_grad()
-    def forward_cached(self, x_pad):
-        """x_pad: [N, 144] in the cache's dtype (zero pad columns).  Returns (head [N, 12], v [N, 1]) in that dtype."""
-        outs = []
-        for lins, ws, bs in self._icache["nets"]:
-            h = x_pad
-            for i, (w, b) in enumerate(zip(ws, bs)):
-                h = nn.functional.linear(h, w, b)
-                if i + 1 < len(ws):
-                    h = torch.tanh(h)
-            outs.append(h[:, :lins[-1].out_features])
-        return outs[0], outs[1]
-
-    def forward(self, obs, amp_bf16: bool = False):
-        pad = (-obs.shape[-1]) % 16
-        x = nn.functional.pad(obs, (0, pad)) if pad else obs
-        if amp_bf16 and obs.is_cuda:
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                out, v = self._run(self.policy, x, pad), self._run(self.value, x, pad)
-            out, v = out.float(), v.float()
-        else:
-            out, v = self._run(self.policy, x, pad), self._run(self.value, x, pad)
+    def forward(self, obs):
+        out, v = self.policy(obs), self.value(obs)
         mean, log_std = out[..., :self.act_dim], torch.clamp(out[..., self.act_dim:], -20.0, 2.0)
         return mean, log_std, v.squeeze(-1)
 
@@ -386,40 +260,6 @@ def gaussian_kl(mean0, log_std0, mean1, log_std1):
     """KL(N0 || N1) for diagonal Gaussians."""
     var0, var1 = torch.exp(2 * log_std0), torch.exp(2 * log_std1)
     return (log_std1 - log_std0 + (var0 + (mean0 - mean1) ** 2) / (2 * var1) - 0.5).sum(-1)
-
-
-class FusedPPOLoss(torch.autograd.Function):
-    """PPOLearner.loss()'s element-wise part as ONE HIP kernel (pnr_ppo_loss, csrc/pnr_ppo.h): forward
-    values and d loss / d head in the same launch instead of ~120 small kernels per minibatch."""
-
-    @staticmethod
-    def forward(ctx, head_p, head_v, mb, kl_c, ent_c, clip, vf_clip, vf_coeff):
-        from . import _lib
-        import ctypes as C
-        lib = _lib.load_library()
-        B = head_p.shape[0]
-        head_p, head_v = head_p.contiguous(), head_v.contiguous()
-        assert head_p.shape == (B, 16) and head_v.shape == (B, 16) and head_p.dtype == head_v.dtype == torch.float32
-        t = {k: mb[k].contiguous() for k in ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values")}
-        assert all(v.dtype == torch.float32 and v.is_cuda and v.shape[0] == B for v in t.values())
-        assert t["actions"].shape == t["mean"].shape == t["log_std"].shape == (B, 6)
-        g_p, g_v = torch.empty_like(head_p), torch.empty_like(head_v)
-        rows = (B + 255) // 256
-        partials = torch.empty((rows, 8), dtype=torch.float32, device=head_p.device)
-        means = torch.empty(8, dtype=torch.float32, device=head_p.device)   # policy_loss, vf_loss, kl, entropy, total
-        P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
-        _lib.check(lib.pnr_ppo_loss(B, None, P(head_p), P(head_v), P(t["actions"]), P(t["logp"]), P(t["mean"]), P(t["log_std"]),
-                                    P(t["adv"]), P(t["vtarg"]), P(t["values"]), P(kl_c), P(ent_c),
-                                    C.c_float(clip), C.c_float(vf_clip), C.c_float(vf_coeff), P(g_p), P(g_v), P(partials),
-                                    rows, P(means), C.c_void_p(torch.cuda.current_stream(head_p.device).cuda_stream)))
-        ctx.save_for_backward(g_p, g_v)
-        ctx.mark_non_differentiable(means)
-        return means[4].clone(), means
-
-    @staticmethod
-    def backward(ctx, g_total, _g_means):
-        g_p, g_v = ctx.saved_tensors
-        return g_p * g_total, g_v * g_total, None, None, None, None, None, None
 
 
 def compute_gae(rewards, values, last_value, terminals, gamma, lam):
@@ -484,7 +324,6 @@ def hip_permutation(n: int, seed: int, stream_id: int, out: torch.Tensor) -> tor
                                                    ctypes.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
     return out[:n]
 
-
 class EpisodeStats:
     """episode_reward_{max,min,mean}, episode_len_mean, episodes_total (cli.py:32-38), on device.
 
@@ -518,34 +357,6 @@ class EpisodeStats:
         self.ret.mul_(keep)
         self.len.mul_(keep)
 
-    def rollout(self, rewards: torch.Tensor, terminals: torch.Tensor) -> None:
-        """The same bookkeeping as T calls of step(), from the rollout's [T, N] reward / terminal (0/1)
-        buffers in ~25 kernels instead of ~30 per step.  With k(t) the 1-based index of the most recent
-        terminal strictly before step t (0 = none in this rollout), the episode ending at a terminal t
-        has return csum[t] - csum[k(t)] (+ the carried-in return if k(t) = 0) and length t - k(t)
-        (+ the carried-in length)."""
-        T, N = rewards.shape
-        term = terminals.to(rewards.dtype)
-        idx = torch.arange(1, T + 1, device=rewards.device, dtype=rewards.dtype).unsqueeze(1)
-        last = torch.cummax(term * idx, dim=0).values                       # most recent terminal at or before t
-        zero = torch.zeros((1, N), device=rewards.device, dtype=rewards.dtype)
-        prev = torch.cat([zero, last[:-1]], dim=0)                          # ... strictly before t
-        csum0 = torch.cat([zero, torch.cumsum(rewards, dim=0)], dim=0)      # csum0[k] = sum of the first k rewards
-        fresh = prev == 0
-        ep_ret = csum0[1:] - torch.gather(csum0, 0, prev.long()) + torch.where(fresh, self.ret.unsqueeze(0), zero)
-        ep_len = idx - prev + torch.where(fresh, self.len.unsqueeze(0), zero)
-        m = term > 0
-        self.w_cnt.add_(m.sum())
-        self.w_sum.add_(torch.where(m, ep_ret, zero).sum().double())
-        self.w_len.add_(torch.where(m, ep_len, zero).sum().double())
-        self.w_max.copy_(torch.maximum(self.w_max, torch.where(m, ep_ret, torch.full_like(zero, -float("inf"))).max()))
-        self.w_min.copy_(torch.minimum(self.w_min, torch.where(m, ep_ret, torch.full_like(zero, float("inf"))).min()))
-        end = last[-1]                                                       # [N]
-        open_ = end == 0
-        tail = csum0[-1] - torch.gather(csum0, 0, end.long().unsqueeze(0)).squeeze(0)
-        self.ret.copy_(tail + torch.where(open_, self.ret, torch.zeros_like(self.ret)))
-        self.len.copy_(float(T) - end + torch.where(open_, self.len, torch.zeros_like(self.len)))
-
     def window_tensor(self) -> torch.Tensor:
         """The window's (return sum, length sum, episode count, max, min) over all ranks as ONE float64 device tensor: read
         it back with whatever else the iteration reports (one host synchronisation), then call finish_window()."""
@@ -569,78 +380,40 @@ class EpisodeStats:
         return out
 
 
-# other threads (the RCCL watchdog of torch.distributed) may touch the HIP runtime while this thread captures
-_CAPTURE_MODE = "thread_local"
-
-
 class PPOLearner:
     """The learn phase alone (usable on CPU with any rollout tensors): minibatch SGD on the clipped
     surrogate + adaptive KL + clipped value loss - entropy bonus, gradients averaged over ranks."""
 
-    def __init__(self, cfg: PPOConfig, device, use_graph: bool = False):
+    def __init__(self, cfg: PPOConfig, device):
         self.cfg = cfg
         self.device = torch.device(device)
         torch.manual_seed(cfg.seed)
         self.model = ActorCritic(cfg).to(self.device)
         pdist.broadcast_module_(self.model)
-        # hipGraph capture of one minibatch update, GPU, no grad clip.  One rank: loss -> backward -> Adam
-        # in ONE graph.  Several ranks: graph A (loss -> backward into a flat gradient bucket), the
-        # bucket's all-reduce issued eagerly (collectives stay out of the graphs), graph B (Adam).
-        self.use_graph = bool(use_graph) and self.device.type == "cuda" and not cfg.grad_clip
-        self._split = self.use_graph and pdist.is_dist()
-        self._flat_grad = None
-        self._graph_b = None
-        self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr, capturable=self.use_graph)
+        # the hand-written kernels carry the whole update when the nets are the reference's (pioneer_knm_train.py:59-61) on a
+        # HIP device; otherwise float32 autograd + torch.optim.Adam
+        self.hip = cfg.wants_hip(self.device)
+        self.opt = None if self.hip else torch.optim.Adam(self.model.parameters(), lr=cfg.lr)
         self.kl_coeff = cfg.kl_coeff
         self.timesteps_total = 0
-        # loss coefficients as device scalars so a captured graph sees their current values
+        # loss coefficients as device scalars: the kernels (and a captured sampling graph) read their current values
         self._kl_c = torch.tensor(float(cfg.kl_coeff), device=self.device)
         self._ent_c = torch.tensor(float(cfg.entropy_coeff_start), device=self.device)
-        self._graph = None
-        self._static = None
-        self._static_info = None
-        self._eager_updates = 0
-        self.fused_loss = self.device.type == "cuda" and cfg.act_dim == 6   # pnr_ppo_loss; torch ops otherwise (CPU)
-        # the hand-written MLP kernels (csrc/pnr_mlp.h) carry the whole differentiable part of an update when the nets are
-        # the reference's (137-256-256, pioneer_knm_train.py:59-61) and bf16 GEMMs were asked for; float32 runs stay on torch
-        self.hip = (self.fused_loss and bool(cfg.amp_bf16) and cfg.obs_dim == 137 and tuple(cfg.fcnet_hiddens) == (256, 256))
         self._mlp = None            # HipMLP with a workspace for one minibatch
         self._means = None          # [minibatches, 8] per-update loss means (HIP path)
         self._perm = None           # the epoch's minibatch shuffle (HIP path)
+        self._flat_grad = None      # several ranks: the gradient bucket that is all-reduced (HIP path)
         self._epochs = 0            # SGD epochs so far: the shuffle's stream id (saved with the optimiser state)
         self._hip_dirty = True      # the packed bf16 weights are stale (construction, restore)
-
-    def drop_graphs(self) -> None:
-        """Forget the captured minibatch update (it is re-captured after the eager warm-up updates)."""
-        if self._graph is not None or self._graph_b is not None:
-            torch.cuda.synchronize(self.device)
-        self._graph = self._graph_b = self._static = self._static_info = self._flat_grad = None
-        self._eager_updates = 0
-        for p in self.model.parameters():
-            p.grad = None                      # split mode made every .grad a view of the flat bucket
 
     def entropy_coeff(self) -> float:
         frac = min(1.0, self.timesteps_total / max(1, self.cfg.entropy_decay_steps))
         return self.cfg.entropy_coeff_start * (1.0 - frac)
 
     def loss(self, mb: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """The torch formulation (float32, autograd): what pnr_mlp_train_step's fused kernel is tested against."""
         cfg = self.cfg
-        if self.hip and mb["obs"].is_cuda:
-            idx = mb.get("idx")
-            B = int(idx.numel()) if idx is not None else int(mb["obs"].shape[0])
-            m = self.hip_mlp(B).policy_loss(mb["obs"], idx, mb.get("filt"), mb, self._kl_c, self._ent_c, cfg.clip_param,
-                                      cfg.vf_clip_param, cfg.vf_loss_coeff)
-            # the reported means are DETACHED views: kept across minibatches (agg, _static_info) they must not keep the
-            # autograd graph alive — its AccumulateGrad nodes would remember the stream of an earlier eager update, and
-            # replaying them under capture on the capture stream tied the two streams together (segfault at capture_end)
-            d = m.detach()
-            return m[4], {"policy_loss": d[0], "vf_loss": d[1], "kl": d[2], "entropy": d[3], "total_loss": d[4]}
-        if self.fused_loss and mb["obs"].is_cuda:
-            hp, hv = self.model.forward_heads(mb["obs"], cfg.amp_bf16)
-            total, m = FusedPPOLoss.apply(hp, hv, mb, self._kl_c, self._ent_c, float(cfg.clip_param),
-                                          float(cfg.vf_clip_param), float(cfg.vf_loss_coeff))
-            return total, {"policy_loss": m[0], "vf_loss": m[1], "kl": m[2], "entropy": m[3], "total_loss": m[4]}
-        mean, log_std, v = self.model(mb["obs"], cfg.amp_bf16)
+        mean, log_std, v = self.model(mb["obs"])
         logp = gaussian_logp(mb["actions"], mean, log_std)
         ratio = torch.exp(logp - mb["logp"])
         adv = mb["adv"]
@@ -669,59 +442,40 @@ class PPOLearner:
         pdist.allreduce_sum_(stats)
         mu = stats[0] / stats[2]
         sd = torch.sqrt(torch.clamp(stats[1] / stats[2] - mu * mu, min=1e-12))
-        hip_path = self.hip and adv.is_cuda
-        # (the HIP path standardises while it packs the record, pnr_ppo_pack_record: the same two float32 operations)
-        adv_n = adv if hip_path else (adv - mu.float()) / (sd.float() + 1e-8)
-        self._adv_scalars = (mu.float().reshape(1), (sd.float() + 1e-8).reshape(1)) if hip_path else None
         self._kl_c.fill_(self.kl_coeff)
         self._ent_c.fill_(self.entropy_coeff())
+        tens = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and k != "adv_stats"}
+        if self.hip:
+            if not adv.is_cuda:
+                raise AssertionError("this learner runs on the HIP kernels: its batches must live on the device")
+            # (the kernels standardise while they pack the record, pnr_ppo_pack_record: the same two float32 operations)
+            m = self._update_hip(tens, batch.get("filt"), B, mbs, (mu.float().reshape(1), (sd.float() + 1e-8).reshape(1)))
+            # PPOTrainer reads the means back together with the episode statistics (one host synchronisation per iteration)
+            return self.finish_update_values(m.tolist()) if readback else m
+        tens["adv"] = (adv - mu.float()) / (sd.float() + 1e-8)
         agg: Dict[str, torch.Tensor] = {}
         nmb = 0
-        filt = batch.get("filt")
-        tens = {k: v for k, v in batch.items() if isinstance(v, torch.Tensor) and k != "adv_stats"}
-        tens["adv"] = adv_n
-        if self.hip and adv.is_cuda:
-            m = self._update_hip(tens, filt, B, mbs, generator)
-            if not readback:
-                return m                                            # PPOTrainer reads it back together with the episode statistics
-            return self.finish_update_values(m.tolist())
-
-        def eager_step(mb):
-            loss, info = self.loss(mb)
-            self.opt.zero_grad(set_to_none=True)
-            loss.backward()
-            pdist.allreduce_mean_grads(self.model.parameters())   # one flat 0.82 MB bucket
-            if cfg.grad_clip:
-                nn.utils.clip_grad_norm_(self.model.parameters(), cfg.grad_clip)
-            self.opt.step()
-            return info
-
-        graph_ok = self.use_graph and (self._static is None or self._static["obs"].shape[0] == mbs)
         for _ in range(cfg.num_sgd_iter):
             perm = torch.randperm(B, device=adv.device, generator=generator)
             for s in range(0, B - mbs + 1, mbs):
                 idx = perm[s:s + mbs]
-                if graph_ok and self._graph is None and self._eager_updates >= 3:
-                    self._capture(tens, idx)                        # after a few eager updates (warm-up)
-                if graph_ok and self._graph is not None:
-                    for k, v in tens.items():
-                        torch.index_select(v, 0, idx, out=self._static[k])
-                    self._graph.replay()
-                    if self._split:
-                        pdist.allreduce_mean_(self._flat_grad)      # the one 0.82 MB bucket, eager
-                        self._graph_b.replay()
-                    info = self._static_info
-                else:
-                    info = eager_step({k: v[idx] for k, v in tens.items()})
-                    self._eager_updates += 1
+                loss, info = self.loss({k: v[idx] for k, v in tens.items()})
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                pdist.allreduce_mean_grads(self.model.parameters())   # one flat 0.82 MB bucket
+                if cfg.grad_clip:
+                    nn.utils.clip_grad_norm_(self.model.parameters(), cfg.grad_clip)
+                self.opt.step()
                 for k, v in info.items():
                     agg[k] = agg.get(k, 0) + v
                 nmb += 1
-        out = {k: float(v) / max(1, nmb) for k, v in agg.items()}
-        return self._finish_update(out, adv.device)
+        m = torch.stack([agg[k] for k in ("policy_loss", "vf_loss", "kl", "entropy", "total_loss")]).double() / max(1, nmb)
+        if pdist.is_dist():                                         # the reported losses are averages over the ranks
+            m = pdist.allreduce_sum_(m) / pdist.dist.get_world_size()
+        return self.finish_update_values(m.tolist())
 
     def finish_update_values(self, m) -> Dict[str, float]:
-        """The HIP path's loss means (already averaged over the ranks) as the result columns + the adaptive-KL step."""
+        """The loss means (already averaged over the ranks) as the result columns + the adaptive-KL step (RLlib PPO: update_kl)."""
         out = {"policy_loss": m[0], "vf_loss": m[1], "kl": m[2], "entropy": m[3], "total_loss": m[4]}
         cfg = self.cfg
         if out["kl"] > 2.0 * cfg.kl_target:
@@ -732,40 +486,28 @@ class PPOLearner:
         out["entropy_coeff"] = self.entropy_coeff()
         return out
 
-    def _finish_update(self, out: Dict[str, float], device) -> Dict[str, float]:
-        cfg = self.cfg
-        # adaptive KL (RLlib PPO: update_kl)
-        kl_t = torch.tensor([out.get("kl", 0.0)], dtype=torch.float64, device=device)
-        pdist.allreduce_sum_(kl_t)
-        kl = float(kl_t) / (pdist.dist.get_world_size() if pdist.is_dist() else 1)
-        if kl > 2.0 * cfg.kl_target:
-            self.kl_coeff *= 1.5
-        elif kl < 0.5 * cfg.kl_target:
-            self.kl_coeff *= 0.5
-        out["kl"] = kl
-        out["cur_kl_coeff"] = self.kl_coeff
-        out["entropy_coeff"] = self.entropy_coeff()
-        return out
-
     def optimizer_state(self):
         """torch.optim.Adam's state_dict on the torch path; on the HIP path Adam's moments as the fused kernel keeps them
         (padded gradient layout) and its update count."""
-        if self.hip and self._mlp is not None:
-            m, v, step = self._mlp.adam_state()
+        if self.hip:
+            m, v, step = self.hip_mlp(1).adam_state()
             return {"hip_adam": {"m": m, "v": v, "step": step, "epochs": self._epochs}}
         return self.opt.state_dict()
 
     def load_optimizer_state(self, sd) -> None:
-        if "hip_adam" in sd:
-            if not self.hip:
-                raise AssertionError("the checkpoint holds the HIP path's optimiser state; this learner runs on torch")
-            mlp = self.hip_mlp(max(1, min(self.cfg.sgd_minibatch_size, 1 << 20)))
-            for dst, k in zip(mlp.adam_state(), ("m", "v", "step")):
+        """A checkpoint restores into the formulation that wrote it: silently dropping Adam's moments (the other layout)
+        would restart their bias correction, so a mismatch raises."""
+        if ("hip_adam" in sd) != self.hip:
+            raise AssertionError(f"the checkpoint holds the {'HIP kernels' if 'hip_adam' in sd else 'torch'} learner's optimiser state, "
+                                 f"this learner runs on {'the HIP kernels' if self.hip else 'torch'}: restore it with "
+                                 f"PPOConfig(hip_kernels={'hip_adam' in sd})")
+        if self.hip:
+            for dst, k in zip(self.hip_mlp(1).adam_state(), ("m", "v", "step")):
                 dst.copy_(sd["hip_adam"][k])
             self._epochs = int(sd["hip_adam"].get("epochs", 0))
-        elif not (self.hip and not sd.get("state")):
+            self._hip_dirty = True           # the master weights changed behind the packed bf16 copies
+        else:
             self.opt.load_state_dict(sd)
-        self._hip_dirty = True           # the master weights changed behind the packed bf16 copies
 
     # -- the HIP path: every minibatch update is pnr_mlp_train_step, three launches, no autograd, no hipGraph needed ----
     def hip_mlp(self, batch: int):
@@ -779,19 +521,18 @@ class PPOLearner:
             self._hip_dirty = True
         return self._mlp
 
-    def _update_hip(self, tens, filt, B, mbs, generator) -> Dict[str, float]:
-        """The minibatch loop on the hand-written kernels.  The kernels gather minibatch rows themselves (a slice of the
-        epoch's permutation is the row index), the float32 master parameters are updated in place by the fused
-        reduction + Adam kernel, which also refreshes the packed bf16 weights for the next forward.  Several ranks:
-        the reduced gradient goes to one flat bucket, is all-reduced (RCCL), and pnr_mlp_adam applies the mean."""
+    def _update_hip(self, tens, filt, B, mbs, adv_scalars) -> torch.Tensor:
+        """The minibatch loop on the hand-written kernels.  Per iteration the record is packed into 96-byte rows, per epoch
+        the shuffle is drawn and applied (the updates then read contiguous rows); the float32 master parameters are updated
+        in place by the fused reduction + Adam kernel, which also refreshes the packed bf16 weights for the next forward.
+        Several ranks: the reduced gradient goes to one flat bucket, is all-reduced (RCCL), and pnr_mlp_adam applies the mean."""
         cfg, dev = self.cfg, self.device
         mlp = self.hip_mlp(mbs)
         if self._hip_dirty:
             mlp.pack()
             self._hip_dirty = False
         rec = {k: v.contiguous() for k, v in tens.items()}
-        nmb_epoch = len(range(0, B - mbs + 1, mbs))
-        total = cfg.num_sgd_iter * nmb_epoch
+        total = cfg.num_sgd_iter * len(range(0, B - mbs + 1, mbs))
         if self._means is None or self._means.shape[0] != total:
             self._means = torch.zeros((total, 8), dtype=torch.float32, device=dev)
         multi = pdist.is_dist()
@@ -800,17 +541,15 @@ class PPOLearner:
             self._flat_grad = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), dtype=torch.float32, device=dev)
         if self._perm is None or self._perm.numel() != B:
             self._perm = torch.empty(B, dtype=torch.int64, device=dev)
-        # the record as one 96-byte row per sample, advantages standardised on the way: once per iteration
-        rows = mlp.pack_record(rec, *(self._adv_scalars or (None, None)))
+        rows = mlp.pack_record(rec, *adv_scalars)
         k = 0
         for _ in range(cfg.num_sgd_iter):
             # each epoch's shuffle: pnr_permutation keyed by (seed, rank, epoch counter) — one launch, no sort
             perm = hip_permutation(B, cfg.seed * 1000003 + (pdist.dist.get_rank() if multi else 0), self._epochs, self._perm)
             self._epochs += 1
-            # ... applied once per epoch (pnr_mlp_gather): the 16 updates then read contiguous rows
             g = mlp.gather_epoch(rec["obs"], perm, filt, None, rec_rows=rows, xs_rows=rec.get("xs"))
             for s in range(0, B - mbs + 1, mbs):
-                mlp.train_step(None, None, None, {k: g[k][s:s + mbs] for k in mlp.REC_KEYS}, self._kl_c, self._ent_c, cfg.clip_param,
+                mlp.train_step(None, None, None, {k_: g[k_][s:s + mbs] for k_ in mlp.REC_KEYS}, self._kl_c, self._ent_c, cfg.clip_param,
                                cfg.vf_clip_param, cfg.vf_loss_coeff, self._means[k], cfg.lr,
                                flat_grad=self._flat_grad if multi else None, xs_in=g["xs"][s:s + mbs])
                 if multi:
@@ -819,64 +558,30 @@ class PPOLearner:
                 k += 1
         m = self._means.mean(0).double()
         if multi:                                                   # the reported losses are averages over the ranks
-            pdist.allreduce_sum_(m)
-            m = m / world
-        return m                                                    # device tensor [8]: read back by the caller
+            m = pdist.allreduce_sum_(m) / world
+        return m                                                    # device tensor [8]
 
 
-def _learner_capture(self, batch, idx):
-    """Capture one minibatch update on static buffers: one hipGraph (single rank) or two with the
-    gradient all-reduce between them (several ranks).  The capture pass only records work."""
-    try:
-        self._static = {k: v[idx].clone() for k, v in batch.items()}
-        torch.cuda.synchronize(self.device)
-        if not self._split:
-            self.opt.zero_grad(set_to_none=True)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
-                loss, info = self.loss(self._static)
-                loss.backward()
-                self.opt.step()
-            self._graph, self._static_info = g, info
-            return
-        # every parameter's .grad becomes a view of one flat bucket; backward accumulates in place
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=self.device)
-        off = 0
-        for p in params:
-            p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, capture_error_mode=_CAPTURE_MODE):
-            flat.zero_()
-            loss, info = self.loss(self._static)
-            loss.backward()
-        with torch.cuda.graph(gb, capture_error_mode=_CAPTURE_MODE):
-            self.opt.step()
-        self._graph, self._graph_b, self._flat_grad, self._static_info = ga, gb, flat, info
-    except Exception:            # capture not possible here: stay eager
-        self._graph, self._graph_b, self._static, self.use_graph, self._split = None, None, None, False, False
-        torch.cuda.synchronize(self.device)
-
-
-PPOLearner._capture = _learner_capture
+# other threads (the RCCL watchdog of torch.distributed) may touch the HIP runtime while this thread captures
+_CAPTURE_MODE = "thread_local"
 
 
 class PPOTrainer:
     """Rollout + learn loop over a PioneerVectorEnv shard (one process per GPU).
 
-    ``use_graph=True`` captures the whole T-step sampling loop (policy forward, action sampling, ``pnr_step``,
-    log-probs, GAE) into ONE hipGraph after an eager warm-up iteration.  With the reference's nets and bf16 GEMMs
-    (``PPOLearner.hip``) the nets run on the hand-written MFMA kernels: one launch per step computes both heads from
-    the RAW observation the env kernel left in the rollout buffer (the MeanStdFilter is applied on load), and the
-    learner reads the same raw buffer through a row index — filtered observations are never materialised."""
+    With the reference's nets (``PPOLearner.hip``) everything runs on the hand-written kernels: per sampler step TWO
+    launches — pnr_mlp_act (both nets on the RAW observation the env kernel left in the rollout buffer, the
+    MeanStdFilter applied on load, the action draw and clip in the policy net's epilogue) and pnr_step — then one
+    pnr_ppo_gae launch for log-probs, GAE and the episode statistics; ``use_graph=True`` replays that whole T-step loop
+    from ONE hipGraph after an eager warm-up iteration.  The torch formulation (``hip_kernels=False`` or other net
+    shapes) samples eagerly with float32 torch ops."""
 
     def __init__(self, env, cfg: Optional[PPOConfig] = None, use_graph: bool = False):
         self.env = env
         self.cfg = cfg or PPOConfig()
         self.device = env.device
         self.rank, _, self.world = pdist.world_info()
-        self.learner = PPOLearner(self.cfg, self.device, use_graph=use_graph)
+        self.learner = PPOLearner(self.cfg, self.device)
         self.hip = self.learner.hip
         self.filter = (MeanStdFilter(self.cfg.obs_dim, self.device, self.cfg.filter_clip)
                        if self.cfg.observation_filter in ("MeanStdFilter", "ConcurrentMeanStdFilter") else NoFilter())
@@ -884,14 +589,11 @@ class PPOTrainer:
         self._ev = None             # timing events of train()
         self.gen = torch.Generator(device=self.device).manual_seed(self.cfg.seed * 1000003 + self.rank)
         self.a_max = torch.from_numpy(env.a_max).to(self.device)
-        self._a_lo = -self.a_max
         self.iteration = 0
-        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self.use_graph = bool(use_graph) and self.hip
         self._graph = None
-        self._xin = None
         T, N, D, A = self.cfg.rollout_fragment_length, env.num_envs, self.cfg.obs_dim, self.cfg.act_dim
         f32 = dict(dtype=torch.float32, device=self.device)
-        self._xlast = torch.empty((N, D), **f32)
         self._env_act = torch.empty((N, A), **f32)
         # raw observations: slot 0 = what the rollout starts from, slot t + 1 = written in place by pnr_step at step t;
         # the nets' inputs of a rollout are slots 0 .. T-1, slot T carries over to the next rollout's slot 0
@@ -906,7 +608,6 @@ class PPOTrainer:
             "adv": torch.empty((T, N), **f32), "vtarg": torch.empty((T, N), **f32),
             "done": torch.empty((T, N), dtype=torch.uint8, device=self.device),
             "trunc": torch.empty((T, N), dtype=torch.uint8, device=self.device),
-            "term_u8": torch.empty((T, N), dtype=torch.uint8, device=self.device),
             "terminals": torch.empty((T, N), **f32),                   # done | truncated as 0 / 1
         }
         if self.hip:
@@ -929,89 +630,49 @@ class PPOTrainer:
         f = self.filter
         return (f._loc, f._inv, f._lo, f._hi) if isinstance(f, MeanStdFilter) else None
 
-    def _noise(self):
-        shape = tuple(self.buf["actions"].shape)
-        # in-graph noise comes from the default (graph-safe) generator
-        return torch.randn(shape, device=self.device) if self._capturing else torch.randn(shape, generator=self.gen, device=self.device)
-
-    def _finish_rollout(self, last_v: torch.Tensor) -> None:
-        cfg, buf = self.cfg, self.buf
-        if self.hip:
-            hip_gae_logp(buf["reward"], buf["values"], last_v.contiguous(), buf["done"], buf["trunc"], buf["actions"], buf["mean"],
-                         buf["log_std"], cfg.gamma, cfg.lambda_, logp=buf["logp"], adv=buf["adv"], vtarg=buf["vtarg"],
-                         terminals=buf["terminals"], stats=self.stats, adv_stats=self._adv_stats)
-            return
-        buf["logp"].copy_(gaussian_logp(buf["actions"], buf["mean"], buf["log_std"]))
-        torch.bitwise_or(buf["done"], buf["trunc"], out=buf["term_u8"])
-        buf["terminals"].copy_(buf["term_u8"])
-        adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, buf["terminals"], cfg.gamma, cfg.lambda_)
-        buf["adv"].copy_(adv); buf["vtarg"].copy_(vtarg)
-
-    def _env_step(self, t: int, act: torch.Tensor) -> None:
+    def _step_env(self, t: int, act: torch.Tensor) -> None:
         buf = self.buf
-        env_act = torch.clamp(act, self._a_lo, self.a_max, out=self._env_act) if self.cfg.clip_actions else act
-        self.env.vector_step(env_act, out={"obs": self.raw_in[t + 1], "reward": buf["reward"][t], "done": buf["done"][t],
-                                           "truncated": buf["trunc"][t]})
+        self.env.vector_step(act, out={"obs": self.raw_in[t + 1], "reward": buf["reward"][t], "done": buf["done"][t],
+                                       "truncated": buf["trunc"][t]})
 
     @torch.no_grad()
     def _collect_impl(self) -> None:
-        """T steps into the static buffers; pure device work (capturable).  Log-probs and GAE are computed once, after
-        the loop, from the [T, N] buffers; episode statistics and filter moments in _collect_tail(), outside any
-        capture."""
-        cfg, buf, model = self.cfg, self.buf, self.learner.model
-        T, A = cfg.rollout_fragment_length, cfg.act_dim
+        """T steps into the static buffers; pure device work (capturable on the HIP path).  Log-probs, GAE and the episode
+        statistics come from ONE launch after the loop; the filter's moments in collect(), outside any capture."""
+        cfg, buf = self.cfg, self.buf
+        T, clip = cfg.rollout_fragment_length, cfg.clip_actions
         self.raw_in[0].copy_(self.raw_in[T])
         self.filter.prepare()
-        noise = self._noise()
+        shape = tuple(buf["actions"].shape)
+        # in-graph noise comes from the default (graph-safe) generator
+        noise = torch.randn(shape, device=self.device) if self._capturing else torch.randn(shape, generator=self.gen, device=self.device)
         if self.hip:
-            # per step TWO launches: pnr_mlp_act (both nets on the raw observation, filter applied on load, action draw and
-            # clip in the policy net's epilogue) and pnr_step
             mlp, filt = self.sample_mlp, self._filt()
             mlp.pack()
-            clip = self.cfg.clip_actions
             for t in range(T):
                 mlp.act(self.raw_in[t], filt, noise[t], self.a_max if clip else None, mean=buf["mean"][t], log_std=buf["log_std"][t],
                         values=buf["values"][t], actions=buf["actions"][t], env_actions=self._env_act if clip else None,
                         xs_out=buf["xs"][t])
-                self.env.vector_step(self._env_act if clip else buf["actions"][t],
-                                     out={"obs": self.raw_in[t + 1], "reward": buf["reward"][t], "done": buf["done"][t],
-                                          "truncated": buf["trunc"][t]})
+                self._step_env(t, self._env_act if clip else buf["actions"][t])
             last = mlp.forward_nograd(self.raw_in[T], None, filt, out=self._last_heads)
             self._last_v.copy_(last[1, :, 0])           # bootstrap value of the state after the last step
-            self._finish_rollout(self._last_v)
+            hip_gae_logp(buf["reward"], buf["values"], self._last_v, buf["done"], buf["trunc"], buf["actions"], buf["mean"],
+                         buf["log_std"], cfg.gamma, cfg.lambda_, logp=buf["logp"], adv=buf["adv"], vtarg=buf["vtarg"],
+                         terminals=buf["terminals"], stats=self.stats, adv_stats=self._adv_stats)
             return
-        model.refresh_inference_cache(cfg.amp_bf16)
-        cdt = model._icache["dtype"]
-        if self._xin is None or self._xin.dtype != cdt:
-            self._xin = torch.zeros((self.raw_in.shape[1], cfg.obs_dim + (-cfg.obs_dim) % 16), dtype=cdt, device=self.device)
-        xin = self._xin
+        model = self.learner.model
         for t in range(T):
-            x = buf["obs"][t]
-            self.filter.apply_(self.raw_in[t], out=x)
-            xin[:, :cfg.obs_dim].copy_(x)
-            head, v = model.forward_cached(xin)
-            buf["mean"][t].copy_(head[:, :A])
-            log_std = torch.clamp(head[:, A:], -20.0, 2.0, out=buf["log_std"][t])
-            buf["values"][t].copy_(v.squeeze(-1))
-            act = torch.addcmul(buf["mean"][t], torch.exp(log_std), noise[t], out=buf["actions"][t])
-            self._env_step(t, act)
-        xin[:, :cfg.obs_dim].copy_(self.filter.apply_(self.raw_in[T], out=self._xlast))
-        self._finish_rollout(model.forward_cached(xin)[1].squeeze(-1).float())
-
-    def _collect_tail(self) -> None:
-        """The rollout's bookkeeping reductions — episode statistics and the filter's moments — run EAGERLY after
-        the (possibly replayed) loop, never inside a captured graph.  Root cause of the r01 "NaNs after graph replay"
-        finding (tools/graph_reduce_probe.py, profiles/r02_graph_reduce_probe.json): a torch reduction over the
-        middle axis of a large tensor ([31, 16384, 137].sum(1): the multi-block path with per-output semaphores that
-        the launcher zeroes by hipMemsetAsync) returns wrong sums from the SECOND replay of a hipGraph on (first
-        replay exact, eager always exact) — depending on the pool layout, which is why changing head widths or
-        minibatch sizes made it come and go.  It fed garbage into the filter's moments.  Nothing of the BLAS
-        library was involved.  The filter only changes at sync(), so observing all inputs here, in one pass, is
-        identical to observing them one by one inside the loop."""
-        buf, T = self.buf, self.cfg.rollout_fragment_length
-        if not self.hip:                                  # the HIP path's pnr_ppo_gae launch has done the episode statistics
-            self.stats.rollout(buf["reward"], buf["terminals"])
-        self.filter.observe(self.raw_in[:T])
+            mean, log_std, v = model(self.filter.apply_(self.raw_in[t], out=buf["obs"][t]))
+            buf["mean"][t].copy_(mean); buf["log_std"][t].copy_(log_std); buf["values"][t].copy_(v)
+            act = torch.addcmul(mean, torch.exp(log_std), noise[t], out=buf["actions"][t])
+            self._step_env(t, torch.clamp(act, -self.a_max, self.a_max, out=self._env_act) if clip else act)
+            term = (buf["done"][t] | buf["trunc"][t]).to(torch.float32)
+            buf["terminals"][t].copy_(term)
+            self.stats.step(buf["reward"][t], term)
+        last_v = model(self.filter.apply_(self.raw_in[T], out=torch.empty_like(self.raw_in[T])))[2]
+        buf["logp"].copy_(gaussian_logp(buf["actions"], buf["mean"], buf["log_std"]))
+        adv, vtarg = compute_gae(buf["reward"], buf["values"], last_v, buf["terminals"], cfg.gamma, cfg.lambda_)
+        buf["adv"].copy_(adv); buf["vtarg"].copy_(vtarg)
 
     _capturing = False
 
@@ -1019,7 +680,7 @@ class PPOTrainer:
         if self.use_graph and self._graph is None and self.iteration >= 1:
             # capture after one eager iteration (allocator and library warm-up done)
             torch.cuda.synchronize(self.device)
-            self._capturing = True              # in-graph noise comes from the default (graph-safe) generator
+            self._capturing = True
             torch.cuda.manual_seed(self.cfg.seed * 7919 + self.rank + 1)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
@@ -1030,8 +691,13 @@ class PPOTrainer:
             self._graph.replay()
         else:
             self._collect_impl()
-        self._collect_tail()
+        # The filter's moment pass runs EAGERLY after the (possibly replayed) loop, never inside a captured graph: a torch
+        # reduction over the middle axis of a large tensor returned wrong sums from the second replay of a hipGraph on (r01's
+        # "NaNs after graph replay"; layout-dependent, cause not pinned below torch: tools/graph_reduce_probe.py,
+        # profiles/r02_graph_reduce_probe.json), and nothing captured here reduces with torch any more.  The filter only changes
+        # at sync(), so observing all inputs in one pass equals observing them one by one inside the loop.
         buf, T = self.buf, self.cfg.rollout_fragment_length
+        self.filter.observe(self.raw_in[:T])
         flat = lambda x: x.reshape(-1, *x.shape[2:])  # noqa: E731
         batch = {"actions": flat(buf["actions"]), "mean": flat(buf["mean"]), "log_std": flat(buf["log_std"]),
                  "logp": flat(buf["logp"]), "values": flat(buf["values"]), "adv": flat(buf["adv"]), "vtarg": flat(buf["vtarg"])}
@@ -1044,18 +710,15 @@ class PPOTrainer:
         return batch
 
     def train(self) -> Dict[str, float]:
-        """One iteration: collect, merge the filter, update.  On the GPU the phase split (sample_time_s / learn_time_s, RLlib's
+        """One iteration: collect, merge the filter, update.  The phase split (sample_time_s / learn_time_s, RLlib's
         sample_time_ms / learn_time_ms) comes from an event recorded between the phases, not from a host synchronisation there:
         the learner's first kernels are queued while the sampler's last ones still run."""
-        cuda = self.device.type == "cuda"
         t0 = time.perf_counter()
-        if cuda:
-            if self._ev is None:
-                self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            self._ev[0].record()
+        if self._ev is None:
+            self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self._ev[0].record()
         batch = self.collect()
-        if cuda:
-            self._ev[1].record()
+        self._ev[1].record()
         t1 = time.perf_counter()
         self.filter.sync()
         steps = batch["obs"].shape[0] * self.world
@@ -1067,13 +730,10 @@ class PPOTrainer:
             info, win = self.learner.finish_update_values(vals[:8]), vals[8:]
         else:
             win = win.tolist()
-        if cuda:
-            self._ev[2].record()
-            torch.cuda.synchronize(self.device)
+        torch.cuda.synchronize(self.device)
         t2 = time.perf_counter()
-        if cuda:
-            gpu_sample = self._ev[0].elapsed_time(self._ev[1]) * 1e-3
-            t1 = t0 + min(max(gpu_sample, t1 - t0), t2 - t0)       # the sampler's share of the wall time of this iteration
+        gpu_sample = self._ev[0].elapsed_time(self._ev[1]) * 1e-3
+        t1 = t0 + min(max(gpu_sample, t1 - t0), t2 - t0)       # the sampler's share of the wall time of this iteration
         self.iteration += 1
         res = self.stats.finish_window(win)
         res.update(info)
@@ -1085,7 +745,9 @@ class PPOTrainer:
     # -- checkpoint / resume (Tune's checkpoint_freq / checkpoint_at_end, pioneer_knm_train.py:72-73) --
     def _env_state(self) -> Dict[str, torch.Tensor]:
         st = {"env_state": self.env.get_state().cpu(), "env_id_offset": int(self.env.env_id_offset),
-              "num_envs": int(self.env.num_envs)}
+              "num_envs": int(self.env.num_envs),
+              # this rank's running episode accumulators and its noise generator: the rollout continues where it stopped
+              "stats_ret": self.stats.ret.cpu(), "stats_len": self.stats.len.cpu(), "gen_state": self.gen.get_state()}
         if self.env.engine_config.mode == "dynamic":
             st["dyn_state"] = self.env.get_dyn_state().cpu()        # q, qd and the per-env randomised parameters
         return st
@@ -1110,13 +772,12 @@ class PPOTrainer:
         return path
 
     def restore(self, path: str, restore_env: bool = False) -> None:
+        """Weights, optimiser state, filter and counters are copied IN PLACE (a captured sampling graph keeps seeing them).
+        With restore_env the env shards, the running episode accumulators and the noise generator come back too: the run
+        then continues exactly as the uninterrupted one would have (eager sampling; a replayed graph draws its noise from
+        the default generator)."""
         ck = torch.load(path, map_location=self.device, weights_only=True)    # tensors and plain values only
         self.learner.model.load_state_dict(ck["model"]); self.learner.load_optimizer_state(ck["opt"])
-        # load_state_dict REPLACES the optimiser's state tensors: a learner graph captured before this call would
-        # keep replaying on the old exp_avg / exp_avg_sq / step.  Drop the captures; they are rebuilt after the
-        # usual eager warm-up updates.  (Model weights and filter moments are copied in place: the sampling
-        # graph keeps seeing them.)
-        self.learner.drop_graphs()
         self.filter.load_state_dict(ck["filter"]); self.learner.kl_coeff = ck["kl_coeff"]
         self.learner.timesteps_total = ck["timesteps_total"]; self.iteration = ck["iteration"]
         self.stats.total = ck["episodes_total"]
@@ -1134,3 +795,6 @@ class PPOTrainer:
             if dynamic:
                 self.env.set_dyn_state(est["dyn_state"].to(self.device))
             self.raw_obs.copy_(self.env.observe())
+            if "stats_ret" in est:
+                self.stats.ret.copy_(est["stats_ret"]); self.stats.len.copy_(est["stats_len"])
+                self.gen.set_state(est["gen_state"].cpu())

@@ -29,11 +29,15 @@ def test_single_gpu_line_has_the_contract_fields():
     r, _ = _bench(SMALL + ["--cpu-seconds", "1"])
     assert r["metric"] == "env-steps/sec" and r["n_gpus"] == 1 and r["steps"] == 64 and r["warmup"] == 8
     assert r["scaling"] == "strong" and r["config"]["total_envs"] == 65536 and r["config"]["envs_per_gpu"] == 65536
-    assert r["repeats"] == 5                       # a 64-step block is far below 50 ms: median of five blocks
+    assert r["repeats"] >= 5                       # a 64-step block is far below 60 ms: many back-to-back blocks
     assert abs(r["value"] - 65536 * 64 / (r["ms_per_step"] * 64e-3)) < 1e-6 * r["value"]
+    assert r["config"]["handles_per_gpu"] == 1 and not r["config"]["hip_graph"]
+    assert r["split_streams"]["handles_per_gpu"] == 2 and 0.05 < r["split_streams"]["frac"] < 1.0
+    assert r["config"]["block_event_spread_p10_p90"] < 0.2
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and 0.05 < rf["frac"] < 1.0 and rf["peak"] == 8000.0
-    assert rf["traffic"] is None or "NOT measured in this run" in rf["traffic_source"]
+    assert ("NOT measured in this run" in rf["traffic_source"]) if rf["traffic"] is not None else ("stale" in rf["traffic_source"] or "profiles/" in rf["traffic_source"])
+    assert rf["launches_per_step"] == 1 and "single_launch" not in rf
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
     p = r["ppo_loop"]
     assert "error" not in p and p["losses_finite"] and p["sgd_minibatch_size"] == 8192 and p["grad_allreduce"] is None

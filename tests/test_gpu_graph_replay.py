@@ -1,9 +1,12 @@
 """The r01 finding "NaNs in unrelated tensors after hipGraph replay", pinned.
 
-Root cause (tools/graph_nan_repro.py parts A-G, tools/graph_reduce_probe.py, profiles/r02_*): a torch reduction over the
-middle axis of a large tensor inside the captured sampling loop (MeanStdFilter.observe on the [T-1, N, 137] rollout
-buffer) returned wrong sums from the second replay on.  The BLAS library was not involved: its 1- / 12-wide head GEMMs
-replay exactly between canaries.  The loop now keeps its reductions outside the captured region."""
+What was found (tools/graph_reduce_probe.py, profiles/r02_graph_reduce_probe.json, r02_nan_repro_*.json; the bisection script
+tools/graph_nan_repro.py drove the torch learner machinery that r03 removed and lives in git history, commit 12bcd55): a torch
+reduction over the middle axis of a large tensor inside the captured sampling loop (MeanStdFilter.observe on the [T-1, N, 137]
+rollout buffer) returned wrong sums from the second replay on — only the second reduction of the variant without a temporary,
+so the cause is layout-dependent (semaphore / memset-node aliasing in the graph's pool is the suspect) and NOT pinned below
+torch.  The BLAS library was not involved: its 1- / 12-wide head GEMMs replay exactly between canaries.  The loop keeps its
+reductions outside the captured region, and nothing captured reduces with torch any more."""
 import numpy as np
 import pytest
 import torch
@@ -37,7 +40,7 @@ def test_formerly_failing_configuration_stays_finite_and_blas_heads_respect_thei
     # 32 768-sample minibatches): the moments the loop accumulates must equal a float64 recomputation from the very
     # buffers it read, at every iteration, and everything stays finite
     env = PioneerVectorEnv(16384, device=dev, seed=0, engine_config=EngineConfig(max_episode_steps=500))
-    tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=2, sgd_minibatch_size=32768, amp_bf16=True),
+    tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=2, sgd_minibatch_size=32768),
                     use_graph=True)
     T = tr.cfg.rollout_fragment_length
     prev = torch.empty_like(tr.raw_obs)

@@ -52,7 +52,7 @@ LEARNER_WORKER = r'''
 import json, os, sys, torch
 import torch.distributed as dist
 sys.path.insert(0, os.environ["PNR_ROOT"])
-from pioneer_amd.ppo import PPOConfig, PPOLearner
+from pioneer_amd.ppo import PPOConfig, PPOLearner, gaussian_logp
 rank = int(os.environ["RANK"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
@@ -60,30 +60,26 @@ dev = torch.device("cuda", 0)
 B = 4096
 g = torch.Generator(device=dev).manual_seed(100 + rank)           # every rank its own share of the batch
 R = lambda *s: torch.randn(*s, generator=g, device=dev)
-batch = {"obs": R(B, 137), "actions": R(B, 6), "mean": 0.1 * R(B, 6), "log_std": 0.1 * R(B, 6),
-         "logp": -8.0 + R(B), "values": R(B), "adv": R(B), "vtarg": R(B)}
-res = {}
-for use_graph in (False, True):
-    cfg = PPOConfig(num_sgd_iter=3, sgd_minibatch_size=B // 2, lr=1e-3, seed=11, amp_bf16=False)
-    lr = PPOLearner(cfg, dev, use_graph=use_graph)
-    pg = torch.Generator(device=dev).manual_seed(5)                # same minibatch permutations in both runs
-    infos = [lr.update(dict(batch), pg) for _ in range(3)]        # 18 updates: 3 eager, capture, 14 replays
-    w = torch.cat([p.detach().reshape(-1).double().cpu() for p in lr.model.parameters()])
-    res[str(use_graph)] = {"w": w, "kl": infos[-1]["kl"], "graphed": lr._graph is not None and lr._graph_b is not None,
-                           "split": bool(lr._split)}
-diff = float((res["True"]["w"] - res["False"]["w"]).abs().max())
-move = float((res["False"]["w"] - torch.cat([p.detach().reshape(-1).double().cpu() for p in PPOLearner(cfg, dev).model.parameters()])).abs().max())
-json.dump({"rank": rank, "diff": diff, "move": move, "graphed": res["True"]["graphed"], "split": res["True"]["split"],
-           "wsum_graph": float(res["True"]["w"].sum()), "wsum_eager": float(res["False"]["w"].sum()),
-           "kl_graph": res["True"]["kl"], "kl_eager": res["False"]["kl"]},
+act, mean, log_std = R(B, 6), 0.1 * R(B, 6), 0.1 * R(B, 6)
+batch = {"obs": R(B, 137), "actions": act, "mean": mean, "log_std": log_std, "logp": gaussian_logp(act, mean, log_std) + 0.2 * R(B),
+         "values": R(B), "adv": R(B), "vtarg": R(B)}
+cfg = PPOConfig(num_sgd_iter=3, sgd_minibatch_size=B // 2, lr=1e-3, seed=11)
+L = PPOLearner(cfg, dev)
+w0 = torch.cat([p.detach().reshape(-1).double().cpu() for p in L.model.parameters()])
+infos = [L.update(dict(batch)) for _ in range(3)]                # 18 updates, each with its gradient all-reduce
+w = torch.cat([p.detach().reshape(-1).double().cpu() for p in L.model.parameters()])
+m, v, step = L.hip_mlp(1).adam_state()
+json.dump({"rank": rank, "hip": bool(L.hip), "flat_bucket": L._flat_grad is not None, "move": float((w - w0).abs().max()),
+           "wsum": float(w.sum()), "wabs": float(w.abs().sum()), "msum": float(m.double().sum()), "vsum": float(v.double().sum()),
+           "step": float(step), "kl": [i["kl"] for i in infos], "total_loss": [i["total_loss"] for i in infos]},
           open(os.path.join(os.environ["PNR_OUT"], f"learner{rank}.json"), "w"))
 dist.destroy_process_group()
 '''
 
 
-def test_split_graph_learner_equals_eager_across_two_ranks(tmp_path):
-    """Several ranks: graph A (loss -> backward into the flat bucket), eager all-reduce, graph B (Adam)
-    must give the weights of the eager data-parallel update, identically on both ranks."""
+def test_hip_learner_keeps_two_ranks_in_lock_step(tmp_path):
+    """Several ranks on the kernels: every update's gradient is all-reduced before Adam, so master weights, Adam's moments and
+    the reported (rank-averaged) losses are identical on both ranks although each rank trains on its own share of the batch."""
     script = tmp_path / "learner.py"
     script.write_text(LEARNER_WORKER)
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
@@ -94,11 +90,11 @@ def test_split_graph_learner_equals_eager_across_two_ranks(tmp_path):
     assert res.returncode == 0, res.stderr[-3000:]
     r0 = json.load(open(tmp_path / "learner0.json")); r1 = json.load(open(tmp_path / "learner1.json"))
     for r in (r0, r1):
-        assert r["graphed"] and r["split"], r                     # the two-graph path really ran
+        assert r["hip"] and r["flat_bucket"] and r["step"] == 18.0, r
         assert r["move"] > 1e-3                                    # the weights did move
-        assert r["diff"] < 2e-5, r                                 # fp32, capturable vs plain Adam arithmetic
-        assert abs(r["kl_graph"] - r["kl_eager"]) < 1e-5
-    assert r0["wsum_graph"] == r1["wsum_graph"] and r0["wsum_eager"] == r1["wsum_eager"]   # ranks in lock-step
+        assert all(np.isfinite(x) for x in r["kl"] + r["total_loss"])
+    for k in ("wsum", "wabs", "msum", "vsum", "kl", "total_loss"):
+        assert r0[k] == r1[k], (k, r0[k], r1[k])                   # ranks in lock-step, bit for bit
 
 
 RCCL_WORKER = r'''
@@ -114,8 +110,7 @@ pdist.is_dist = lambda: dist.is_initialized()       # take the multi-rank code p
 from pioneer_amd import PioneerVectorEnv, EngineConfig
 from pioneer_amd.ppo import PPOConfig, PPOTrainer
 env = PioneerVectorEnv(2048, device=dev, seed=3, engine_config=EngineConfig(max_episode_steps=40))
-tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=16, num_sgd_iter=3, sgd_minibatch_size=8192, lr=3e-4, seed=3,
-                               amp_bf16=True), use_graph=True)
+tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=16, num_sgd_iter=3, sgd_minibatch_size=8192, lr=3e-4, seed=3), use_graph=True)
 rows = [tr.train() for _ in range(5)]
 json.dump({"backend": dist.get_backend(), "sampling_graph": tr._graph is not None,
            "hip": bool(tr.learner.hip), "flat_bucket": tr.learner._flat_grad is not None,

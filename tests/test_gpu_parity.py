@@ -211,6 +211,77 @@ def test_sharding_invariance():
         e.close()
 
 
+def test_split_batch_on_two_streams_equals_one_launch_bit_for_bit():
+    """bench.py's headline variant (config.variant): the 65 536 envs as TWO handles of 32 768 whose launches go to two
+    streams and write disjoint row ranges of the SAME output buffers, 40 steps across auto-resets, eager and replayed from
+    a hipGraph, against one handle stepped with one launch per step: observations, rewards, flags and the final state are
+    identical bit for bit."""
+    import ctypes as C
+    from pioneer_amd import PioneerVectorEnv, EngineConfig, _lib
+    n, K, dev = 65536, 40, torch.device("cuda:0")
+    eng = dict(max_episode_steps=17, auto_reset=True)
+    g = torch.Generator(device=dev).manual_seed(11)
+    amax = None
+    V = C.c_void_p
+
+    def fresh(parts):
+        per = n // parts
+        envs = [PioneerVectorEnv(per, device=dev, seed=3, env_id_offset=i * per, engine_config=EngineConfig(**eng)) for i in range(parts)]
+        for e in envs:
+            e.reset()
+        return envs
+
+    ref = fresh(1)[0]
+    amax = torch.from_numpy(ref.a_max).to(dev)
+    acts = (torch.rand(K, n, 6, generator=g, device=dev) * 2 - 1) * amax
+    want = {k: [] for k in ("obs", "rew", "done", "trunc")}
+    for t in range(K):
+        o, r, d, tr = ref.vector_step(acts[t])
+        want["obs"].append(o); want["rew"].append(r); want["done"].append(d); want["trunc"].append(tr)
+    want = {k: torch.stack(v) for k, v in want.items()}
+    want_state = ref.get_state()
+    assert int(want["done"].sum()) + int(want["trunc"].sum()) > n       # every env was reset at least once on the way
+    ref.close()
+
+    for graph in (False, True):
+        envs = fresh(2)
+        per = n // 2
+        obs = torch.zeros(K, n, 137, device=dev); rew = torch.zeros(K, n, device=dev)
+        done = torch.zeros(K, n, dtype=torch.uint8, device=dev); trunc = torch.zeros(K, n, dtype=torch.uint8, device=dev)
+        main = torch.cuda.current_stream(dev)
+        side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+
+        def enqueue(cur):
+            ev = torch.cuda.Event(); ev.record(cur)
+            for s_ in side:
+                s_.wait_event(ev)
+            for t in range(K):
+                for i, e in enumerate(envs):
+                    o = i * per
+                    _lib.check(e.lib.pnr_step(e._h, V(acts[t, o:].data_ptr()), V(obs[t, o:].data_ptr()), V(rew[t, o:].data_ptr()),
+                                              V(done[t, o:].data_ptr()), V(trunc[t, o:].data_ptr()), None, V(side[i].cuda_stream)), e._h)
+            for s_ in side:
+                e2 = torch.cuda.Event(); e2.record(s_); cur.wait_event(e2)
+
+        if graph:
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(dev)
+            with torch.cuda.stream(cap):
+                gr.capture_begin()
+                enqueue(torch.cuda.current_stream(dev))
+                gr.capture_end()
+            gr.replay()
+        else:
+            enqueue(main)
+        torch.cuda.synchronize()
+        assert torch.equal(obs, want["obs"]) and torch.equal(rew, want["rew"])
+        assert torch.equal(done, want["done"]) and torch.equal(trunc, want["trunc"])
+        assert torch.equal(torch.cat([e.get_state() for e in envs], dim=1), want_state)
+        for e in envs:
+            e.close()
+
+
 def test_full_size_properties_65536():
     """BASELINE full size: size-independent properties over a 65 536-env rollout + oracle spot-check."""
     n = 65536

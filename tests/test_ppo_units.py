@@ -1,34 +1,10 @@
-"""CPU unit tests of the PPO driver's rollout bookkeeping (no GPU, no env): the vectorised
-episode statistics, the prepared observation filter and the cached-weight inference path must
-reproduce their step-by-step / autograd counterparts."""
+"""CPU unit tests of the PPO driver's host-side pieces (no GPU, no env): the prepared observation filter against its
+call form, the shifted-sum moments, the config's checkpoint compatibility."""
 import numpy as np
 import pytest
 import torch
 
-from pioneer_amd.ppo import ActorCritic, EpisodeStats, MeanStdFilter, PPOConfig
-
-
-@pytest.mark.parametrize("seed", [0, 1, 2])
-def test_rollout_statistics_equal_step_by_step(seed):
-    g = torch.Generator().manual_seed(seed)
-    T, N = 37, 53
-    a, b = EpisodeStats(N, "cpu"), EpisodeStats(N, "cpu")
-    for it in range(4):                                   # carry-over across rollouts included
-        rew = torch.randn(T, N, generator=g)
-        p = 0.0 if it == 2 else 0.08                      # one rollout without any terminal
-        term = (torch.rand(T, N, generator=g) < p).float()
-        if it == 3:
-            term[0] = 1.0; term[-1] = 1.0                 # terminals on the first and the last step
-        for t in range(T):
-            a.step(rew[t], term[t])
-        b.rollout(rew, term)
-        assert torch.allclose(a.ret, b.ret, atol=1e-5) and torch.equal(a.len, b.len)
-        assert float(a.w_cnt) == float(b.w_cnt) and float(a.w_len) == float(b.w_len)
-        assert abs(float(a.w_sum) - float(b.w_sum)) < 1e-3 * max(1.0, abs(float(a.w_sum)))
-        if float(a.w_cnt) > 0:
-            assert abs(float(a.w_max) - float(b.w_max)) < 1e-5 and abs(float(a.w_min) - float(b.w_min)) < 1e-5
-        ra, rb = a.summarize(), b.summarize()
-        assert ra["episodes_this_iter"] == rb["episodes_this_iter"] and ra["episodes_total"] == rb["episodes_total"]
+from pioneer_amd.ppo import ActorCritic, MeanStdFilter, PPOConfig
 
 
 def test_prepared_filter_equals_call():
@@ -46,22 +22,15 @@ def test_prepared_filter_equals_call():
     assert torch.allclose(f2.apply_(big, out=torch.empty_like(big)), f2(big), rtol=1e-6)
 
 
-def test_cached_inference_equals_forward():
-    torch.manual_seed(0)
+def test_config_from_dict_reads_old_checkpoints():
+    """Checkpoints of r01 / r02 carry `amp_bf16` in their cfg dict: read as `hip_kernels`; unknown keys are dropped."""
+    c = PPOConfig.from_dict({"fcnet_hiddens": [256, 256], "lr": 1e-4, "amp_bf16": False, "some_removed_option": 3})
+    assert c.fcnet_hiddens == (256, 256) and c.lr == 1e-4 and c.hip_kernels is False
+    assert PPOConfig.from_dict(PPOConfig().__dict__) == PPOConfig()
+    assert not PPOConfig().wants_hip("cpu") and PPOConfig().wants_hip("cuda:0") and not PPOConfig(fcnet_hiddens=(64, 64)).wants_hip("cuda:0")
     m = ActorCritic(PPOConfig())
-    obs = torch.randn(33, 137)
-    mean, log_std, v = m(obs)
-    m.refresh_inference_cache(False)
-    xin = torch.zeros(33, 144); xin[:, :137] = obs
-    head, vc = m.forward_cached(xin)
-    assert torch.allclose(head[:, :6], mean, atol=1e-6) and torch.allclose(head[:, 6:].clamp(-20, 2), log_std, atol=1e-6)
-    assert torch.allclose(vc.squeeze(-1), v, atol=1e-6)
-    with torch.no_grad():                                                    # the cache follows the parameters
-        for p in m.parameters():
-            p.add_(0.01)
-    m.refresh_inference_cache(False)
-    mean2 = m(obs)[0]
-    assert torch.allclose(m.forward_cached(xin)[0][:, :6], mean2, atol=1e-6) and not torch.allclose(mean2, mean)
+    mean, log_std, v = m(torch.randn(33, 137))
+    assert mean.shape == (33, 6) and log_std.shape == (33, 6) and v.shape == (33,) and float(log_std.max()) <= 2.0
 
 
 def test_constant_obs_columns_filter_to_exactly_zero():

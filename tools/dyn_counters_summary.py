@@ -39,7 +39,10 @@ def one(path, needle, steps):
 
 def main():
     step, roll, out = sys.argv[1:4]
-    res = {"_how": HOW, "kernels": {"dyn_step_kernel<1,1,1,0>": one(step, "dyn_step_kernel", 1),
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pioneer_amd import _lib
+    res = {"_how": HOW, "csrc_sha16": _lib.source_fingerprint(), "kernels": {"dyn_step_kernel<1,1,1,0>": one(step, "dyn_step_kernel", 1),
                                     "dyn_rollout_kernel<1,1,1,0>": one(roll, "dyn_rollout_kernel", 32)}}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res["kernels"].items():

@@ -23,6 +23,10 @@ def main():
         doc = json.load(open(out))
     except Exception:
         doc = {}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pioneer_amd import _lib
+    doc["csrc_sha16"] = _lib.source_fingerprint()      # the env-kernel sources these passes ran on (bench.py checks it)
     doc.setdefault("_how", "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the bench's main leg; KiB per dispatch")
     doc["kinematic:env_major:65536:1"] = {
         "profile": label, "fetch_size_kib_mean": f_kib, "write_size_kib_mean": w_kib, "dispatches": n,

@@ -14,7 +14,7 @@ os.makedirs(out, exist_ok=True)
 eng = EngineConfig(max_episode_steps=500, mode="dynamic", pd_kp=400.0, pd_kd=40.0, pd_inertia_scaled=True) if dynamic \
     else EngineConfig(max_episode_steps=500)
 env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=eng)
-tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=32768, lr=1e-4, amp_bf16=True,
+tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=32768, lr=1e-4, 
                                entropy_coeff_start=3e-3, entropy_decay_steps=100_000_000, seed=0), use_graph=True)
 for _ in range(iters):
     r = tr.train()

@@ -14,7 +14,7 @@ scaled = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False  # gains per uni
 bf16 = bool(int(sys.argv[7])) if len(sys.argv) > 7 else True     # 0: float32 torch learner (autograd, BLAS) instead of the HIP kernels
 lr = float(sys.argv[8]) if len(sys.argv) > 8 else 3e-4
 env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500, mode=mode, pd_kp=kp, pd_kd=kd, pd_inertia_scaled=scaled))
-cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, lr=lr, amp_bf16=bf16,
+cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, lr=lr, hip_kernels=bf16,
                 entropy_coeff_start=3e-3, entropy_decay_steps=100_000_000, seed=0)
 tr = PPOTrainer(env, cfg, use_graph=True)
 t0 = time.time(); rows = []
