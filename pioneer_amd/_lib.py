@@ -198,10 +198,12 @@ def _stale() -> bool:
     return _newer(deps, LIB_PATH)
 
 
-def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None) -> str:
+def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None, units=None) -> str:
     """hipcc --offload-arch=gfx950 -> pioneer_amd/csrc/libpioneer_amd.so (in-tree): the two translation units are compiled in
     parallel (only those whose sources changed) and linked.  extra_flags / out_path build a variant next to it (e.g.
-    -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B, -DPNR_DIAG_BUILD=1 for the timing-only ablations), with objects of its own."""
+    -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B, -DPNR_DIAG_BUILD=1 for the timing-only ablations), with objects of its own;
+    `units` names the translation units the flags concern (e.g. ("pnr_learn.hip",) for an MLP kernel A/B: seconds instead of
+    minutes) — the others are linked from the default build's objects."""
     variant = out_path is not None or bool(extra_flags)
     if variant:
         force = True
@@ -214,9 +216,16 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
         raise RuntimeError("hipcc not found: cannot build libpioneer_amd.so")
     tag = ("." + os.path.splitext(os.path.basename(out_path))[0]) if variant else ""
     procs, objs = [], []
+    own = []
     for unit, deps in UNITS.items():
+        if variant and units is not None and unit not in units:
+            objs.append(_obj_path(unit))                 # the default build's object (build_library() must have run)
+            if not os.path.exists(objs[-1]):
+                raise RuntimeError(f"{objs[-1]} is missing: build the default library first")
+            continue
         obj = _obj_path(unit, tag)
         objs.append(obj)
+        own.append(obj)
         if not force and not _newer([os.path.join(CSRC, d) for d in deps] + [HEADER], obj):
             continue
         cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, os.path.join(CSRC, unit)]
@@ -231,7 +240,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True, cwd=CSRC)
     if variant:
-        for o in objs:
+        for o in own:
             os.remove(o)
     return out_path or LIB_PATH
 

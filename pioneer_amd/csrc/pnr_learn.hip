@@ -26,6 +26,12 @@ static int fail(pnr_handle, int code, const char* fmt, ...)
     return rc;
 }
 
+#if PNR_MLP_STAMPS
+// diagnostic variant only (tools/mlp_stamps.py): where the fused kernel's waves write their phase stamps
+static unsigned long long* g_mlp_stamps = nullptr;
+extern "C" int pnr_mlp_set_stamp_buffer(void* p) { g_mlp_stamps = static_cast<unsigned long long*>(p); return 0; }
+#endif
+
 extern "C" {
 
 int pnr_ppo_loss(int64_t batch, const int64_t* idx, const float* head_policy, const float* head_value, const float* actions,
@@ -359,6 +365,9 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     F.clip = s->clip_param; F.vf_clip = s->vf_clip_param; F.vf_coeff = s->vf_loss_coeff;
     F.g_head = s->g_head; F.partials = s->partials; F.adam_step = s->adam_step;
     F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
+#if PNR_MLP_STAMPS
+    F.stamps = g_mlp_stamps;
+#endif
     hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, thr, 0, st, F);
     if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
         hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,

@@ -48,7 +48,9 @@ constexpr int kMlpBM = PNR_MLP_BM;   // samples per workgroup tile (forward / ba
                                      // registers, i.e. two workgroups per CU whose phases overlap; 128 -> one (A/B in DESIGN.md)
 constexpr int kMlpCB = kMlpBM / 32;  // 32-sample column blocks per tile
 static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implemented");
-// PNR_MLP_DIAG: timing-only ablations of the forward kernel (results are wrong when set; tools/mlp_ablation.py)
+// PNR_MLP_DIAG: timing-only ablations of the forward kernel (results are wrong when set; tools/mlp_ablation.py): 1 no tanh,
+// 2 no observation loads, 4 / 8 no layer-2 / layer-1 product, 16 no head, 32 no forward epilogues, 64 no tile stores (h1, h2,
+// dz2, dz1), 128 no H1 reload, 256 no loss (record loads and arithmetic)
 #ifndef PNR_MLP_RING
 #define PNR_MLP_RING 5            // depth of the weight-fragment prefetch ring (A/B: tools/mlp_variant_ab.py)
 #endif
@@ -56,6 +58,18 @@ static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implem
 #define PNR_MLP_DIAG 0
 #endif
 constexpr int kMlpThreads = 256;  // four waves
+// PNR_MLP_STAMPS=1 (a diagnostic variant, tools/mlp_stamps.py): every wave of the fused kernel writes s_memtime at its phase
+// boundaries into a buffer of its own (no output depends on it).  The product build carries none of it.
+#ifndef PNR_MLP_STAMPS
+#define PNR_MLP_STAMPS 0
+#endif
+constexpr int kMlpStampSlots = 26;   // 0..22 phase boundaries (s_memtime), 24 / 25 s_memrealtime (100 MHz) at start / end
+#if PNR_MLP_STAMPS
+#define MLP_STAMP(i) do { if (P.stamps && lane == 0) { unsigned long long* sp_ = P.stamps + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + w) * kMlpStampSlots; \
+    sp_[(i)] = __builtin_amdgcn_s_memtime(); if ((i) == 0) sp_[24] = __builtin_amdgcn_s_memrealtime(); if ((i) == 22) sp_[25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define MLP_STAMP(i) do { } while (0)
+#endif
 
 // packed bf16 weights of ONE net, element offsets.  Every matrix is stored FRAGMENT-NATIVE: the 32 x 16 (or 16 x 32) block
 // that one MFMA consumes as its A operand is 1 KiB contiguous in lane order, so a wave's fragment load is one fully
@@ -155,40 +169,91 @@ __device__ __forceinline__ float tanh_fast(float x)
 
 __device__ __forceinline__ bf16x8 ld_global_bf16x8(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
+// Workgroup rendezvous for hand-offs that go through LDS only (every tile exchange in these kernels): the wave's DS operations
+// have completed (lgkmcnt), then s_barrier.  __syncthreads() additionally waits for vmcnt(0), i.e. for every global store
+// and prefetched weight fragment still in flight — each barrier then costs a write acknowledgement from HBM (the tile stores of
+// h1 / h2 / dz2 / dz1) or an L2 round trip (the next product's first weight fragments).  PNR_MLP_LDS_BARRIER=0 restores it (A/B).
+#ifndef PNR_MLP_SCHED_PIN
+#define PNR_MLP_SCHED_PIN 0       // 1: pin every k-step's [fragment loads][LDS reads][MFMAs] order (A/B r03: no gain in the fused kernel, +20 % time in the sampler's forward)
+#endif
+#ifndef PNR_MLP_LDS_BARRIER
+#define PNR_MLP_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void mlp_barrier()
+{
+#if PNR_MLP_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // acc[rb][cb] += W[64 rows of this wave][K] . tile[BM samples][K]^T.  W: fragment-native packing (global, L2);
-// tile: LDS, row stride STRIDE.
+// tile: LDS, row stride STRIDE.  Two steps, so that the first D - 1 k-steps of weight fragments can be requested EARLY
+// (prefetch()): ahead of a tile store to HBM — a wave's vector-memory operations return in order, so fragments requested
+// behind a 32 KB store wait for its acknowledgement — and ahead of the epilogue / barrier in front of the product.
+template <int K, int STRIDE>
+struct MlpGemm {
+    static constexpr int KS = K / 16;
+    static constexpr int D = PNR_MLP_RING;     // A fragments run D - 1 k-steps ahead of their use (L2 latency ~ 2-3 k-steps of MFMAs)
+    bf16x8 a[D][2];
+    const __bf16* wa;
+    // w_blocks: the first of this wave's two row-blocks in the fragment-native packing: block (rb, ks) at (rb KS + ks) * 512
+    __device__ __forceinline__ void prefetch(const __bf16* __restrict__ w_blocks, int lane)
+    {
+        wa = w_blocks + lane * 8;
+#pragma unroll
+        for (int p = 0; p < D - 1; ++p) {
+            if (p < KS) {
+                a[p][0] = ld_global_bf16x8(wa + 512 * p);
+                a[p][1] = ld_global_bf16x8(wa + 512 * (KS + p));
+            }
+        }
+    }
+    // `after_loads` runs once, right behind the product's LAST fragment load (k-step KS - D): the place for a tile store to
+    // HBM — nothing this product still needs can queue behind it, and it drains under the remaining MFMAs and the epilogue
+    template <class F>
+    __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[2][kMlpCB], int lane, F&& after_loads)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const __bf16* tb = tile + r * STRIDE + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + D - 1 < KS) {
+                a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
+                a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 512 * (KS + ks + D - 1));
+            }
+            if (ks == (KS > D ? KS - D : 0)) {
+                __builtin_amdgcn_sched_barrier(0);
+                after_loads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 b[kMlpCB];
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < kMlpCB; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][rb], b[cb], acc[rb][cb], 0, 0, 0);
+#if PNR_MLP_SCHED_PIN
+            // pin the k-step's shape in the emitted code: [the two fragment loads for k-step ks + D - 1] [this k-step's
+            // LDS reads] [its MFMAs].  Left to itself hipcc sinks the fragment loads next to their use (some directly in
+            // front of an s_waitcnt vmcnt(0)), which exposes an L2 round trip inside every product.
+            if (ks + D - 1 < KS) __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, kMlpCB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 2 * kMlpCB, 0);
+#endif
+        }
+    }
+};
+
 template <int K, int STRIDE>
 __device__ __forceinline__ void mlp_gemm_w_xt(const __bf16* __restrict__ w_blocks, const __bf16* tile, f32x16 (&acc)[2][kMlpCB], int lane)
 {
-    // w_blocks: the first of this wave's two row-blocks in the fragment-native packing: block (rb, ks) at (rb KS + ks) * 512
-    constexpr int KS = K / 16;
-    const int r = lane & 31, h = lane >> 5;
-    const __bf16* wa = w_blocks + lane * 8;
-    const __bf16* tb = tile + r * STRIDE + 8 * h;
-    constexpr int D = PNR_MLP_RING;           // A fragments run D - 1 k-steps ahead of their use (L2 latency ~ 2-3 k-steps of MFMAs)
-    bf16x8 a[D][2];
-#pragma unroll
-    for (int p = 0; p < D - 1; ++p) {
-        if (p < KS) {
-            a[p][0] = ld_global_bf16x8(wa + 512 * p);
-            a[p][1] = ld_global_bf16x8(wa + 512 * (KS + p));
-        }
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (ks + D - 1 < KS) {
-            a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
-            a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 512 * (KS + ks + D - 1));
-        }
-        bf16x8 b[kMlpCB];
-#pragma unroll
-        for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][rb], b[cb], acc[rb][cb], 0, 0, 0);
-    }
+    MlpGemm<K, STRIDE> g;
+    g.prefetch(w_blocks, lane);
+    g.run(tile, acc, lane, [] {});
 }
 
 __device__ __forceinline__ void mlp_zero_acc(f32x16 (&acc)[2][kMlpCB])
@@ -216,6 +281,82 @@ __device__ __forceinline__ void mlp_bias_acc(f32x16 (&acc)[2][kMlpCB], const flo
                 for (int j = 0; j < 4; ++j) acc[rb][cb][4 * q + j] = bq[j];
         }
 }
+
+// The same in two steps: the eight 16-byte bias loads of a wave are REQUESTED early — in front of the product's weight-fragment
+// prefetch, so that they are the older operations (vector-memory results return in order: asked for behind the fragments, as
+// the accumulators' initial values, each bias load made the compiler wait for vmcnt(0), draining the prefetch ring inside the
+// product) — and consumed when the accumulators are initialised.
+struct MlpBias {
+    f32x4 q[2][4];
+    __device__ __forceinline__ void load(const float* __restrict__ b, int w, int h)
+    {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[rb][k] = *reinterpret_cast<const f32x4*>(b + 64 * w + 32 * rb + 8 * k + 4 * h);
+    }
+    __device__ __forceinline__ void init(f32x16 (&acc)[2][kMlpCB]) const
+    {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[rb][cb][4 * k + j] = q[rb][k][j];
+    }
+};
+
+// The tile's share of the rollout record, FUSED kernel, contiguous rows (no idx): requested early by all 256 threads as 16-byte
+// pieces (policy net: actions | mean | log_std [64][6], adv, logp [64]; value net: vtarg, values [64]), parked in the dead input
+// tile before the loss.  Read by the loss wave with per-sample loads behind the idx gather it was a dependent HBM round trip in
+// the middle of the tile's chain (7.7 us of the launch in the timing-only ablation, profiles/r03_b_mlp_fused_ablation.json).
+constexpr int kRecLdsFloats = 3 * kMlpBM * kMlpAct + 2 * kMlpBM;          // 1 280
+struct MlpRecordTile {
+    f32x4 v[2];
+    __device__ __forceinline__ static const float* piece(const float* const (&src)[5], int net, int j, long long row0, long long B, bool& ok)
+    {
+        // piece j of the tile: policy 0..95 actions, 96..191 mean, 192..287 log_std, 288..303 adv, 304..319 logp; value 0..15 vtarg, 16..31 values
+        int arr, off;
+        if (net == 0) { if (j < 288) { arr = j / 96; off = (j % 96) * 4; } else { arr = 3 + (j - 288) / 16; off = ((j - 288) % 16) * 4; } }
+        else { arr = 3 + j / 16; off = (j % 16) * 4; }
+        const long long per = (net == 0 && arr < 3) ? kMlpAct : 1;
+        const long long e = row0 * per + off;                   // first element of the piece in its array
+        ok = e + 3 < B * per;
+        return src[arr] + e;
+    }
+    __device__ __forceinline__ void load(const float* const (&src)[5], int net, long long row0, long long B, int tid)
+    {
+        const int n = net == 0 ? 320 : 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = tid + kMlpThreads * i;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bool ok = false;
+            if (j < n) {
+                const float* p = piece(src, net, j, row0, B, ok);
+                typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // a caller's slice may start on any float
+                if (ok) v[i] = *reinterpret_cast<const f32x4u*>(p);
+                else {                                          // the batch's last, partial tile: element by element
+                    const long long per = (net == 0 && j < 288) ? kMlpAct : 1;
+                    const long long e0 = p - src[net == 0 ? (j < 288 ? j / 96 : 3 + (j - 288) / 16) : 3 + j / 16];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (e0 + k < B * per) v[i][k] = p[k];
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void park(float* lds, int net, int tid) const
+    {
+        const int n = net == 0 ? 320 : 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = tid + kMlpThreads * i;
+            if (j < n) *reinterpret_cast<f32x4*>(lds + (net == 0 ? 4 * j : 3 * kMlpBM * kMlpAct + 4 * j)) = v[i];
+        }
+    }
+};
 
 // copy a [BM][256] bf16 tile between LDS (row stride kHS) and row-major global rows [row0, row0 + BM) of n_rows
 __device__ __forceinline__ void mlp_store_htile(const __bf16* tile, __bf16* __restrict__ dst, long long row0, long long n_rows, int tid)
@@ -277,6 +418,7 @@ struct MlpFwdParams {
     float* adam_step;          // the optimiser's update count (device scalar), incremented once per launch; or null
     __bf16* dz1;               // [2][B][256]
     __bf16* dz2;
+    unsigned long long* stamps; // PNR_MLP_STAMPS builds only: [workgroups][4 waves][kMlpStampSlots] cycle stamps, or null
 };
 
 // Forward pass of one 64-sample tile through one net: grid (ceil(B / 64), nets), 256 threads.
@@ -295,6 +437,14 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     const long long row0 = (long long)blockIdx.x * kMlpBM;
     const __bf16* wp = P.wpack + (size_t)net * kPackElems;
     const float* bias = P.bias + net * kBiasElems;
+    // layer 1's bias and first weight fragments do not depend on the tile: requested before anything else, the bias first
+    MLP_STAMP(0);
+    MlpBias bias1;
+    bias1.load(bias, w, lane >> 5);
+    __builtin_amdgcn_sched_barrier(0);
+    MlpGemm<kMlpInPad, kXS> g1;
+    g1.prefetch(wp + kOffW1 + 2 * w * (kMlpInPad / 16) * 512, lane);
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (FUSED) {       // this launch is one optimiser update: counted here, read by the Adam kernel two launches on
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
     }
@@ -302,12 +452,21 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero)
     {
         float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
-        if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy
-            for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kMlpThreads) {
-                const int row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (row0 + row < P.B) v = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
-                *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = v;
+        if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy,
+            // every load of the thread in flight before the first LDS write (as a load -> write loop it was five dependent
+            // HBM round trips per tile: 7 600 of a tile's 52 000 cycles in the phase stamps, profiles/r03_b_mlp_stamps.json)
+            constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kMlpThreads - 1) / kMlpThreads;
+            uint4 v[kIt];
+#pragma unroll
+            for (int i = 0; i < kIt; ++i) {
+                const int ch = tid + kMlpThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (ch < kCh && row0 + row < P.B) v[i] = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < kIt; ++i) {
+                const int ch = tid + kMlpThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                if (ch < kCh) *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = v[i];
             }
         } else {
         if (P.f_loc) {
@@ -317,7 +476,7 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
                 fv[i] = k < kMlpIn ? src[k] : 0.f;
             }
         }
-        __syncthreads();
+        mlp_barrier();
         // two threads per row, 72 columns each: every load of the thread (18 unaligned 16-byte loads; a row starts on a
         // 4-byte boundary only) is issued before the first use.  Written as a loop over (row, column pair) with one
         // dependent idx -> row load per iteration this stage was a chain of ~36 memory round trips per thread:
@@ -357,7 +516,7 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
             }
         }
         }
-        __syncthreads();
+        mlp_barrier();
         if (P.xs && net == 0) {                                   // the input is the same for both nets: saved once
             for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kMlpThreads) {
                 const int row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
@@ -367,6 +526,7 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
         }
     }
 
+    MLP_STAMP(1);                         // stage 0 done (tile in LDS, barrier passed)
     const int c = lane & 31, h = lane >> 5;
     f32x16 acc[2][kMlpCB];
     // tanh in registers (the bias is what the accumulators started from), each register quad = four consecutive features
@@ -386,19 +546,51 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     };
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
-    mlp_bias_acc(acc, bias, w, h);
-    if (!(PNR_MLP_DIAG & 8)) mlp_gemm_w_xt<kMlpInPad, kXS>(wp + kOffW1 + 2 * w * (kMlpInPad / 16) * 512, xt, acc, lane);
+    bias1.init(acc);
+    if (!(PNR_MLP_DIAG & 8)) g1.run(xt, acc, lane, [] {});
+    MLP_STAMP(2);                         // layer-1 product issued
     if (!(PNR_MLP_DIAG & 32)) epilogue();
-    __syncthreads();
-    if (P.h1) mlp_store_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+    MLP_STAMP(3);                         // layer-1 epilogue
+    // layer 2's first weight fragments are requested BEFORE the tile store: a wave's vector-memory operations return in
+    // order, so behind the 32 KB store they would wait for its acknowledgement from HBM
+    MlpBias bias2;
+    bias2.load(bias + kMlpHid, w, h);
+    __builtin_amdgcn_sched_barrier(0);
+    MlpGemm<kMlpHid, kHS> g2;
+    g2.prefetch(wp + kOffW2 + 2 * w * (kMlpHid / 16) * 512, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mlp_barrier();
+    MLP_STAMP(4);                         // barrier after the layer-1 epilogue
+    MLP_STAMP(5);
 
-    // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it
-    mlp_bias_acc(acc, bias + kMlpHid, w, h);
-    if (!(PNR_MLP_DIAG & 4)) mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2 + 2 * w * (kMlpHid / 16) * 512, ht, acc, lane);
-    __syncthreads();
+    // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it.  The H1 tile leaves for
+    // HBM from INSIDE the product, behind its last weight-fragment load (timing-only ablation r03: the four tile stores cost
+    // 15 of the kernel's 50 us while every product's fragment loads queued behind one of them)
+    bias2.init(acc);
+    MlpRecordTile rect;
+    const bool rec_early = FUSED && !P.idx && !(PNR_MLP_DIAG & 256);
+    if (!(PNR_MLP_DIAG & 4)) g2.run(ht, acc, lane, [&] {
+        if constexpr (FUSED) {
+            if (rec_early) {
+                // policy: actions, mean, log_std, adv, logp; value: -, -, -, vtarg, values
+                const float* const src[5] = {P.rec_actions, P.rec_mean, P.rec_log_std, net == 0 ? P.rec_adv : P.rec_vtarg, net == 0 ? P.rec_logp : P.rec_values};
+                rect.load(src, net, row0, P.B, tid);
+            }
+        }
+        if (P.h1 && !(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+    });
+    if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
+        if (rec_early) rect.park(reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
+    }
+    MLP_STAMP(6);                         // layer-2 product issued
+    mlp_barrier();
+    MLP_STAMP(7);
     if (!(PNR_MLP_DIAG & 32)) epilogue();
-    __syncthreads();
-    if (P.h2) mlp_store_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+    MLP_STAMP(8);                         // layer-2 epilogue
+    mlp_barrier();
+    MLP_STAMP(9);
+    if (P.h2 && !(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+    MLP_STAMP(10);                        // H2 store issued
 
     // ---- layer 3: head^T [16][samples] = W3 . H2^T + b3 with 16x16x32 MFMAs; wave w owns BM / 4 samples
     if (!(PNR_MLP_DIAG & 16)) {
@@ -466,21 +658,38 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
         }
     }
 
+    MLP_STAMP(11);                        // head product + its stores
     if constexpr (FUSED) {
         float* hd = reinterpret_cast<float*>(xt);                         // [64][16] float32 head rows (written above)
         __bf16* gt = xt + kMlpBM * kMlpHead * 2;                          // [64][kGS] bf16 head gradients, behind them
-        __syncthreads();
+        // W3^T's two fragments for the first backward product: requested before the loss (waves 1-3 wait there anyway)
+        bf16x8 w3t[2];
+        {
+            const __bf16* wa = wp + kOffW3T + 2 * w * 512 + lane * 8;
+            w3t[0] = ld_global_bf16x8(wa); w3t[1] = ld_global_bf16x8(wa + 512);
+        }
+        mlp_barrier();
+        MLP_STAMP(12);                    // barrier before the loss
         // ---- the tile's loss: wave 0, thread = sample (pnr_ppo.h: the per-sample halves ppo_loss_kernel is made of)
         if (w == 0) {
             const long long b = row0 + lane;
-            const bool live = b < P.B;
+            const bool live = b < P.B && !(PNR_MLP_DIAG & 256);
             const float invB = 1.0f / (float)P.B;
             // the sample's rollout record (behind the idx gather), loaded here rather than prefetched: 22 registers live
             // across the three products cost the third workgroup per CU, which hides this round trip anyway
             float rec_a[6], rec_m0[6], rec_l0[6], rec_adv = 0.f, rec_lp0 = 0.f, rec_vt = 0.f, rec_v0 = 0.f;
 #pragma unroll
             for (int j = 0; j < 6; ++j) { rec_a[j] = 0.f; rec_m0[j] = 0.f; rec_l0[j] = 0.f; }
-            if (live) {
+            if (live && rec_early) {
+                const float* rl = reinterpret_cast<const float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2;
+                if (net == 0) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { rec_a[j] = rl[lane * 6 + j]; rec_m0[j] = rl[384 + lane * 6 + j]; rec_l0[j] = rl[768 + lane * 6 + j]; }
+                    rec_adv = rl[1152 + lane]; rec_lp0 = rl[1216 + lane];
+                } else {
+                    rec_vt = rl[1152 + lane]; rec_v0 = rl[1216 + lane];
+                }
+            } else if (live) {
                 const long long r = P.idx ? P.idx[b] : b;
                 if (net == 0) {
 #pragma unroll
@@ -532,7 +741,9 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
                 *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        __syncthreads();
+        MLP_STAMP(13);                    // loss done (wave 0) / nothing (waves 1-3)
+        mlp_barrier();
+        MLP_STAMP(14);                    // barrier after the loss
 
         // acc * (1 - h^2) with h read from the tile at this lane's own quads and the product written over it
         const auto bwd_epilogue = [&]() {
@@ -553,8 +764,6 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
         // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
         mlp_zero_acc(acc);
         {
-            const __bf16* wa = wp + kOffW3T + 2 * w * 512 + lane * 8;
-            const bf16x8 a[2] = {ld_global_bf16x8(wa), ld_global_bf16x8(wa + 512)};
             bf16x8 b[kMlpCB];
 #pragma unroll
             for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
@@ -562,37 +771,52 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < kMlpCB; ++cb)
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[rb], b[cb], acc[rb][cb], 0, 0, 0);
         }
         bwd_epilogue();
-        __syncthreads();
-        mlp_store_htile(ht, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        MLP_STAMP(15);                    // dH2 product + its epilogue
+        MlpGemm<kMlpHid, kHS> g4;                 // W2^T's first fragments ahead of the dZ2 store
+        g4.prefetch(wp + kOffW2T + 2 * w * (kMlpHid / 16) * 512, lane);
+        mlp_barrier();
+        MLP_STAMP(16);                    // barrier after it
 
-        // ---- dH1^T = W2^T . dZ2^T, then H1 into the tile and dZ1 in place over it
+        // ---- dH1^T = W2^T . dZ2^T (the dZ2 tile leaves from inside the product), then H1 into the tile and dZ1 in place over it
         mlp_zero_acc(acc);
-        mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2T + 2 * w * (kMlpHid / 16) * 512, ht, acc, lane);
+        g4.run(ht, acc, lane, [&] {
+            if (!(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        });
+        MLP_STAMP(17);                    // dZ2 store + W2^T product issued
         // H1 comes back (this workgroup wrote it a moment ago: L2) as 16-byte row pieces; requested only now, so that the
         // 32 registers are not live across the product (three workgroups per CU hide the round trip)
         uint4 h1r[kMlpBM / 8];
         {
+            // every thread reads back exactly the pieces it stored itself (mlp_store_htile's mapping); its stores are waited
+            // for explicitly, since no barrier in this kernel waits for global memory any more (the dZ2 store issued before
+            // the product above is the youngest one outstanding)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const __bf16* src = P.h1 + (size_t)net * P.B * kMlpHid;
 #pragma unroll
             for (int i = 0; i < kMlpBM / 8; ++i) {
                 const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
                 h1r[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (row0 + row < P.B) h1r[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
+                if (row0 + row < P.B && !(PNR_MLP_DIAG & 128)) h1r[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
             }
         }
-        __syncthreads();                         // every read of dZ2 (the product and the store above) is done
+        MLP_STAMP(18);                    // H1 reload requested (after vmcnt(0))
+        mlp_barrier();                         // every read of dZ2 (the product and the store above) is done
+        MLP_STAMP(19);
 #pragma unroll
         for (int i = 0; i < kMlpBM / 8; ++i) {
             const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
             *reinterpret_cast<uint4*>(ht + row * kHS + cc * 8) = h1r[i];
         }
-        __syncthreads();
+        mlp_barrier();
+        MLP_STAMP(20);                    // H1 back in the tile
         bwd_epilogue();
-        __syncthreads();
-        mlp_store_htile(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        MLP_STAMP(21);
+        mlp_barrier();
+        if (!(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        MLP_STAMP(22);                    // end
     }
 }
 
@@ -754,7 +978,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
         *reinterpret_cast<bf16x8*>(gt + row * kGS + 8 * half) = pk;
     }
     mlp_load_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
-    __syncthreads();
+    mlp_barrier();
 
     f32x16 acc[2][kMlpCB];
     // acc * (1 - h^2) with h from the activation tile, packed into the gradient tile (same quad layout as forward)
@@ -800,21 +1024,21 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
         }
     }
     epilogue();
-    __syncthreads();                                                               // every wave is done with H2
+    mlp_barrier();                                                               // every wave is done with H2
     mlp_store_htile(dz, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
 #pragma unroll
     for (int i = 0; i < kMlpBM / 8; ++i) {
         const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
         *reinterpret_cast<uint4*>(ht + row * kHS + cc * 8) = h1r[i];
     }
-    __syncthreads();
+    mlp_barrier();
 
     // ---- dH1^T = W2^T . dZ2^T
     mlp_zero_acc(acc);
     mlp_gemm_w_xt<kMlpHid, kHS>(wp + kOffW2T + 2 * w * (kMlpHid / 16) * 512, dz, acc, lane);
-    __syncthreads();                         // all reads of dZ2 done before it is overwritten
+    mlp_barrier();                         // all reads of dZ2 done before it is overwritten
     epilogue();
-    __syncthreads();
+    mlp_barrier();
     mlp_store_htile(dz, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
 }
 
@@ -935,9 +1159,9 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
         ca.load(P.dz2 + nb, kMlpHid, s_begin, s_end, tid);
         cb.load(P.h1 + nb + 128 * part, kMlpHid, s_begin, s_end, tid);
         for (long long s = s_begin; s < s_end; s += kWgChunk) {
-            __syncthreads();                                         // every wave is done with the previous chunk
+            mlp_barrier();                                         // every wave is done with the previous chunk
             ca.store(ta, kTrH, tid); cb.store(tb, kTrHalf, tid);
-            __syncthreads();
+            mlp_barrier();
             if (s + kWgChunk < s_end) {                              // the next chunk travels while this one is multiplied
                 ca.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
                 cb.load(P.h1 + nb + 128 * part, kMlpHid, s + kWgChunk, s_end, tid);
@@ -976,7 +1200,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
         ca.load(P.dz1 + nb, kMlpHid, s_begin, s_end, tid);
         cb.load(P.xs, kMlpInPad, s_begin, s_end, tid);
         for (long long s = s_begin; s < s_end; s += kWgChunk) {
-            __syncthreads();
+            mlp_barrier();
             ca.store(ta, kTrH, tid); cb.store(tb, kTrX, tid);
             if (tid < kWgChunk) {                                     // columns 144..159: a one (real rows only), zeros
                 bf16x8 one = {(__bf16)((s + tid < s_end) ? 1.0f : 0.0f), (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -984,7 +1208,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
                 *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad) = one;
                 *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad + 8) = zero;
             }
-            __syncthreads();
+            mlp_barrier();
             if (s + kWgChunk < s_end) {
                 ca.load(P.dz1 + nb, kMlpHid, s + kWgChunk, s_end, tid);
                 cb.load(P.xs, kMlpInPad, s + kWgChunk, s_end, tid);
@@ -1029,7 +1253,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
         ch2.load(P.h2 + nb, kMlpHid, s_begin, s_end, tid);
         cz2.load(P.dz2 + nb, kMlpHid, s_begin, s_end, tid);
         for (long long s = s_begin; s < s_end; s += kWgChunk) {
-            __syncthreads();
+            mlp_barrier();
             ch2.store(th, kTrH, tid); cz2.store(tz, kTrH, tid);
             if (tid < 2 * kWgChunk) {
                 const int row = tid >> 1, half = tid & 1;
@@ -1043,7 +1267,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
                 for (int j = 0; j < 4; ++j) { pk[j] = (__bf16)g0[j]; pk[4 + j] = (__bf16)g1[j]; }
                 *reinterpret_cast<bf16x8*>(tg + row * kTrG + 8 * half) = pk;
             }
-            __syncthreads();
+            mlp_barrier();
             if (s + kWgChunk < s_end) {
                 ch2.load(P.h2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
                 cz2.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Where a tile of the fused learner kernel (mlp_forward_kernel<true>) spends its cycles: run pnr_mlp_train_step at 32 768
+samples on the diagnostic variant built with -DPNR_MLP_STAMPS=1 (every wave stamps s_memtime at its phase boundaries into a
+buffer of its own) and print, per phase, the median / p10 / p90 over all workgroups of the LAST launch, per wave 0 and waves
+1-3.  Build + run (GPU box):
+  python -c "from pioneer_amd import _lib, os; ..."  (see tools/r03_mlp_ab.sh) ; PNR_LIB_PATH=.../libpioneer_amd_stamps.so python tools/mlp_stamps.py OUT.json"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pioneer_amd import _lib  # noqa: E402
+from pioneer_amd.mlp import HipMLP  # noqa: E402
+from pioneer_amd.ppo import ActorCritic, PPOConfig, gaussian_logp  # noqa: E402
+
+NAMES = ["prefetch W1", "stage 0 (tile copy, barriers)", "layer-1 product", "layer-1 epilogue (tanh)", "barrier", "H1 store issue",
+         "layer-2 product", "barrier", "layer-2 epilogue (tanh)", "W3 fetch + barrier", "H2 store issue", "head product", "W3T fetch + barrier",
+         "loss (wave 0)", "barrier after loss", "dH2 product + epilogue", "W2T prefetch + barrier", "dZ2 store + W2T product",
+         "vmcnt(0) + H1 reload request", "barrier", "H1 into tile + barrier", "dZ1 epilogue", "barrier + dZ1 store issue"]
+
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+dev = torch.device("cuda", 0)
+lib = _lib.load_library()
+raw = C.CDLL(_lib.LIB_PATH)
+if not hasattr(raw, "pnr_mlp_set_stamp_buffer"):
+    sys.exit("this library was not built with -DPNR_MLP_STAMPS=1")
+torch.manual_seed(0)
+model = ActorCritic(PPOConfig()).to(dev)
+mlp = HipMLP(model, B, dev)
+mlp.pack()
+R = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+act, mean, ls = R(B, 6), 0.1 * R(B, 6), 0.1 * R(B, 6)
+rec = {"actions": act, "mean": mean, "log_std": ls, "logp": gaussian_logp(act, mean, ls), "values": R(B), "adv": R(B), "vtarg": R(B)}
+xs = R(B, 144).bfloat16().contiguous()
+klc, entc, means = torch.tensor(0.2, device=dev), torch.tensor(0.01, device=dev), torch.zeros(8, device=dev)
+wgs = (B // 64) * 2
+stamps = torch.zeros((wgs, 4, 26), dtype=torch.int64, device=dev)
+raw.pnr_mlp_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
+for _ in range(10):
+    mlp.train_step(None, None, None, rec, klc, entc, 0.3, 10.0, 1.0, means, 2e-5, xs_in=xs)
+torch.cuda.synchronize()
+full = stamps.cpu().numpy().astype(np.int64)
+st = full[:, :, :23]
+rt0, rt1 = full[:, 0, 24], full[:, 0, 25]                     # s_memrealtime (100 MHz) at start / end of wave 0
+d = np.diff(st, axis=2)                       # [wgs, 4, 22] cycles per phase
+span_us = (rt1.max() - rt0.min()) / 100.0
+tile_us = (rt1 - rt0) / 100.0
+clk = (st[:, 0, 22] - st[:, 0, 0]) / np.maximum(tile_us, 1e-9) / 1e3       # GHz: shader cycles per microsecond of real time
+start_us = (rt0 - rt0.min()) / 100.0
+out = {"workgroups": wgs, "launch_span_us": float(span_us), "tile_cycles_median": int(np.median(st[:, :, 22] - st[:, :, 0])),
+       "tile_us_median": float(np.median(tile_us)), "in_kernel_clock_ghz_median": float(np.median(clk)),
+       "tile_start_us_percentiles_10_50_75_90_100": [float(np.percentile(start_us, q)) for q in (10, 50, 75, 90, 100)], "phases": []}
+print(f"launch span {span_us:.1f} us; a tile takes {out['tile_cycles_median']} cycles = {out['tile_us_median']:.1f} us (median) at "
+      f"{out['in_kernel_clock_ghz_median']:.2f} GHz; tile start times (us) p10/50/75/90/100: {out['tile_start_us_percentiles_10_50_75_90_100']}")
+print(f"{'phase':44s} {'wave0 med':>9s} {'p10':>7s} {'p90':>7s} | {'w1-3 med':>9s} {'p10':>7s} {'p90':>7s}")
+for i in range(22):
+    a, b = d[:, 0, i], d[:, 1:, i].reshape(-1)
+    row = {"phase": NAMES[i + 1], "wave0": [int(np.median(a)), int(np.percentile(a, 10)), int(np.percentile(a, 90))],
+           "waves1_3": [int(np.median(b)), int(np.percentile(b, 10)), int(np.percentile(b, 90))]}
+    out["phases"].append(row)
+    print(f"{NAMES[i + 1]:44s} {row['wave0'][0]:9d} {row['wave0'][1]:7d} {row['wave0'][2]:7d} | {row['waves1_3'][0]:9d} {row['waves1_3'][1]:7d} {row['waves1_3'][2]:7d}")
+early = start_us < 0.25 * span_us
+out["tile_us_first_round"] = float(np.median(tile_us[early]))
+out["tile_us_later"] = float(np.median(tile_us[~early])) if (~early).any() else None
+out["workgroups_first_round"] = int(early.sum())
+print(f"tiles that start in the first quarter of the launch ({out['workgroups_first_round']} workgroups): {out['tile_us_first_round']:.1f} us each; later ones: {out['tile_us_later']}")
+if len(sys.argv) > 1:
+    json.dump(out, open(sys.argv[1], "w"), indent=1)
