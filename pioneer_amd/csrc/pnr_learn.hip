@@ -119,7 +119,7 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
     P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
     P.xs = static_cast<__bf16*>(xs); P.h1 = static_cast<__bf16*>(h1); P.h2 = static_cast<__bf16*>(h2);
     P.B = batch; P.first_net = first_net; P.n_nets = n_nets;
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kMlpThreads), 0,
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kFwdThreads), 0,
                        (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
@@ -215,7 +215,7 @@ int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float
     P.noise = noise; P.a_max = a_max; P.mean = mean; P.log_std = log_std; P.values = values; P.actions = actions;
     P.env_actions = a_max ? env_actions : actions;
     P.xs = static_cast<__bf16*>(xs_out);                     // the nets' input as they saw it, for the learner (or null)
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0,
+    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kFwdThreads), 0,
                        (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
@@ -368,7 +368,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
 #if PNR_MLP_STAMPS
     F.stamps = g_mlp_stamps;
 #endif
-    hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, thr, 0, st, F);
+    hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, dim3(kFwdThreads), 0, st, F);
     if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
         hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
                            s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);

@@ -65,7 +65,7 @@ constexpr int kMlpThreads = 256;  // four waves
 #endif
 constexpr int kMlpStampSlots = 26;   // 0..22 phase boundaries (s_memtime), 24 / 25 s_memrealtime (100 MHz) at start / end
 #if PNR_MLP_STAMPS
-#define MLP_STAMP(i) do { if (P.stamps && lane == 0) { unsigned long long* sp_ = P.stamps + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + w) * kMlpStampSlots; \
+#define MLP_STAMP(i) do { if (P.stamps && lane == 0) { unsigned long long* sp_ = P.stamps + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kFwdWaves + w) * kMlpStampSlots; \
     sp_[(i)] = __builtin_amdgcn_s_memtime(); if ((i) == 0) sp_[24] = __builtin_amdgcn_s_memrealtime(); if ((i) == 22) sp_[25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define MLP_STAMP(i) do { } while (0)
@@ -313,8 +313,10 @@ struct MlpBias {
 // tile before the loss.  Read by the loss wave with per-sample loads behind the idx gather it was a dependent HBM round trip in
 // the middle of the tile's chain (7.7 us of the launch in the timing-only ablation, profiles/r03_b_mlp_fused_ablation.json).
 constexpr int kRecLdsFloats = 3 * kMlpBM * kMlpAct + 2 * kMlpBM;          // 1 280
+template <int NT>
 struct MlpRecordTile {
-    f32x4 v[2];
+    static constexpr int kN = (320 + NT - 1) / NT;
+    f32x4 v[kN];
     __device__ __forceinline__ static const float* piece(const float* const (&src)[5], int net, int j, long long row0, long long B, bool& ok)
     {
         // piece j of the tile: policy 0..95 actions, 96..191 mean, 192..287 log_std, 288..303 adv, 304..319 logp; value 0..15 vtarg, 16..31 values
@@ -330,8 +332,8 @@ struct MlpRecordTile {
     {
         const int n = net == 0 ? 320 : 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = tid + kMlpThreads * i;
+        for (int i = 0; i < kN; ++i) {
+            const int j = tid + NT * i;
             v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             bool ok = false;
             if (j < n) {
@@ -351,8 +353,8 @@ struct MlpRecordTile {
     {
         const int n = net == 0 ? 320 : 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int j = tid + kMlpThreads * i;
+        for (int i = 0; i < kN; ++i) {
+            const int j = tid + NT * i;
             if (j < n) *reinterpret_cast<f32x4*>(lds + (net == 0 ? 4 * j : 3 * kMlpBM * kMlpAct + 4 * j)) = v[i];
         }
     }
@@ -426,8 +428,74 @@ struct MlpFwdParams {
 // pass — the activations are written once (for the weight-gradient kernel) and never read back, except H1, which
 // returns from L2 while dZ2 is being multiplied.  One 256-column LDS tile serves H1, H2, dZ2 (in place over H2), H1
 // again and dZ1 (in place), the dead input tile holds the head rows and their gradients: 53 KB as in the plain forward.
+// ---- the forward / fused kernel's own geometry: EIGHT waves per 64-sample tile, each owning one 32-row block of every layer's
+// output (r02 - r03b ran four waves with two row blocks each).  What decides the launch time is the length of a tile's dependent
+// chain — a tile took 44 500 cycles even alone on its CU (profiles/r03_c_mlp_stamps_one_workgroup_per_cu.json: 5 600 of them
+// MFMA) — and per wave that chain is products + epilogues + tile stores + reload, all proportional to the rows a wave owns.
+constexpr int kFwdWaves = 8;
+constexpr int kFwdThreads = 64 * kFwdWaves;
+static_assert((kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats + 4 * 8) * 4 <= kMlpBM * kXS * 2, "head rows, head gradients, record and loss sums fit the dead input tile");
+static_assert(kFwdWaves * 32 == kMlpHid, "one 32-row block of the 256 hidden units per wave");
+
+// the one-row-block product: acc[cb] += W[32 rows of this wave][K] . tile[BM samples][K]^T (see MlpGemm for the two steps)
+template <int K, int STRIDE>
+struct MlpGemm1 {
+    static constexpr int KS = K / 16;
+    static constexpr int D = PNR_MLP_RING;
+    bf16x8 a[D];
+    const __bf16* wa;
+    // w_block: this wave's row block in the fragment-native packing: k-step ks at ks * 512
+    __device__ __forceinline__ void prefetch(const __bf16* __restrict__ w_block, int lane)
+    {
+        wa = w_block + lane * 8;
+#pragma unroll
+        for (int p = 0; p < D - 1; ++p)
+            if (p < KS) a[p] = ld_global_bf16x8(wa + 512 * p);
+    }
+    template <class F>
+    __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[kMlpCB], int lane, F&& after_loads)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const __bf16* tb = tile + r * STRIDE + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + D - 1 < KS) a[(ks + D - 1) % D] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
+            if (ks == (KS > D ? KS - D : 0)) {
+                __builtin_amdgcn_sched_barrier(0);
+                after_loads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // (reading the sample fragments one k-step ahead of their MFMAs — 16 more registers — changed nothing in the fused
+            // kernel and cost the sampler's forward 9 us of 14: r03, dropped)
+            bf16x8 b[kMlpCB];
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb)
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], b[cb], acc[cb], 0, 0, 0);
+        }
+    }
+};
+
+// a [BM][256] bf16 tile between LDS (row stride kHS) and row-major global rows, by NT threads
+template <int NT>
+__device__ __forceinline__ void mlp_store_htile_nt(const __bf16* tile, __bf16* __restrict__ dst, long long row0, long long n_rows, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < kMlpBM * 32 / NT; ++i) {
+        const int ch = tid + NT * i, row = ch >> 5, cc = ch & 31;
+        if (row0 + row < n_rows)
+            *reinterpret_cast<uint4*>(dst + (row0 + row) * kMlpHid + cc * 8) = *reinterpret_cast<const uint4*>(tile + row * kHS + cc * 8);
+    }
+}
+
+// Forward pass of one 64-sample tile through one net: grid (ceil(B / 64), nets), 512 threads.
+// FUSED: followed, in the same workgroup, by the tile's loss (one wave, a thread per sample) and its backward-data
+// pass — the activations are written once (for the weight-gradient kernel) and never read back; H1 also stays in the
+// registers of the lanes that made it, for the dZ1 epilogue.  One 256-column LDS tile serves H1, H2, dZ2 (in place over H2)
+// and dZ1, the dead input tile holds the head rows, their gradients and the tile's record: 53 KB.
 template <bool FUSED>
-__global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel(const MlpFwdParams P)
+__global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[kMlpBM * kXS + kMlpBM * kHS];
     __bf16* xt = lds;
@@ -437,13 +505,29 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     const long long row0 = (long long)blockIdx.x * kMlpBM;
     const __bf16* wp = P.wpack + (size_t)net * kPackElems;
     const float* bias = P.bias + net * kBiasElems;
-    // layer 1's bias and first weight fragments do not depend on the tile: requested before anything else, the bias first
+    const int c = lane & 31, h = lane >> 5;
+    // a wave's four 16-byte bias pieces (rows 32 w + 8 k + 4 h ..): requested in FRONT of the product's weight-fragment prefetch,
+    // so that they are the older operations (vector-memory results return in order: asked for behind the fragments, as the
+    // accumulators' initial values, each bias load made the compiler wait for vmcnt(0), draining the prefetch ring inside the product)
+    const auto bias_load = [&](const float* b, f32x4 (&q)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(b + 32 * w + 8 * k + 4 * h);
+    };
+    const auto bias_init = [&](f32x16 (&acc)[kMlpCB], const f32x4 (&q)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[cb][4 * k + j] = q[k][j];
+    };
+    // layer 1's bias and first weight fragments do not depend on the tile: requested before anything else
     MLP_STAMP(0);
-    MlpBias bias1;
-    bias1.load(bias, w, lane >> 5);
+    f32x4 bq1[4];
+    bias_load(bias, bq1);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm<kMlpInPad, kXS> g1;
-    g1.prefetch(wp + kOffW1 + 2 * w * (kMlpInPad / 16) * 512, lane);
+    MlpGemm1<kMlpInPad, kXS> g1;
+    g1.prefetch(wp + kOffW1 + w * (kMlpInPad / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FUSED) {       // this launch is one optimiser update: counted here, read by the Adam kernel two launches on
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
@@ -453,72 +537,78 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     {
         float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
         if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy,
-            // every load of the thread in flight before the first LDS write (as a load -> write loop it was five dependent
-            // HBM round trips per tile: 7 600 of a tile's 52 000 cycles in the phase stamps, profiles/r03_b_mlp_stamps.json)
-            constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kMlpThreads - 1) / kMlpThreads;
+            // every load of the thread in flight before the first LDS write
+            constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFwdThreads - 1) / kFwdThreads;
             uint4 v[kIt];
 #pragma unroll
             for (int i = 0; i < kIt; ++i) {
-                const int ch = tid + kMlpThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
                 v[i] = make_uint4(0u, 0u, 0u, 0u);
                 if (ch < kCh && row0 + row < P.B) v[i] = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
             }
 #pragma unroll
             for (int i = 0; i < kIt; ++i) {
-                const int ch = tid + kMlpThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
                 if (ch < kCh) *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = v[i];
             }
         } else {
         if (P.f_loc) {
-            for (int i = tid; i < 4 * kMlpInPad; i += kMlpThreads) {
+            for (int i = tid; i < 4 * kMlpInPad; i += kFwdThreads) {
                 const int which = i / kMlpInPad, k = i % kMlpInPad;
                 const float* src = which == 0 ? P.f_loc : (which == 1 ? P.f_inv : (which == 2 ? P.f_lo : P.f_hi));
                 fv[i] = k < kMlpIn ? src[k] : 0.f;
             }
         }
         mlp_barrier();
-        // two threads per row, 72 columns each: every load of the thread (18 unaligned 16-byte loads; a row starts on a
-        // 4-byte boundary only) is issued before the first use.  Written as a loop over (row, column pair) with one
-        // dependent idx -> row load per iteration this stage was a chain of ~36 memory round trips per thread:
-        // 35.8 us of a 16 384-sample launch (rocprof r02_b) against ~3 us of MFMA time.
+        // eight threads per row, 18 columns each: every load of the thread (a row starts on a 4-byte boundary only) is issued
+        // before the first use.  Written as a loop over (row, column pair) with one dependent idx -> row load per iteration this
+        // stage was a chain of ~36 memory round trips per thread: 35.8 us of a 16 384-sample launch (rocprof r02_b).
         {
-            constexpr int TPR = kMlpThreads / kMlpBM;             // threads per row: 2 (72 columns each) or 4 (36)
-            constexpr int CPT = kMlpInPad / TPR, NV = CPT / 4;    // columns and 16-byte loads per thread
+            constexpr int TPR = kFwdThreads / kMlpBM;             // threads per row: 8
+            constexpr int CPT = kMlpInPad / TPR;                  // 18 columns: four 16-byte loads + one 8-byte load
+            static_assert(CPT == 18, "stage 0 is written for 18 columns per thread");
             const int row = tid / TPR, part = tid % TPR;
             const long long b = row0 + row;
             const bool live = b < P.B;
             const float* src = P.obs + (live ? (P.idx ? P.idx[b] : b) : 0) * kMlpIn + CPT * part;
             typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            f32x4 v[NV];
+            typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+            float x[20];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int col = CPT * part + 4 * j;
-                v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (live && !(PNR_MLP_DIAG & 2)) {
-                    if (col + 3 < kMlpIn) v[j] = *reinterpret_cast<const f32x4u*>(src + 4 * j);         // cols .. 135
-                    else if (col < kMlpIn) v[j][0] = src[4 * j];                                       // col 136 alone
+            for (int j = 0; j < 20; ++j) x[j] = 0.f;
+            if (live && !(PNR_MLP_DIAG & 2)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = CPT * part + 4 * j;
+                    if (col + 3 < kMlpIn) { const f32x4 v = *reinterpret_cast<const f32x4u*>(src + 4 * j); x[4 * j] = v[0]; x[4 * j + 1] = v[1]; x[4 * j + 2] = v[2]; x[4 * j + 3] = v[3]; }
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (col + k < kMlpIn) x[4 * j + k] = src[4 * j + k];
+                    }
                 }
+                const int col = CPT * part + 16;
+                if (col + 1 < kMlpIn) { const f32x2u v = *reinterpret_cast<const f32x2u*>(src + 16); x[16] = v[0]; x[17] = v[1]; }
+                else if (col < kMlpIn) x[16] = src[16];
             }
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int col = CPT * part + 4 * j;
-                f32x4 x = v[j];
-                if (P.f_loc) {
-                    const f32x4 loc = *reinterpret_cast<const f32x4*>(fv + col), inv = *reinterpret_cast<const f32x4*>(fv + kMlpInPad + col);
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(fv + 2 * kMlpInPad + col), hi = *reinterpret_cast<const f32x4*>(fv + 3 * kMlpInPad + col);
+            for (int j = 0; j < CPT; ++j) {
+                const int col = CPT * part + j;
+                float y = x[j];
+                if (P.f_loc) y = fminf(fmaxf((y - fv[col]) * fv[kMlpInPad + col], fv[2 * kMlpInPad + col]), fv[3 * kMlpInPad + col]);
+                x[j] = (live && col < kMlpIn) ? y : 0.f;
+            }
+            // 18 bf16 = 36 bytes per thread, 4-byte aligned in the tile: nine dword stores
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) x[k] = fminf(fmaxf((x[k] - loc[k]) * inv[k], lo[k]), hi[k]);
-                }
-                bf16x4 pk;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) pk[k] = (__bf16)((live && col + k < kMlpIn) ? x[k] : 0.f);
-                *reinterpret_cast<bf16x4*>(xt + row * kXS + col) = pk;
+            for (int j = 0; j < CPT; j += 2) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 pk = {(__bf16)x[j], (__bf16)x[j + 1]};
+                *reinterpret_cast<bf16x2*>(xt + row * kXS + CPT * part + j) = pk;
             }
         }
         }
         mlp_barrier();
         if (P.xs && net == 0) {                                   // the input is the same for both nets: saved once
-            for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kMlpThreads) {
+            for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kFwdThreads) {
                 const int row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
                 if (row0 + row < P.B)
                     *reinterpret_cast<uint4*>(P.xs + (row0 + row) * kMlpInPad + cc * 8) = *reinterpret_cast<const uint4*>(xt + row * kXS + cc * 8);
@@ -527,47 +617,47 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     }
 
     MLP_STAMP(1);                         // stage 0 done (tile in LDS, barrier passed)
-    const int c = lane & 31, h = lane >> 5;
-    f32x16 acc[2][kMlpCB];
+    f32x16 acc[kMlpCB];
     // tanh in registers (the bias is what the accumulators started from), each register quad = four consecutive features
     // of one sample -> one ds_write_b64
-    const auto epilogue = [&]() {
+    // FUSED: layer 1's activations additionally STAY in this lane's registers (32 bf16 = 16 registers: exactly the values the
+    // dZ1 epilogue multiplies its own accumulators with), instead of coming back from L2 behind a vmcnt(0), two barriers and an
+    // LDS round trip (3 500 of a tile's 44 000 cycles in the phase stamps)
+    bf16x4 h1keep[FUSED ? kMlpCB * 4 : 1];
+    const auto epilogue = [&](bool keep) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 pk;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bf16x4 pk;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)((PNR_MLP_DIAG & 1) ? acc[rb][cb][4 * q + j] : tanh_fast(acc[rb][cb][4 * q + j]));
-                    *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h) = pk;
-                }
+                for (int j = 0; j < 4; ++j) pk[j] = (__bf16)((PNR_MLP_DIAG & 1) ? acc[cb][4 * q + j] : tanh_fast(acc[cb][4 * q + j]));
+                *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk;
+                if constexpr (FUSED) { if (keep) h1keep[4 * cb + q] = pk; }
+            }
     };
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
-    bias1.init(acc);
+    bias_init(acc, bq1);
     if (!(PNR_MLP_DIAG & 8)) g1.run(xt, acc, lane, [] {});
     MLP_STAMP(2);                         // layer-1 product issued
-    if (!(PNR_MLP_DIAG & 32)) epilogue();
+    if (!(PNR_MLP_DIAG & 32)) epilogue(true);
     MLP_STAMP(3);                         // layer-1 epilogue
-    // layer 2's first weight fragments are requested BEFORE the tile store: a wave's vector-memory operations return in
-    // order, so behind the 32 KB store they would wait for its acknowledgement from HBM
-    MlpBias bias2;
-    bias2.load(bias + kMlpHid, w, h);
+    // layer 2's bias and first weight fragments are requested ahead of the barrier (and of the tile store behind it)
+    f32x4 bq2[4];
+    bias_load(bias + kMlpHid, bq2);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm<kMlpHid, kHS> g2;
-    g2.prefetch(wp + kOffW2 + 2 * w * (kMlpHid / 16) * 512, lane);
+    MlpGemm1<kMlpHid, kHS> g2;
+    g2.prefetch(wp + kOffW2 + w * (kMlpHid / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
     mlp_barrier();
     MLP_STAMP(4);                         // barrier after the layer-1 epilogue
     MLP_STAMP(5);
 
     // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it.  The H1 tile leaves for
-    // HBM from INSIDE the product, behind its last weight-fragment load (timing-only ablation r03: the four tile stores cost
-    // 15 of the kernel's 50 us while every product's fragment loads queued behind one of them)
-    bias2.init(acc);
-    MlpRecordTile rect;
+    // HBM from INSIDE the product, behind its last weight-fragment load, and the tile's record is requested there too
+    bias_init(acc, bq2);
+    MlpRecordTile<kFwdThreads> rect;
     const bool rec_early = FUSED && !P.idx && !(PNR_MLP_DIAG & 256);
     if (!(PNR_MLP_DIAG & 4)) g2.run(ht, acc, lane, [&] {
         if constexpr (FUSED) {
@@ -577,7 +667,7 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
                 rect.load(src, net, row0, P.B, tid);
             }
         }
-        if (P.h1 && !(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        if (P.h1 && !(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
     });
     if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
         if (rec_early) rect.park(reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
@@ -585,237 +675,243 @@ __global__ __launch_bounds__(kMlpThreads, FUSED ? 3 : 1) void mlp_forward_kernel
     MLP_STAMP(6);                         // layer-2 product issued
     mlp_barrier();
     MLP_STAMP(7);
-    if (!(PNR_MLP_DIAG & 32)) epilogue();
+    if (!(PNR_MLP_DIAG & 32)) epilogue(false);
     MLP_STAMP(8);                         // layer-2 epilogue
     mlp_barrier();
     MLP_STAMP(9);
-    if (P.h2 && !(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
-    MLP_STAMP(10);                        // H2 store issued
+    MLP_STAMP(10);
 
-    // ---- layer 3: head^T [16][samples] = W3 . H2^T + b3 with 16x16x32 MFMAs; wave w owns BM / 4 samples
-    if (!(PNR_MLP_DIAG & 16)) {
+    // ---- layer 3: head^T [16][samples] = W3 . H2^T + b3 with 16x16x32 MFMAs; waves 0-3 own 16 samples each (waves 4-7 go on to
+    // the H2 store)
+    if (!(PNR_MLP_DIAG & 16) && w < 4) {
         const int r16 = lane & 15, g = lane >> 4;
-        constexpr int SB = kMlpBM / 64;                               // 16-sample blocks per wave
-        f32x4 a3[SB];
-        const f32x4 b3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);    // rows 4g .. 4g+3: the accumulators' start
-#pragma unroll
-        for (int sb = 0; sb < SB; ++sb) a3[sb] = b3;
+        f32x4 a3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);    // rows 4g .. 4g+3: the accumulators' start
         const __bf16* w3 = wp + kOffW3 + lane * 8;                    // fragment-native: block ks at ks * 512
+        bf16x8 w3f[kMlpHid / 32];
+#pragma unroll
+        for (int ks = 0; ks < kMlpHid / 32; ++ks) w3f[ks] = ld_global_bf16x8(w3 + 512 * ks);
 #pragma unroll
         for (int ks = 0; ks < kMlpHid / 32; ++ks) {
-            const bf16x8 a = ld_global_bf16x8(w3 + 512 * ks);
-#pragma unroll
-            for (int sb = 0; sb < SB; ++sb) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (16 * SB * w + 16 * sb + r16) * kHS + 32 * ks + 8 * g);
-                a3[sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, a3[sb], 0, 0, 0);
-            }
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (16 * w + r16) * kHS + 32 * ks + 8 * g);
+            a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks], b, a3, 0, 0, 0);
         }
-#pragma unroll
-        for (int sb = 0; sb < SB; ++sb) {
-            const long long b = row0 + 16 * SB * w + 16 * sb + r16; // column = sample, rows 4g .. 4g+3 = head entries
-            const f32x4 h = a3[sb];
-            if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = h;
+        {
+            const long long b = row0 + 16 * w + r16;                  // column = sample, rows 4g .. 4g+3 = head entries
+            const f32x4 hq = a3;
+            if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = hq;
             if constexpr (FUSED) {                                    // head rows of the tile, float32 [64][16], in the dead input tile
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(xt) + (16 * SB * w + 16 * sb + r16) * kMlpHead + 4 * g) = h;
-                continue;
-            }
-            if (!P.noise) continue;
-            if (net == 1) {
-                if (b < P.B && g == 0) P.values[b] = h[0];
-                continue;
-            }
-            // policy rows: g = 0 holds means 0..3, g = 1 means 4, 5 and raw log-stds 0, 1, g = 2 raw log-stds 2..5.
-            // Six cross-lane reads put each mean next to its log-std (executed by all lanes: no divergence around them).
-            const auto ls = [](float x) { return fminf(fmaxf(x, -20.f), 2.f); };
-            const float l0 = ls(__shfl(h[2], r16 + 16)), l1 = ls(__shfl(h[3], r16 + 16));
-            const float l2 = ls(__shfl(h[0], r16 + 32)), l3 = ls(__shfl(h[1], r16 + 32));
-            const float l4 = ls(__shfl(h[2], r16 + 32)), l5 = ls(__shfl(h[3], r16 + 32));
-            if (b >= P.B || g > 2) continue;
-            const size_t o = (size_t)b * kMlpAct;
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const auto st2 = [](float* dst, float x, float y) { *reinterpret_cast<f32x2*>(dst) = (f32x2){x, y}; };
-            const auto draw = [&](int j, float m, float l, float& a, float& e) {
-                a = fmaf(expf(l), P.noise[o + j], m);
-                e = P.a_max ? fminf(fmaxf(a, -P.a_max[j]), P.a_max[j]) : a;
-            };
-            if (g == 0) {
-                float a[4], e[4];
-                draw(0, h[0], l0, a[0], e[0]); draw(1, h[1], l1, a[1], e[1]);
-                draw(2, h[2], l2, a[2], e[2]); draw(3, h[3], l3, a[3], e[3]);
-                st2(P.mean + o, h[0], h[1]); st2(P.mean + o + 2, h[2], h[3]);
-                st2(P.actions + o, a[0], a[1]); st2(P.actions + o + 2, a[2], a[3]);
-                if (P.env_actions != P.actions) { st2(P.env_actions + o, e[0], e[1]); st2(P.env_actions + o + 2, e[2], e[3]); }
-            } else if (g == 1) {
-                float a[2], e[2];
-                draw(4, h[0], l4, a[0], e[0]); draw(5, h[1], l5, a[1], e[1]);
-                st2(P.mean + o + 4, h[0], h[1]);
-                st2(P.actions + o + 4, a[0], a[1]);
-                if (P.env_actions != P.actions) st2(P.env_actions + o + 4, e[0], e[1]);
-                st2(P.log_std + o, ls(h[2]), ls(h[3]));
-            } else {
-                st2(P.log_std + o + 2, ls(h[0]), ls(h[1])); st2(P.log_std + o + 4, ls(h[2]), ls(h[3]));
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(xt) + (16 * w + r16) * kMlpHead + 4 * g) = hq;
+            } else if (P.noise) {
+                if (net == 1) {
+                    if (b < P.B && g == 0) P.values[b] = hq[0];
+                } else {
+                    // policy rows: g = 0 holds means 0..3, g = 1 means 4, 5 and raw log-stds 0, 1, g = 2 raw log-stds 2..5.
+                    // Six cross-lane reads put each mean next to its log-std (executed by all lanes: no divergence around them).
+                    const auto ls = [](float x) { return fminf(fmaxf(x, -20.f), 2.f); };
+                    const float l0 = ls(__shfl(hq[2], r16 + 16)), l1 = ls(__shfl(hq[3], r16 + 16));
+                    const float l2 = ls(__shfl(hq[0], r16 + 32)), l3 = ls(__shfl(hq[1], r16 + 32));
+                    const float l4 = ls(__shfl(hq[2], r16 + 32)), l5 = ls(__shfl(hq[3], r16 + 32));
+                    if (b < P.B && g <= 2) {
+                        const size_t o = (size_t)b * kMlpAct;
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const auto st2 = [](float* dst, float x, float y) { *reinterpret_cast<f32x2*>(dst) = (f32x2){x, y}; };
+                        const auto draw = [&](int j, float m, float l, float& a, float& e) {
+                            a = fmaf(expf(l), P.noise[o + j], m);
+                            e = P.a_max ? fminf(fmaxf(a, -P.a_max[j]), P.a_max[j]) : a;
+                        };
+                        if (g == 0) {
+                            float a[4], e[4];
+                            draw(0, hq[0], l0, a[0], e[0]); draw(1, hq[1], l1, a[1], e[1]);
+                            draw(2, hq[2], l2, a[2], e[2]); draw(3, hq[3], l3, a[3], e[3]);
+                            st2(P.mean + o, hq[0], hq[1]); st2(P.mean + o + 2, hq[2], hq[3]);
+                            st2(P.actions + o, a[0], a[1]); st2(P.actions + o + 2, a[2], a[3]);
+                            if (P.env_actions != P.actions) { st2(P.env_actions + o, e[0], e[1]); st2(P.env_actions + o + 2, e[2], e[3]); }
+                        } else if (g == 1) {
+                            float a[2], e[2];
+                            draw(4, hq[0], l4, a[0], e[0]); draw(5, hq[1], l5, a[1], e[1]);
+                            st2(P.mean + o + 4, hq[0], hq[1]);
+                            st2(P.actions + o + 4, a[0], a[1]);
+                            if (P.env_actions != P.actions) st2(P.env_actions + o + 4, e[0], e[1]);
+                            st2(P.log_std + o, ls(hq[2]), ls(hq[3]));
+                        } else {
+                            st2(P.log_std + o + 2, ls(hq[0]), ls(hq[1])); st2(P.log_std + o + 4, ls(hq[2]), ls(hq[3]));
+                        }
+                    }
+                }
             }
         }
     }
-
     MLP_STAMP(11);                        // head product + its stores
+
+    if constexpr (!FUSED) {
+        if (P.h2 && !(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+    }
     if constexpr (FUSED) {
         float* hd = reinterpret_cast<float*>(xt);                         // [64][16] float32 head rows (written above)
         __bf16* gt = xt + kMlpBM * kMlpHead * 2;                          // [64][kGS] bf16 head gradients, behind them
-        // W3^T's two fragments for the first backward product: requested before the loss (waves 1-3 wait there anyway)
-        bf16x8 w3t[2];
-        {
-            const __bf16* wa = wp + kOffW3T + 2 * w * 512 + lane * 8;
-            w3t[0] = ld_global_bf16x8(wa); w3t[1] = ld_global_bf16x8(wa + 512);
-        }
+        const float* rl = reinterpret_cast<const float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2;   // the parked record
+        float* wsum = reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats; // [8 waves][4] loss sums
+        // W3^T's fragment for the first backward product: requested before the H2 store and the loss
+        const bf16x8 w3t = ld_global_bf16x8(wp + kOffW3T + w * 512 + lane * 8);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
         mlp_barrier();
         MLP_STAMP(12);                    // barrier before the loss
-        // ---- the tile's loss: wave 0, thread = sample (pnr_ppo.h: the per-sample halves ppo_loss_kernel is made of)
-        if (w == 0) {
-            const long long b = row0 + lane;
+        // ---- the tile's loss on all 512 threads: eight lanes per sample, lane d < 6 = action dimension d of the policy head
+        // (ppo_policy_sample's arithmetic, its sums over the dimensions as three xor-shuffles inside the group), lane 0 the
+        // value head (ppo_value_sample).  As one thread per sample on wave 0 the other seven waves waited 4 300 cycles of a
+        // tile's 38 000 for it (profiles/r03_d_mlp_stamps.json).
+        {
+            const int sl = tid >> 3, d = tid & 7;                     // sample of the tile, lane of its group
+            const long long b = row0 + sl;
             const bool live = b < P.B && !(PNR_MLP_DIAG & 256);
             const float invB = 1.0f / (float)P.B;
-            // the sample's rollout record (behind the idx gather), loaded here rather than prefetched: 22 registers live
-            // across the three products cost the third workgroup per CU, which hides this round trip anyway
-            float rec_a[6], rec_m0[6], rec_l0[6], rec_adv = 0.f, rec_lp0 = 0.f, rec_vt = 0.f, rec_v0 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) { rec_a[j] = 0.f; rec_m0[j] = 0.f; rec_l0[j] = 0.f; }
-            if (live && rec_early) {
-                const float* rl = reinterpret_cast<const float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2;
-                if (net == 0) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) { rec_a[j] = rl[lane * 6 + j]; rec_m0[j] = rl[384 + lane * 6 + j]; rec_l0[j] = rl[768 + lane * 6 + j]; }
-                    rec_adv = rl[1152 + lane]; rec_lp0 = rl[1216 + lane];
-                } else {
-                    rec_vt = rl[1152 + lane]; rec_v0 = rl[1216 + lane];
+            const long long r = (!rec_early && live && P.idx) ? P.idx[b] : b;
+            float g0 = 0.f, g1 = 0.f;                                 // head-gradient entries d and 6 + d (lanes 6, 7: padding 12 + ..)
+            float s_surr = 0.f, s_vf = 0.f, s_kl = 0.f, s_ent = 0.f;  // the sample's loss terms (meaningful on lane 0 of the group)
+            if (net == 0) {
+                const bool dim = d < kMlpAct;
+                float m = 0.f, raw = 0.f, a = 0.f, m0 = 0.f, l0 = 0.f, adv = 0.f, lp0 = 0.f;
+                if (live) {
+                    if (dim) { m = hd[sl * kMlpHead + d]; raw = hd[sl * kMlpHead + kMlpAct + d]; }
+                    if (rec_early) {
+                        if (dim) { a = rl[sl * 6 + d]; m0 = rl[384 + sl * 6 + d]; l0 = rl[768 + sl * 6 + d]; }
+                        adv = rl[1152 + sl]; lp0 = rl[1216 + sl];
+                    } else {
+                        if (dim) { a = P.rec_actions[r * 6 + d]; m0 = P.rec_mean[r * 6 + d]; l0 = P.rec_log_std[r * 6 + d]; }
+                        adv = P.rec_adv[r]; lp0 = P.rec_logp[r];
+                    }
                 }
-            } else if (live) {
-                const long long r = P.idx ? P.idx[b] : b;
-                if (net == 0) {
+                const bool pass = raw >= -20.0f && raw <= 2.0f;           // torch.clamp passes the gradient on [min, max]
+                const float ls = fminf(fmaxf(raw, -20.0f), 2.0f);
+                const float si = expf(-ls);
+                const float z = (a - m) * si;
+                const float ivar = si * si;
+                const float dm = m0 - m;
+                const float q = (expf(2.0f * l0) + dm * dm) * ivar;        // (var0 + (m0 - m)^2) / var
+                float lp = dim ? (-0.5f * z * z - ls) : 0.f;
+                float kl = dim ? (ls - l0 + 0.5f * q - 0.5f) : 0.f;
+                float en = dim ? ls : 0.f;
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) { rec_a[j] = P.rec_actions[r * 6 + j]; rec_m0[j] = P.rec_mean[r * 6 + j]; rec_l0[j] = P.rec_log_std[r * 6 + j]; }
-                    rec_adv = P.rec_adv[r]; rec_lp0 = P.rec_logp[r];
-                } else {
-                    rec_vt = P.rec_vtarg[r]; rec_v0 = P.rec_values[r];
+                for (int o = 1; o < 8; o <<= 1) { lp += __shfl_xor(lp, o, 64); kl += __shfl_xor(kl, o, 64); en += __shfl_xor(en, o, 64); }
+                const float logp = lp - 0.5f * 6.0f * 1.8378770664093453f;  // -3 log(2 pi)
+                const float ent = en + 6.0f * 1.4189385332046727f;          // 6 * 0.5 log(2 pi e)
+                const float ratio = expf(logp - lp0);
+                const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+                const float s1 = adv * ratio, s2 = adv * rc;
+                const float surr = fminf(s1, s2);
+                const bool inrange = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
+                // torch.minimum: the smaller argument takes the gradient, a tie splits it; the clipped branch is constant outside the range
+                float dsurr;
+                if (s1 < s2) dsurr = s1;
+                else if (s1 == s2) dsurr = 0.5f * s1 + (inrange ? 0.5f * s1 : 0.f);
+                else dsurr = inrange ? s1 : 0.f;
+                const float klc = *P.kl_coeff, entc = *P.ent_coeff;
+                if (live && dim) {
+                    g0 = (-dsurr * z * si + klc * (-dm * ivar)) * invB;
+                    g1 = pass ? (-dsurr * (z * z - 1.0f) + klc * (1.0f - q) - entc) * invB : 0.f;
                 }
+                if (live) { s_surr = -surr; s_kl = kl; s_ent = ent; }
+            } else if (d == 0 && live) {
+                const float vt = rec_early ? rl[1152 + sl] : P.rec_vtarg[r], v0 = rec_early ? rl[1216 + sl] : P.rec_values[r];
+                float dvf;
+                ppo_value_sample(hd[sl * kMlpHead], vt, v0, P.vf_clip, s_vf, dvf);
+                g0 = P.vf_coeff * dvf * invB;
             }
-            float g[kMlpHead];
-#pragma unroll
-            for (int j = 0; j < kMlpHead; ++j) g[j] = 0.f;
-            float sums[4] = {0.f, 0.f, 0.f, 0.f};                          // -surr, vf, kl, entropy
-            if (live) {
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(hd + lane * kMlpHead), q1 = *reinterpret_cast<const f32x4*>(hd + lane * kMlpHead + 4),
-                            q2 = *reinterpret_cast<const f32x4*>(hd + lane * kMlpHead + 8);
-                if (net == 0) {
-                    const float m[6] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1]};
-                    const float raw[6] = {q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
-                    float gm[6], gl[6];
-                    ppo_policy_sample(m, raw, rec_a, rec_m0, rec_l0, rec_adv, rec_lp0, P.clip, *P.kl_coeff, *P.ent_coeff, invB, gm, gl,
-                                      sums[0], sums[2], sums[3]);
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) { g[j] = gm[j]; g[6 + j] = gl[j]; }
-                } else {
-                    float dvf;
-                    ppo_value_sample(q0[0], rec_vt, rec_v0, P.vf_clip, sums[1], dvf);
-                    g[0] = P.vf_coeff * dvf * invB;
-                }
-                f32x4* gp = reinterpret_cast<f32x4*>(P.g_head + ((size_t)net * P.B + b) * kMlpHead);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) gp[q] = (f32x4){g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
+            // head gradients: entries d and 6 + d of the sample's row (lanes 6, 7: the zero padding 12 .. 15), float32 for the
+            // weight-gradient kernel, bf16 for this tile's backward products
+            const int e0 = d < kMlpAct ? d : 12 + 2 * (d - 6), e1 = d < kMlpAct ? kMlpAct + d : 13 + 2 * (d - 6);
+            if (b < P.B) {
+                float* gp = P.g_head + ((size_t)net * P.B + b) * kMlpHead;
+                gp[e0] = g0; gp[e1] = g1;
             }
-            bf16x8 p0, p1;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { p0[j] = (__bf16)g[j]; p1[j] = (__bf16)g[8 + j]; }
-            *reinterpret_cast<bf16x8*>(gt + lane * kGS) = p0;
-            *reinterpret_cast<bf16x8*>(gt + lane * kGS + 8) = p1;
+            gt[sl * kGS + e0] = (__bf16)g0;
+            gt[sl * kGS + e1] = (__bf16)g1;
+            // the tile's sums: lane 0 of every group, then across the wave's eight samples; the waves' partial sums meet in LDS
+            float sums[4] = {d == 0 ? s_surr : 0.f, d == 0 ? s_vf : 0.f, d == 0 ? s_kl : 0.f, d == 0 ? s_ent : 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float x = sums[k];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+                for (int off = 8; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
                 sums[k] = x;
             }
-            if (lane == 0) {
-                float* pr = P.partials + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * 8;
-                *reinterpret_cast<f32x4*>(pr) = (f32x4){sums[0], sums[1], sums[2], sums[3]};
-                *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+            if (lane == 0) *reinterpret_cast<f32x4*>(wsum + 4 * w) = (f32x4){sums[0], sums[1], sums[2], sums[3]};
         }
-        MLP_STAMP(13);                    // loss done (wave 0) / nothing (waves 1-3)
+        MLP_STAMP(13);                    // loss done
         mlp_barrier();
         MLP_STAMP(14);                    // barrier after the loss
+        if (tid == 0) {                   // the eight waves' sums in wave order: one row of partial sums per workgroup
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < kFwdWaves; ++k) t += *reinterpret_cast<const f32x4*>(wsum + 4 * k);
+            float* pr = P.partials + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * 8;
+            *reinterpret_cast<f32x4*>(pr) = t;
+            *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 
         // acc * (1 - h^2) with h read from the tile at this lane's own quads and the product written over it
         const auto bwd_epilogue = [&]() {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
-                for (int cb = 0; cb < kMlpCB; ++cb)
+                for (int q = 0; q < 4; ++q) {
+                    __bf16* at = ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h;
+                    const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at);
+                    bf16x4 pk;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        __bf16* at = ht + (32 * cb + c) * kHS + 64 * w + 32 * rb + 8 * q + 4 * h;
-                        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at);
-                        bf16x4 pk;
+                    for (int j = 0; j < 4; ++j) { const float hf = (float)hv[j]; pk[j] = (__bf16)(acc[cb][4 * q + j] * (1.0f - hf * hf)); }
+                    *reinterpret_cast<bf16x4*>(at) = pk;
+                }
+        };
+        const auto zero_acc = [&]() {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { const float hf = (float)hv[j]; pk[j] = (__bf16)(acc[rb][cb][4 * q + j] * (1.0f - hf * hf)); }
-                        *reinterpret_cast<bf16x4*>(at) = pk;
-                    }
+            for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
         };
         // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
-        mlp_zero_acc(acc);
+        zero_acc();
         {
             bf16x8 b[kMlpCB];
 #pragma unroll
             for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < kMlpCB; ++cb)
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[rb], b[cb], acc[rb][cb], 0, 0, 0);
+            for (int cb = 0; cb < kMlpCB; ++cb)
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t, b[cb], acc[cb], 0, 0, 0);
         }
         bwd_epilogue();
         MLP_STAMP(15);                    // dH2 product + its epilogue
-        MlpGemm<kMlpHid, kHS> g4;                 // W2^T's first fragments ahead of the dZ2 store
-        g4.prefetch(wp + kOffW2T + 2 * w * (kMlpHid / 16) * 512, lane);
+        MlpGemm1<kMlpHid, kHS> g4;                // W2^T's first fragments ahead of the barrier
+        g4.prefetch(wp + kOffW2T + w * (kMlpHid / 16) * 512, lane);
+        __builtin_amdgcn_sched_barrier(0);
         mlp_barrier();
         MLP_STAMP(16);                    // barrier after it
 
         // ---- dH1^T = W2^T . dZ2^T (the dZ2 tile leaves from inside the product), then H1 into the tile and dZ1 in place over it
-        mlp_zero_acc(acc);
+        zero_acc();
         g4.run(ht, acc, lane, [&] {
-            if (!(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+            if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
         });
         MLP_STAMP(17);                    // dZ2 store + W2^T product issued
-        // H1 comes back (this workgroup wrote it a moment ago: L2) as 16-byte row pieces; requested only now, so that the
-        // 32 registers are not live across the product (three workgroups per CU hide the round trip)
-        uint4 h1r[kMlpBM / 8];
-        {
-            // every thread reads back exactly the pieces it stored itself (mlp_store_htile's mapping); its stores are waited
-            // for explicitly, since no barrier in this kernel waits for global memory any more (the dZ2 store issued before
-            // the product above is the youngest one outstanding)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const __bf16* src = P.h1 + (size_t)net * P.B * kMlpHid;
-#pragma unroll
-            for (int i = 0; i < kMlpBM / 8; ++i) {
-                const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
-                h1r[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (row0 + row < P.B && !(PNR_MLP_DIAG & 128)) h1r[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * kMlpHid + cc * 8);
-            }
-        }
-        MLP_STAMP(18);                    // H1 reload requested (after vmcnt(0))
-        mlp_barrier();                         // every read of dZ2 (the product and the store above) is done
+        MLP_STAMP(18);
+        mlp_barrier();                         // every read of dZ2 (the product and the store inside it) is done: the tile is free
         MLP_STAMP(19);
+        MLP_STAMP(20);
+        // dZ1 = dH1 * (1 - H1^2) with H1 from this lane's own registers, written into the free tile for the coalesced store
 #pragma unroll
-        for (int i = 0; i < kMlpBM / 8; ++i) {
-            const int ch = tid + kMlpThreads * i, row = ch >> 5, cc = ch & 31;
-            *reinterpret_cast<uint4*>(ht + row * kHS + cc * 8) = h1r[i];
-        }
-        mlp_barrier();
-        MLP_STAMP(20);                    // H1 back in the tile
-        bwd_epilogue();
+        for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x4 hv = h1keep[4 * cb + q];
+                bf16x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float hf = (float)hv[j]; pk[j] = (__bf16)(acc[cb][4 * q + j] * (1.0f - hf * hf)); }
+                *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk;
+            }
         MLP_STAMP(21);
         mlp_barrier();
-        if (!(PNR_MLP_DIAG & 64)) mlp_store_htile(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
         MLP_STAMP(22);                    // end
     }
 }

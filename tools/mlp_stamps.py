@@ -38,7 +38,7 @@ rec = {"actions": act, "mean": mean, "log_std": ls, "logp": gaussian_logp(act, m
 xs = R(B, 144).bfloat16().contiguous()
 klc, entc, means = torch.tensor(0.2, device=dev), torch.tensor(0.01, device=dev), torch.zeros(8, device=dev)
 wgs = (B // 64) * 2
-stamps = torch.zeros((wgs, 4, 26), dtype=torch.int64, device=dev)
+stamps = torch.zeros((wgs, 8, 26), dtype=torch.int64, device=dev)
 raw.pnr_mlp_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
 for _ in range(10):
     mlp.train_step(None, None, None, rec, klc, entc, 0.3, 10.0, 1.0, means, 2e-5, xs_in=xs)
@@ -56,7 +56,7 @@ out = {"workgroups": wgs, "launch_span_us": float(span_us), "tile_cycles_median"
        "tile_start_us_percentiles_10_50_75_90_100": [float(np.percentile(start_us, q)) for q in (10, 50, 75, 90, 100)], "phases": []}
 print(f"launch span {span_us:.1f} us; a tile takes {out['tile_cycles_median']} cycles = {out['tile_us_median']:.1f} us (median) at "
       f"{out['in_kernel_clock_ghz_median']:.2f} GHz; tile start times (us) p10/50/75/90/100: {out['tile_start_us_percentiles_10_50_75_90_100']}")
-print(f"{'phase':44s} {'wave0 med':>9s} {'p10':>7s} {'p90':>7s} | {'w1-3 med':>9s} {'p10':>7s} {'p90':>7s}")
+print(f"{'phase':44s} {'wave0 med':>9s} {'p10':>7s} {'p90':>7s} | {'others med':>9s} {'p10':>7s} {'p90':>7s}")
 for i in range(22):
     a, b = d[:, 0, i], d[:, 1:, i].reshape(-1)
     row = {"phase": NAMES[i + 1], "wave0": [int(np.median(a)), int(np.percentile(a, 10)), int(np.percentile(a, 90))],
