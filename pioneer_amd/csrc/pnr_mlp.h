@@ -1165,16 +1165,19 @@ struct MlpWgradParams {
 // A 64-row chunk of COLS bf16 columns (a multiple of 8) on its way from row-major global memory (row stride src_stride)
 // into an LDS tile: loaded into registers first (every load of the chunk in flight together), written later — the
 // weight-gradient loop requests chunk c + 1 before it multiplies chunk c.
+// (eight waves per workgroup: two per SIMD — with the four of r02 every MFMA chain, LDS read and chunk hand-over of a workgroup
+// was exposed on a SIMD that had nothing else to run)
+constexpr int kWgThreads = 512;
 template <int COLS>
 struct WgChunk {
-    static constexpr int kPerThread = (kWgChunk * (COLS / 8) + kMlpThreads - 1) / kMlpThreads;
+    static constexpr int kPerThread = (kWgChunk * (COLS / 8) + kWgThreads - 1) / kWgThreads;
     uint4 v[kPerThread];
     __device__ __forceinline__ void load(const __bf16* __restrict__ src, long long src_stride, long long row0, long long n_rows, int tid)
     {
         constexpr int cpr = COLS / 8;
 #pragma unroll
         for (int i = 0; i < kPerThread; ++i) {
-            const int ch = tid + kMlpThreads * i, row = ch / cpr, cc = ch % cpr;
+            const int ch = tid + kWgThreads * i, row = ch / cpr, cc = ch % cpr;
             v[i] = make_uint4(0u, 0u, 0u, 0u);
             if (ch < kWgChunk * cpr && row0 + row < n_rows) v[i] = *reinterpret_cast<const uint4*>(src + (row0 + row) * src_stride + cc * 8);
         }
@@ -1184,7 +1187,7 @@ struct WgChunk {
         constexpr int cpr = COLS / 8;
 #pragma unroll
         for (int i = 0; i < kPerThread; ++i) {
-            const int ch = tid + kMlpThreads * i, row = ch / cpr, cc = ch % cpr;
+            const int ch = tid + kWgThreads * i, row = ch / cpr, cc = ch % cpr;
             if (ch < kWgChunk * cpr) *reinterpret_cast<uint4*>(tile + row * tstride + cc * 8) = v[i];
         }
     }
@@ -1228,7 +1231,7 @@ __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, in
     }
 }
 
-__global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradParams P)
+__global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradParams P)
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[kWgChunk * kTrH + kWgChunk * kTrH + kWgChunk * kTrG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1240,13 +1243,13 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
     const size_t nb = (size_t)net * P.B * kMlpHid;
 
     if (part < 2) {
-        // dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half]; waves 2 x 2, each 128 (o) x 64 (i)
+        // dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half]; waves 4 x 2, each 64 (o) x 64 (i)
         __bf16* ta = lds;                        // dZ2 chunk [64][256], stride kTrH
         __bf16* tb = lds + kWgChunk * kTrH;      // H1 chunk [64][128], stride kTrHalf
         const int wo = w >> 1, wi = w & 1;
-        f32x16 acc[4][2];
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -1264,34 +1267,32 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
             }
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-                bf16x8 fa[4], fb[2];
+                bf16x8 fa[2], fb[2];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) fa[a] = wg_frag32(ta, kTrH, 16 * ks, 128 * wo + 32 * a, lane);
+                for (int a = 0; a < 2; ++a) fa[a] = wg_frag32(ta, kTrH, 16 * ks, 64 * wo + 32 * a, lane);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) fb[b] = wg_frag32(tb, kTrHalf, 16 * ks, 64 * wi + 32 * b, lane);
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                wg_store_block(slab + kGW2, kMlpHid, 128 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
-    } else if (part == 2) {
-        // dW1 = dZ1^T . X (144 columns) and db1 = dZ1^T . 1 (the tile's column 144 is all ones); wave w: rows 64w..
-        __bf16* ta = lds;                        // dZ1 chunk [64][256]
-        __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
-        f32x16 acc[2][5];
-#pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 5; ++b)
+            for (int b = 0; b < 2; ++b)
+                wg_store_block(slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
+    } else if (part == 2) {
+        // dW1 = dZ1^T . X (144 columns) and db1 = dZ1^T . 1 (the tile's column 144 is all ones); wave w: rows 32w..
+        __bf16* ta = lds;                        // dZ1 chunk [64][256]
+        __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
+        f32x16 acc[5];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        for (int b = 0; b < 5; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
         WgChunk<kMlpHid> ca; WgChunk<kMlpInPad> cb;
         ca.load(P.dz1 + nb, kMlpHid, s_begin, s_end, tid);
         cb.load(P.xs, kMlpInPad, s_begin, s_end, tid);
@@ -1311,27 +1312,23 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
             }
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-                bf16x8 fa[2], fb[5];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) fa[a] = wg_frag32(ta, kTrH, 16 * ks, 64 * w + 32 * a, lane);
+                bf16x8 fb[5];
+                const bf16x8 fa = wg_frag32(ta, kTrH, 16 * ks, 32 * w, lane);
 #pragma unroll
                 for (int b = 0; b < 5; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * b, lane);
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 5; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 5; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
             }
         }
+        {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-            for (int b = 0; b < 5; ++b) wg_store_block(slab + kGW1, kMlpInPad, 64 * w + 32 * a, 32 * b, kMlpInPad, acc[a][b], lane);
+            for (int b = 0; b < 5; ++b) wg_store_block(slab + kGW1, kMlpInPad, 32 * w, 32 * b, kMlpInPad, acc[b], lane);
             // column 144 of the product = db1: lane c == 16 of block b == 4
             if ((lane & 31) == 16) {
                 const int hh = lane >> 5;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) slab[kGB1 + 64 * w + 32 * a + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[a][4][i];
+                for (int i = 0; i < 16; ++i) slab[kGB1 + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[4][i];
             }
         }
     } else {
@@ -1339,9 +1336,9 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
         __bf16* th = lds;                        // H2 chunk [64][256]
         __bf16* tz = lds + kWgChunk * kTrH;      // dZ2 chunk [64][256]
         __bf16* tg = lds + 2 * kWgChunk * kTrH;  // G chunk [64][16] as bf16
-        f32x4 aw3[4], ab2[4], ab3 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 aw3[2], ab2[2], ab3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { aw3[b] = ab3; ab2[b] = ab3; }
+        for (int b = 0; b < 2; ++b) { aw3[b] = ab3; ab2[b] = ab3; }
         bf16x8 ones;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -1373,20 +1370,20 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_wgrad_kernel(const MlpWgradPa
                 const bf16x8 fg = wg_frag16(tg, kTrG, 32 * ks, 0, lane);          // A: rows = head entries
                 if (w == 0) ab3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, ones, ab3, 0, 0, 0);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {                                      // wave w: feature columns 64w + 16b ..
-                    const bf16x8 fh = wg_frag16(th, kTrH, 32 * ks, 64 * w + 16 * b, lane);
+                for (int b = 0; b < 2; ++b) {                                      // wave w: feature columns 32w + 16b ..
+                    const bf16x8 fh = wg_frag16(th, kTrH, 32 * ks, 32 * w + 16 * b, lane);
                     aw3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, fh, aw3[b], 0, 0, 0);
-                    const bf16x8 fz = wg_frag16(tz, kTrH, 32 * ks, 64 * w + 16 * b, lane);
+                    const bf16x8 fz = wg_frag16(tz, kTrH, 32 * ks, 32 * w + 16 * b, lane);
                     ab2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fz, ab2[b], 0, 0, 0);
                 }
             }
         }
         const int c16 = lane & 15, g = lane >> 4;                  // C: col = lane & 15, rows 4g .. 4g+3
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < 2; ++b) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) slab[kGW3 + (4 * g + j) * kMlpHid + 64 * w + 16 * b + c16] = aw3[b][j];
-            if (g == 0) slab[kGB2 + 64 * w + 16 * b + c16] = ab2[b][0];            // every row of 1^T . dZ2 is db2
+            for (int j = 0; j < 4; ++j) slab[kGW3 + (4 * g + j) * kMlpHid + 32 * w + 16 * b + c16] = aw3[b][j];
+            if (g == 0) slab[kGB2 + 32 * w + 16 * b + c16] = ab2[b][0];            // every row of 1^T . dZ2 is db2
         }
         if (w == 0 && c16 == 0) {
 #pragma unroll
