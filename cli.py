@@ -3,10 +3,12 @@
 
 Keeps the reference CLI's surface (cli.py:12-40 there: sub-command ``pioneer-train-kinem`` with
 ``-e/--experiment``, ``-c/--checkpoint-freq``, ``-n/--num-samples``, ``-w/--num-workers``,
-``--no-monitor``; ``tracking.training_root`` and a ``logging`` dictConfig read from an optional
-``config.yaml`` next to this file) on top of ``pioneer_amd.launch.train``, plus ``pioneer-eval`` (the role of the
-reference's temp/pioneer_eval.py: restore a checkpoint, roll out, record).  For several GPUs run it
-under ``python -m torch.distributed.run --nproc-per-node N cli.py pioneer-train-kinem ...``.
+``--no-monitor``, and ``tensorboard -e EXPERIMENT``, cli.py:43-55; ``tracking.training_root`` and a ``logging`` dictConfig read
+from ``config.yaml`` next to this file, as the reference's config.yaml:1-24) on top of ``pioneer_amd.launch.train``, plus
+``pioneer-eval`` (the role of the reference's temp/pioneer_eval.py: restore a checkpoint, roll out, record) and the engine's own
+switches (``--restore CHECKPOINT``, ``--trial-parallel``, ``--mode``).  For several GPUs run it under
+``python -m torch.distributed.run --nproc-per-node N cli.py pioneer-train-kinem ...`` (``--trial-parallel``: one trial per GPU
+at a time, the reference's own parallelism; default: every trial data-parallel over the GPUs).
 """
 import argparse
 import logging
@@ -47,6 +49,12 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("--iterations", type=int, default=1000)
     tr.add_argument("--envs-per-worker", type=int, default=4096)
     tr.add_argument("--mode", choices=["kinematic", "dynamic"], default="kinematic")
+    tr.add_argument("--restore", default=None, metavar="CHECKPOINT", help="start every trial from this PPOTrainer.save() file")
+    tr.add_argument("--trial-parallel", action="store_true",
+                    help="several GPUs: rank r runs trials r, r + world, ... on its own (no traffic between the GPUs)")
+    tb = sub.add_parser("tensorboard", help="serve the experiment's event files with TensorBoard (reference cli.py:43-55)")
+    tb.add_argument("-e", "--experiment", required=True, help="experiment name")
+    tb.add_argument("--port", type=int, default=6006)
     ev = sub.add_parser("pioneer-eval", help="roll a saved policy out in the single-env facade, optionally record a GIF")
     ev.add_argument("-k", "--checkpoint", required=True, help="a checkpoint_*.pt written by pioneer-train-kinem")
     ev.add_argument("--episodes", type=int, default=3)
@@ -57,9 +65,32 @@ def build_parser() -> argparse.ArgumentParser:
     return ap
 
 
+def launch_tensorboard(tensorboard_root: str, port: int = 6006) -> int:
+    """pioneer/util.py:35-42 of the reference starts TensorBoard in-process and waits for Enter.  TensorBoard is a third-party
+    package that this image does not carry: when it is importable it is started as a CHILD process on the experiment's event
+    files (written by pioneer_amd/tb.py) until Enter / EOF; otherwise the command says where the files are and fails."""
+    import importlib.util
+    import subprocess
+    n_events = sum(f.startswith("events.out.tfevents.") for _, _, fs in os.walk(tensorboard_root) for f in fs)
+    if importlib.util.find_spec("tensorboard") is None:
+        print(f"tensorboard is not installed here; {n_events} event file(s) under {tensorboard_root} "
+              f"(serve them with: tensorboard --bind_all --port {port} --logdir {tensorboard_root})", file=sys.stderr)
+        return 3
+    proc = subprocess.Popen([sys.executable, "-m", "tensorboard.main", "--bind_all", "--port", str(port), "--logdir", tensorboard_root])
+    logging.getLogger(__name__).info("Launched TensorBoard on port %d for %s (%d event files)", port, tensorboard_root, n_events)
+    try:
+        input("\nPress Enter to exit (this will terminate TensorBoard)\n")
+    except EOFError:
+        pass
+    proc.terminate()
+    return 0
+
+
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
     settings = load_settings()
+    if args.command == "tensorboard":
+        return launch_tensorboard(os.path.join(settings["tracking"]["training_root"], args.experiment), args.port)
     if args.command == "pioneer-eval":
         import json
         from pioneer_amd.evaluate import evaluate
@@ -75,7 +106,8 @@ def main(argv=None) -> int:
     out_dir = os.path.join(settings["tracking"]["training_root"], args.experiment)
     rows = train(results_dir=out_dir, checkpoint_freq=args.checkpoint_freq, num_samples=args.num_samples,
                  num_workers=args.num_workers, monitor=not args.no_monitor,
-                 training_iterations=args.iterations, envs_per_worker=args.envs_per_worker, mode=args.mode)
+                 training_iterations=args.iterations, envs_per_worker=args.envs_per_worker, mode=args.mode,
+                 restore=args.restore, trial_parallel=args.trial_parallel)
     if int(os.environ.get("RANK", "0")) == 0:
         print("Results:\n\n" + dump(rows, RESULT_COLUMNS) + "\n")
     return 0

@@ -385,6 +385,13 @@ typedef struct pnr_mlp_step {
     const void* xs_in;      /* optional [batch][144] bf16: the nets' input already gathered, filtered and rounded by
                              * pnr_mlp_gather.  Then obs / idx / the filter vectors are not read, the record arrays (actions ..
                              * value_old) are read row by row, and `xs` is not written */
+    int32_t first_net, n_nets; /* the nets this call works on: 0, 0 (or 0, 2) = both; 0, 1 = the policy net; 1, 1 = the value net.
+                             * The two nets share nothing but their input (vf_share_layers False), so a multi-GPU run may drive them
+                             * as two independent chains on two streams — each train_step -> all-reduce of ITS half of flat_grad
+                             * -> pnr_mlp_adam — and one net's all-reduce overlaps the other's kernels.  Every call counts one update
+                             * in *adam_step: two chains need two counters.  `means` of a one-net call holds that net's terms only
+                             * (policy: policy_loss, kl, entropy and their share of total; value: vf_loss and its share): the
+                             * update's means are the element-wise sum of the two rows.  partial_rows >= n_nets * ceil(batch / 64) */
 } pnr_mlp_step;
 /*
  * An SGD epoch's shuffle applied once: row i of every output is row idx[i] of the corresponding input — the observation

@@ -113,6 +113,7 @@ class PnrMlpStep(C.Structure):
         ("dz1", C.c_void_p), ("dz2", C.c_void_p),
         ("partials", C.c_void_p), ("partial_rows", C.c_int64), ("slabs", C.c_void_p), ("slab_floats", C.c_int64),
         ("means", C.c_void_p), ("flat_grad", C.c_void_p), ("xs_in", C.c_void_p),
+        ("first_net", C.c_int32), ("n_nets", C.c_int32),
     ]
 
 

@@ -239,7 +239,7 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0, st, Bp);
     MlpWgradParams Wp;
     Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
-    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows;
+    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows; Wp.first_net = 0;
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kWgThreads), 0, st, Wp);
     MlpReduceParams Rp;
     Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate; Rp.scale = scale;
@@ -268,13 +268,18 @@ static int mlp_step_check(const pnr_mlp_step* s, const char* who)
         return fail(nullptr, PNR_ERR_INVALID, "%s: null weight / optimiser buffer", who);
     if (s->n3_policy < 1 || s->n3_policy > kMlpHead || s->n3_value < 1 || s->n3_value > kMlpHead)
         return fail(nullptr, PNR_ERR_INVALID, "%s: head widths must be in 1..16", who);
+    if (s->first_net < 0 || s->n_nets < 0 || s->first_net + (s->n_nets ? s->n_nets : kMlpNets) > kMlpNets)
+        return fail(nullptr, PNR_ERR_INVALID, "%s: bad net range (first_net %d, n_nets %d)", who, s->first_net, s->n_nets);
     return PNR_OK;
 }
 
 // loss_rows > 0: the launch also sums the update's loss means (rows of the fused kernel in s->partials)
+static inline int step_nets(const pnr_mlp_step* s) { return s->n_nets ? s->n_nets : kMlpNets; }
+
 static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices, float scale, hipStream_t st, long long loss_rows = 0)
 {
     MlpAdamParams A;
+    A.first_net = s->first_net;
     A.partials = loss_rows > 0 ? s->partials : nullptr; A.loss_rows = loss_rows; A.batch = s->batch; A.means = s->means;
     A.kl_coeff = s->kl_coeff; A.ent_coeff = s->entropy_coeff; A.vf_coeff = s->vf_loss_coeff;
     A.grad = grad; A.slices = slices; A.grad_scale = scale;
@@ -286,7 +291,7 @@ static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices
     A.m = s->adam_m; A.v = s->adam_v; A.step = s->adam_step;
     A.lr = s->lr; A.beta1 = s->beta1; A.beta2 = s->beta2; A.eps = s->eps;
     A.wpack = static_cast<__bf16*>(s->wpack); A.bias = s->bias;
-    hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, kMlpNets), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, step_nets(s)), dim3(256), 0, st, A);
 }
 
 int pnr_ppo_pack_record(int64_t rows, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
@@ -345,8 +350,9 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: slabs hold %lld floats, the launch needs %lld",
                     (long long)s->slab_floats, slices * kMlpNets * kGradElems);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), kMlpNets), thr(kMlpThreads);
-    const long long prow = (long long)tiles.x * kMlpNets;       // one row of loss sums per workgroup of the fused kernel
+    const int nets = step_nets(s);
+    const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), nets);
+    const long long prow = (long long)tiles.x * nets;           // one row of loss sums per workgroup of the fused kernel
     if (s->partial_rows < prow)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: partials hold %lld rows, the launch needs %lld",
                     (long long)s->partial_rows, prow);
@@ -358,7 +364,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     F.xs_in = static_cast<const __bf16*>(s->xs_in);
     if (F.xs_in) { F.idx = nullptr; F.f_loc = F.f_inv = F.f_lo = F.f_hi = nullptr; }       // everything was applied by pnr_mlp_gather
     F.xs = F.xs_in ? nullptr : static_cast<__bf16*>(s->xs); F.h1 = static_cast<__bf16*>(s->h1); F.h2 = static_cast<__bf16*>(s->h2);
-    F.B = B; F.first_net = 0; F.n_nets = kMlpNets;
+    F.B = B; F.first_net = s->first_net; F.n_nets = nets;
     F.rec_actions = s->actions; F.rec_logp = s->logp_old; F.rec_mean = s->mean_old; F.rec_log_std = s->log_std_old;
     F.rec_adv = s->adv; F.rec_vtarg = s->value_target; F.rec_values = s->value_old;
     F.kl_coeff = s->kl_coeff; F.ent_coeff = s->entropy_coeff;
@@ -374,10 +380,11 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
                            s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
     MlpWgradParams Wp;
     Wp.g_head = s->g_head; Wp.xs = F.xs_in ? F.xs_in : F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
-    Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kWgThreads), 0, st, Wp);
+    Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows; Wp.first_net = s->first_net;
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, nets), dim3(kWgThreads), 0, st, Wp);
     if (s->flat_grad)
-        hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((kMlpNets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad);
+        hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((nets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad,
+                           s->first_net * kGradElems, nets * kGradElems);
     else
         mlp_launch_adam(s, s->slabs, (int)slices, 1.0f, st, prow);      // + the loss means, in the same launch
     HIP_TRY(nullptr, hipGetLastError());

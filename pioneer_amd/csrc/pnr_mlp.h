@@ -1160,6 +1160,7 @@ struct MlpWgradParams {
     float* slabs;              // [slices][2][kGradElems]
     long long B;
     long long slice_rows;      // samples per slice, a multiple of kWgChunk
+    int first_net;             // blockIdx.z + first_net = net
 };
 
 // A 64-row chunk of COLS bf16 columns (a multiple of 8) on its way from row-major global memory (row stride src_stride)
@@ -1235,7 +1236,7 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[kWgChunk * kTrH + kWgChunk * kTrH + kWgChunk * kTrG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int slice = blockIdx.x, part = blockIdx.y, net = blockIdx.z;
+    const int slice = blockIdx.x, part = blockIdx.y, net = blockIdx.z + P.first_net;
     const long long s_begin = (long long)slice * P.slice_rows;
     long long s_end = s_begin + P.slice_rows;
     if (s_end > P.B) s_end = P.B;
@@ -1425,10 +1426,11 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(const MlpReduceParams P
 }
 
 // slabs -> one flat gradient [2][kGradElems] (the bucket a multi-GPU run all-reduces), summed in slice order
-__global__ __launch_bounds__(256) void mlp_reduce_flat_kernel(const float* __restrict__ slabs, int slices, float* __restrict__ flat)
+// (elements [first, first + count) of the bucket: one net's half when the nets are driven as two chains)
+__global__ __launch_bounds__(256) void mlp_reduce_flat_kernel(const float* __restrict__ slabs, int slices, float* __restrict__ flat, int first, int count)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kMlpNets * kGradElems) return;
+    const int i = first + blockIdx.x * 256 + threadIdx.x;
+    if (i >= first + count) return;
     constexpr size_t kStride = (size_t)kMlpNets * kGradElems;
     float s = 0.f;
     int k = 0;
@@ -1468,17 +1470,18 @@ struct MlpAdamParams {
     long long loss_rows, batch;
     float* means;              // [8]
     const float* kl_coeff; const float* ent_coeff; float vf_coeff;
+    int first_net;             // blockIdx.y + first_net = net
 };
 
 __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
 {
-    const int net = blockIdx.y;
+    const int net = blockIdx.y + P.first_net;
     if (blockIdx.x == 0) {
         // the extra block (the FIRST one, so that it starts with the launch and not as its tail): the five loss means from the fused kernel's per-workgroup rows (ppo_loss_finish_split_kernel's
         // job), in the shadow of the other 838 blocks
         // instead of a 5.6 us launch of its own
         __shared__ float red[4][kPpoSums];
-        if (net != 0 || !P.partials) return;
+        if (blockIdx.y != 0 || !P.partials) return;
         ppo_loss_means_block(P.partials, P.loss_rows, P.batch, P.means, P.kl_coeff, P.ent_coeff, P.vf_coeff, red);
         return;
     }

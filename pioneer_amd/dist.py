@@ -10,8 +10,30 @@ import torch
 import torch.distributed as dist
 
 
+_SOLO = False
+
+
+class solo:
+    """Inside this context the process behaves as a ONE-rank job although a process group exists: `is_dist()` is False (no
+    collective is issued by anything that asks it first), `world_info()` reports rank 0 of 1 (with the real local rank: the GPU).
+    What `launch.train(trial_parallel=True)` wraps a rank's own trials in — the reference's scaling axis (Tune runs
+    `num_samples` independent trials, pioneer_knm_train.py:43-44): no traffic between the GPUs at all while they train."""
+
+    def __enter__(self):
+        global _SOLO
+        self._prev, _SOLO = _SOLO, True
+        return self
+
+    def __exit__(self, *exc):
+        global _SOLO
+        _SOLO = self._prev
+        return False
+
+
 def world_info() -> Tuple[int, int, int]:
     """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    if _SOLO:
+        return 0, int(os.environ.get("LOCAL_RANK", "0")), 1
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
 
@@ -35,7 +57,30 @@ def init_distributed(backend: str = None, device: torch.device = None) -> Tuple[
 
 
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return (not _SOLO) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def run_trials(num_samples: int, run_one, trial_parallel: bool = False):
+    """`run_one(trial_index) -> row` for trials 0 .. num_samples - 1.  Default: every rank runs every trial together (each
+    trial is data-parallel over the ranks).  trial_parallel with several ranks: rank r runs trials r, r + world, ... on its own
+    (`solo`), and the rows are gathered once at the end — every rank returns all rows in trial order."""
+    rank, _, world = world_info()
+    if not (trial_parallel and is_dist()):
+        return [run_one(t) for t in range(num_samples)]
+    with solo():
+        mine = [(t, run_one(t)) for t in range(rank, num_samples, world)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    return [row for _, row in sorted((x for part in gathered for x in part), key=lambda tr: tr[0])]
+
+
+def broadcast_object(obj, src: int = 0):
+    """The same Python object on every rank (rank `src`'s)."""
+    if not is_dist():
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
 
 
 def shard_range(total_envs: int, world: int, rank: int) -> Tuple[int, int]:

@@ -41,8 +41,16 @@ def train(results_dir: str,
           log_every: int = 10,
           use_graph: bool = True,
           monitor_steps: int = 500,
-          engine_config: Optional[EngineConfig] = None):
-    """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list."""
+          engine_config: Optional[EngineConfig] = None,
+          trial_parallel: bool = False,
+          restore: Optional[str] = None):
+    """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list.
+
+    Several GPUs (torch.distributed.run): by default every trial is data-parallel over the ranks (env shards, gradients
+    all-reduced).  ``trial_parallel=True`` is the reference's own parallelism instead — Tune runs its ``num_samples`` trials
+    independently (pioneer_knm_train.py:43-44; cli.py:15 defaults to 128 of them): rank r trains trials r, r + world, ... on
+    its own GPU with ``num_workers x envs_per_worker`` envs each and NO traffic between the GPUs until the result rows are
+    gathered at the end.  ``restore``: a PPOTrainer.save() checkpoint every trial starts from (Tune's restore=...)."""
     # the engine's own options: as given, or — dynamics mode — the inertia-scaled motor (omega = 20 rad/s, zeta = 1 on every
     # joint: with plain torque gains PPO does not learn the task, DESIGN.md section 6); TimeLimit(500) and auto-reset as
     # the reference's prepare_env wraps it (pioneer_knm_train.py:27)
@@ -53,19 +61,20 @@ def train(results_dir: str,
     if not engine.auto_reset:
         raise AssertionError("train(): engine_config.auto_reset must be True (the sampler relies on the in-kernel auto-reset)")
     mode = engine.mode
-    rank, local_rank, world = pdist.world_info()
+    _, local_rank, _ = pdist.world_info()
     if os.environ.get("PNR_DIST_BACKEND") == "gloo":        # rehearsal: ranks may share the visible GPUs
         local_rank %= max(1, torch.cuda.device_count())
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     pdist.init_distributed(device=device)
     results_dir = os.path.expanduser(results_dir)
-    experiment_id = uuid.uuid4().hex
-    rows: List[Dict] = []
-    total_envs = max(1, num_workers) * envs_per_worker * world
-    start, count = pdist.shard_range(total_envs, world, rank)
+    experiment_id = pdist.broadcast_object(uuid.uuid4().hex)
 
-    for trial in range(num_samples):
+    def run_one(trial: int) -> Dict:
+        # (inside run_trials' solo context with trial_parallel: this rank is then "rank 0 of 1")
+        rank, _, world = pdist.world_info()
+        total_envs = max(1, num_workers) * envs_per_worker * world
+        start, count = pdist.shard_range(total_envs, world, rank)
         trial_id = f"{trial:05d}"
         tdir = os.path.join(results_dir, f"PPO_Pioneer-v1_{trial_id}")
         if rank == 0:
@@ -88,7 +97,9 @@ def train(results_dir: str,
         env = PioneerVectorEnv(count, device=device, seed=cfg.seed, env_id_offset=start,
                                pioneer_config=pioneer_config,
                                engine_config=engine)
-        trainer = PPOTrainer(env, cfg, use_graph=use_graph)   # hipGraph-captured sampling and updates
+        trainer = PPOTrainer(env, cfg, use_graph=use_graph)   # hipGraph-captured sampling
+        if restore:
+            trainer.restore(os.path.expanduser(restore))
         last = {}
         # the files Tune leaves in a trial directory: params.json, result.json (one line per iteration), progress.csv,
         # a TensorBoard event file
@@ -130,8 +141,10 @@ def train(results_dir: str,
             csv_log.close()
         if tb_log:
             tb_log.close()
-        rows.append(last)
         env.close()
+        return last
+
+    rows: List[Dict] = pdist.run_trials(num_samples, run_one, trial_parallel)
     try:
         import pandas as pd
         return pd.DataFrame(rows)

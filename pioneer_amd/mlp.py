@@ -150,9 +150,12 @@ class HipMLP:
             n = int(self.lib.pnr_mlp_grad_floats())
             f32 = dict(dtype=torch.float32, device=self.device)
             self._adam = (torch.zeros(n, **f32), torch.zeros(n, **f32), torch.zeros((), **f32))
+            self._step_value_net = torch.zeros((), **f32)      # the value net's own count when the nets run as two chains
         return self._adam
 
-    def _step_args(self, lr, betas, eps):
+    def _step_args(self, lr, betas, eps, nets=None):
+        """nets = (first_net, n_nets) or None for both.  Every train_step call counts one update in its counter, so the value
+        net's chain (nets == (1, 1)) counts in a counter of its own; it follows the common one whenever both nets step together."""
         s = _lib.PnrMlpStep()
         s.struct_size = C.sizeof(_lib.PnrMlpStep)
         for k, prm in enumerate(self.params):
@@ -160,9 +163,19 @@ class HipMLP:
         s.n3_policy, s.n3_value = self.n3
         m, v, step = self.adam_state()
         s.wpack, s.bias = self.wpack.data_ptr(), self.bias.data_ptr()
-        s.adam_m, s.adam_v, s.adam_step = m.data_ptr(), v.data_ptr(), step.data_ptr()
+        s.adam_m, s.adam_v = m.data_ptr(), v.data_ptr()
+        s.adam_step = (self._step_value_net if nets == (1, 1) else step).data_ptr()
         s.lr, s.beta1, s.beta2, s.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
+        if nets is not None:
+            s.first_net, s.n_nets = int(nets[0]), int(nets[1])
         return s
+
+    def sync_step_counters(self, to_chains: bool) -> None:
+        """Two-chain mode keeps one update count per net: copied from the common count before the chains start, and back (they
+        agree) after they have joined."""
+        _, _, step = self.adam_state()
+        if to_chains:
+            self._step_value_net.copy_(step)
 
     REC_KEYS = ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values")
 
@@ -215,7 +228,7 @@ class HipMLP:
 
     def train_step(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float, means_out: torch.Tensor,
                    lr: float, betas=(0.9, 0.999), eps: float = 1e-8, flat_grad: Optional[torch.Tensor] = None,
-                   xs_in: Optional[torch.Tensor] = None) -> None:
+                   xs_in: Optional[torch.Tensor] = None, nets=None) -> None:
         """Forward, loss, backward and — unless ``flat_grad`` is given — the Adam update of the float32 master
         parameters plus the refresh of the packed bf16 weights, all on the device (pnr_mlp_train_step).  With
         ``flat_grad`` ([pnr_mlp_grad_floats()]) the reduced gradient lands there instead and nothing is updated: all-reduce
@@ -236,7 +249,7 @@ class HipMLP:
             v = rec[k]
             assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
         assert means_out.dtype == torch.float32 and means_out.numel() >= 8 and means_out.is_contiguous()
-        s = self._step_args(lr, betas, eps)
+        s = self._step_args(lr, betas, eps, nets)
         s.batch = B
         if xs_in is not None:
             s.xs_in = xs_in.data_ptr()
@@ -258,8 +271,10 @@ class HipMLP:
             s.flat_grad = flat_grad.data_ptr()
         _lib.check(self.lib.pnr_mlp_train_step(C.byref(s), self._stream()))
 
-    def adam(self, flat_grad: torch.Tensor, grad_scale: float, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
-        s = self._step_args(lr, betas, eps)
+    def adam(self, flat_grad: torch.Tensor, grad_scale: float, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, nets=None) -> None:
+        """Adam on the all-reduced bucket ``flat_grad`` ([pnr_mlp_grad_floats()], always the WHOLE bucket: ``nets`` selects the half
+        that is applied)."""
+        s = self._step_args(lr, betas, eps, nets)
         _lib.check(self.lib.pnr_mlp_adam(C.byref(s), _p(flat_grad), C.c_float(grad_scale), self._stream()))
 
     def policy_loss(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float) -> torch.Tensor:

@@ -19,6 +19,36 @@ def test_parser_keeps_the_reference_options():
         ap.parse_args(["pioneer-train-kinem"])                      # -e is required, as in the reference
     e = ap.parse_args(["pioneer-eval", "-k", "ck.pt", "--gif", "o.gif"])
     assert e.checkpoint == "ck.pt" and e.gif == "o.gif" and e.episodes == 3
+    a = ap.parse_args(["pioneer-train-kinem", "-e", "x", "--restore", "ck.pt", "--trial-parallel"])
+    assert a.restore == "ck.pt" and a.trial_parallel
+    t = ap.parse_args(["tensorboard", "-e", "exp1"])                # the reference's second sub-command (cli.py:43-55)
+    assert t.command == "tensorboard" and t.experiment == "exp1" and t.port == 6006
+
+
+def test_shipped_config_yaml_has_the_reference_keys():
+    import cli
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config.yaml")))
+    assert set(cfg) == {"tracking", "logging"} and "training_root" in cfg["tracking"]
+    assert cfg["logging"]["version"] == 1 and cfg["logging"]["root"]["handlers"] == ["console_handler"]
+    s = cli.load_settings()                                          # the dictConfig is valid
+    assert s["tracking"]["training_root"] == cfg["tracking"]["training_root"]
+
+
+def test_tensorboard_command_without_the_package(tmp_path, monkeypatch, capsys):
+    """No TensorBoard in this image: the command names the event files and fails (exit code 3) instead of pretending."""
+    import importlib.util
+    import cli
+    if importlib.util.find_spec("tensorboard") is not None:
+        pytest.skip("tensorboard is installed")
+    monkeypatch.setitem(cli.DEFAULTS["tracking"], "training_root", str(tmp_path))
+    monkeypatch.setattr(cli, "HERE", str(tmp_path))                  # no config.yaml: the defaults
+    d = tmp_path / "exp1" / "PPO_Pioneer-v1_00000"
+    d.mkdir(parents=True)
+    (d / "events.out.tfevents.1.host").write_bytes(b"")
+    assert cli.main(["tensorboard", "-e", "exp1"]) == 3
+    err = capsys.readouterr().err
+    assert "1 event file(s)" in err and "tensorboard --bind_all" in err
 
 
 def test_settings_default_and_yaml_override(tmp_path, monkeypatch):
@@ -34,6 +64,7 @@ def test_settings_default_and_yaml_override(tmp_path, monkeypatch):
 def test_train_then_eval_through_the_cli(tmp_path, monkeypatch, capsys):
     import cli
     monkeypatch.setitem(cli.DEFAULTS["tracking"], "training_root", str(tmp_path))
+    monkeypatch.setattr(cli, "HERE", str(tmp_path))                  # not the repo's config.yaml: the defaults above
     rc = cli.main(["pioneer-train-kinem", "-e", "smoke", "-c", "1", "-n", "1", "-w", "1", "--no-monitor",
                    "--iterations", "2", "--envs-per-worker", "256"])
     assert rc == 0
@@ -45,6 +76,13 @@ def test_train_then_eval_through_the_cli(tmp_path, monkeypatch, capsys):
     rc = cli.main(["pioneer-eval", "-k", str(tdir / "checkpoint_final.pt"), "--episodes", "1", "--max-steps", "6",
                    "--gif", str(tmp_path / "e.gif")])
     assert rc == 0 and (tmp_path / "e.gif").exists() and "episode_rewards" in capsys.readouterr().out
+    # --restore: a second experiment continues from the first one's checkpoint (iteration and timestep counters carry on)
+    rc = cli.main(["pioneer-train-kinem", "-e", "resumed", "-c", "0", "-n", "1", "--no-monitor", "--iterations", "1",
+                   "--envs-per-worker", "256", "--restore", str(tdir / "checkpoint_final.pt")])
+    assert rc == 0
+    import json
+    row = json.loads((tmp_path / "resumed" / "PPO_Pioneer-v1_00000" / "result.json").read_text().strip().splitlines()[-1])
+    assert row["training_iteration"] == 3 and row["timesteps_total"] == 3 * 32 * 256
 
 
 @pytest.mark.gpu

@@ -48,6 +48,49 @@ def test_two_ranks_train_in_lock_step(tmp_path):
     assert r0["wsum"] == r1["wsum"] and r0["wabs"] == r1["wabs"]                   # one checkpoint, ranks in lock-step
 
 
+TRIAL_WORKER = r'''
+import json, os, sys, torch
+sys.path.insert(0, os.environ["PNR_ROOT"])
+from pioneer_amd.launch import train
+from pioneer_amd.ppo import PPOConfig
+out = os.environ["PNR_OUT"]
+df = train(results_dir=out, checkpoint_freq=0, num_samples=3, num_workers=1, monitor=False, training_iterations=2, envs_per_worker=256,
+           ppo_config=PPOConfig(rollout_fragment_length=8, num_sgd_iter=2, sgd_minibatch_size=1024, seed=5), trial_parallel=True)
+rows = df.to_dict("records") if hasattr(df, "to_dict") else df
+json.dump([{k: r[k] for k in ("trial_id", "experiment_id", "timesteps_total", "kl", "episodes_total")} for r in rows],
+          open(os.path.join(out, f"trials_rank{os.environ['RANK']}.json"), "w"))
+'''
+
+
+def test_trial_parallel_training_on_two_ranks(tmp_path):
+    """The reference's own scaling axis (Tune's num_samples trials, pioneer_knm_train.py:43-44): with trial_parallel each rank
+    trains its own trials as a one-rank job — 256 envs each, not 512 shared — and every rank gets all rows; a trial's result
+    equals (to the rounding of the CPU-side weight initialisation) the same trial trained by a single process."""
+    script = tmp_path / "trials.py"
+    script.write_text(TRIAL_WORKER)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, PNR_ROOT=ROOT, PNR_OUT=str(tmp_path), PNR_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r0 = json.load(open(tmp_path / "trials_rank0.json")); r1 = json.load(open(tmp_path / "trials_rank1.json"))
+    assert r0 == r1 and [r["trial_id"] for r in r0] == ["00000", "00001", "00002"]
+    assert len({r["experiment_id"] for r in r0}) == 1
+    assert all(r["timesteps_total"] == 2 * 8 * 256 for r in r0)       # one rank's envs per trial: nothing was sharded
+    for t in ("00000", "00001", "00002"):
+        assert (tmp_path / f"PPO_Pioneer-v1_{t}" / "checkpoint_final.pt").exists()
+    # the same trial 1 in this process (one rank): identical result row
+    from pioneer_amd.launch import train
+    from pioneer_amd.ppo import PPOConfig
+    solo = train(results_dir=str(tmp_path / "solo"), checkpoint_freq=0, num_samples=2, num_workers=1, monitor=False, training_iterations=2,
+                 envs_per_worker=256, ppo_config=PPOConfig(rollout_fragment_length=8, num_sgd_iter=2, sgd_minibatch_size=1024, seed=5))
+    row = (solo.to_dict("records") if hasattr(solo, "to_dict") else solo)[1]
+    # (to rounding: the nets' orthogonal initialisation is a CPU QR factorisation whose last bits follow the BLAS thread count,
+    # which differs between this process and the torchrun children)
+    assert abs(row["kl"] - r0[1]["kl"]) <= 2e-2 * abs(row["kl"]) and row["episodes_total"] == r0[1]["episodes_total"]
+
+
 LEARNER_WORKER = r'''
 import json, os, sys, torch
 import torch.distributed as dist
@@ -64,14 +107,24 @@ act, mean, log_std = R(B, 6), 0.1 * R(B, 6), 0.1 * R(B, 6)
 batch = {"obs": R(B, 137), "actions": act, "mean": mean, "log_std": log_std, "logp": gaussian_logp(act, mean, log_std) + 0.2 * R(B),
          "values": R(B), "adv": R(B), "vtarg": R(B)}
 cfg = PPOConfig(num_sgd_iter=3, sgd_minibatch_size=B // 2, lr=1e-3, seed=11)
-L = PPOLearner(cfg, dev)
-w0 = torch.cat([p.detach().reshape(-1).double().cpu() for p in L.model.parameters()])
-infos = [L.update(dict(batch)) for _ in range(3)]                # 18 updates, each with its gradient all-reduce
-w = torch.cat([p.detach().reshape(-1).double().cpu() for p in L.model.parameters()])
-m, v, step = L.hip_mlp(1).adam_state()
-json.dump({"rank": rank, "hip": bool(L.hip), "flat_bucket": L._flat_grad is not None, "move": float((w - w0).abs().max()),
-           "wsum": float(w.sum()), "wabs": float(w.abs().sum()), "msum": float(m.double().sum()), "vsum": float(v.double().sum()),
-           "step": float(step), "kl": [i["kl"] for i in infos], "total_loss": [i["total_loss"] for i in infos]},
+out = {}
+for chains in (True, False):
+    L = PPOLearner(cfg, dev)
+    L.net_chains = chains          # True (default): the two nets as two SGD chains on two streams, each with its own all-reduce
+    w0 = torch.cat([p.detach().reshape(-1).double().cpu() for p in L.model.parameters()])
+    infos = [L.update(dict(batch)) for _ in range(3)]                # 18 updates, each with its gradient all-reduce(s)
+    torch.cuda.synchronize()
+    w = torch.cat([p.detach().reshape(-1).double().cpu() for p in L.model.parameters()])
+    m, v, step = L.hip_mlp(1).adam_state()
+    out[str(chains)] = {"hip": bool(L.hip), "flat_bucket": L._flat_grad is not None, "streams": L._net_streams is not None,
+                        "move": float((w - w0).abs().max()), "w": w, "m": m.double().cpu(), "v": v.double().cpu(), "step": float(step),
+                        "kl": [i["kl"] for i in infos], "total_loss": [i["total_loss"] for i in infos]}
+a, b = out["True"], out["False"]
+same = bool(torch.equal(a["w"], b["w"]) and torch.equal(a["m"], b["m"]) and torch.equal(a["v"], b["v"]))
+json.dump({"rank": rank, "hip": a["hip"] and b["hip"], "flat_bucket": a["flat_bucket"], "chains_ran": a["streams"] and not b["streams"],
+           "chains_equal_one_bucket": same, "loss_gap": max(abs(x - y) for x, y in zip(a["total_loss"] + a["kl"], b["total_loss"] + b["kl"])),
+           "move": a["move"], "wsum": float(a["w"].sum()), "wabs": float(a["w"].abs().sum()), "msum": float(a["m"].sum()),
+           "vsum": float(a["v"].sum()), "step": a["step"], "kl": a["kl"], "total_loss": a["total_loss"]},
           open(os.path.join(os.environ["PNR_OUT"], f"learner{rank}.json"), "w"))
 dist.destroy_process_group()
 '''
@@ -79,7 +132,9 @@ dist.destroy_process_group()
 
 def test_hip_learner_keeps_two_ranks_in_lock_step(tmp_path):
     """Several ranks on the kernels: every update's gradient is all-reduced before Adam, so master weights, Adam's moments and
-    the reported (rank-averaged) losses are identical on both ranks although each rank trains on its own share of the batch."""
+    the reported (rank-averaged) losses are identical on both ranks although each rank trains on its own share of the batch —
+    and the two-chain form (each net on its own stream with its own all-reduce, what a multi-GPU run uses) leaves exactly the
+    weights and moments of the serial one-bucket form."""
     script = tmp_path / "learner.py"
     script.write_text(LEARNER_WORKER)
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
@@ -91,6 +146,8 @@ def test_hip_learner_keeps_two_ranks_in_lock_step(tmp_path):
     r0 = json.load(open(tmp_path / "learner0.json")); r1 = json.load(open(tmp_path / "learner1.json"))
     for r in (r0, r1):
         assert r["hip"] and r["flat_bucket"] and r["step"] == 18.0, r
+        assert r["chains_ran"] and r["chains_equal_one_bucket"], r    # bit for bit: same sums per element, same Adam arithmetic
+        assert r["loss_gap"] < 1e-5                                   # the means differ in the order of three additions only
         assert r["move"] > 1e-3                                    # the weights did move
         assert all(np.isfinite(x) for x in r["kl"] + r["total_loss"])
     for k in ("wsum", "wabs", "msum", "vsum", "kl", "total_loss"):

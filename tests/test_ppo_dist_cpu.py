@@ -161,3 +161,40 @@ def test_learner_improves_surrogate_single_process():
     info = L.update(b, torch.Generator().manual_seed(0))
     after = float(L.loss(dict(b, adv=(b["adv"] - b["adv"].mean()) / b["adv"].std()))[0])
     assert after < before and np.isfinite(info["kl"]) and info["kl"] >= 0
+
+
+def _trial_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    pdist.init_distributed(backend="gloo")
+    seen = []
+
+    def run_one(t):
+        # inside a rank's own trial nothing may reach for the process group
+        assert not pdist.is_dist() and pdist.world_info() == (0, rank, 1)
+        L = PPOLearner(PPOConfig(num_sgd_iter=1, sgd_minibatch_size=32, lr=1e-3, seed=t), "cpu")   # broadcast_module_ must be a no-op
+        info = L.update(make_batch(64, seed=t), torch.Generator().manual_seed(t))
+        seen.append(t)
+        return {"trial_id": f"{t:05d}", "rank": rank, "kl": info["kl"]}
+
+    rows = pdist.run_trials(5, run_one, trial_parallel=True)
+    assert pdist.is_dist() and pdist.world_info() == (rank, rank, world)              # back to the two-rank job
+    exp = pdist.broadcast_object(f"exp-from-{rank}")
+    torch.save({"rows": rows, "seen": seen, "exp": exp}, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_trial_parallel_runs_each_trial_on_one_rank_and_gathers_the_rows(tmp_path):
+    """launch.train(trial_parallel=True)'s plumbing (pdist.run_trials / solo) under gloo, world size 2: rank r runs trials r,
+    r + 2, ... as a one-rank job (no collective inside a trial), every rank ends up with all rows in trial order, and a trial's
+    result equals the same trial run in a single process."""
+    port = _free_port()
+    mp.spawn(_trial_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "t0.pt", weights_only=False); r1 = torch.load(tmp_path / "t1.pt", weights_only=False)
+    assert r0["seen"] == [0, 2, 4] and r1["seen"] == [1, 3]
+    assert r0["rows"] == r1["rows"] and [r["trial_id"] for r in r0["rows"]] == [f"{t:05d}" for t in range(5)]
+    assert [r["rank"] for r in r0["rows"]] == [0, 1, 0, 1, 0]
+    assert r0["exp"] == r1["exp"] == "exp-from-0"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    L = PPOLearner(PPOConfig(num_sgd_iter=1, sgd_minibatch_size=32, lr=1e-3, seed=3), "cpu")
+    assert L.update(make_batch(64, seed=3), torch.Generator().manual_seed(3))["kl"] == r0["rows"][3]["kl"]
