@@ -441,7 +441,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
 #define PNR_DYN_LAUNCH2(O, A, R, C) do { \
         if (T > 1) hipLaunchKernelGGL((dyn_rollout_kernel<O, A, R, C>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                       Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); \
-        else hipLaunchKernelGGL((dyn_step_kernel<O, A, R, C>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
+        else hipLaunchKernelGGL((dyn_step_kernel<O, A, R, C>), gridD, dim3(kWave * kDynStepWaves), 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                 Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); } while (0)
             // contact-free handles run instantiations without any contact code
             // (PHYS: bit 0 contacts, bit 1 the inertia-scaled motor)

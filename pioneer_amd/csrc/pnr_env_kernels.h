@@ -281,27 +281,38 @@ __device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParam
 
 // Leading scalar arguments as in step_kernel: preloaded into SGPRs, they repeat P.state / D.dyn / P.actions /
 // P.n / P.dt / P.eps and carry max_v_to_r.
+// PNR_DYN_STEP_WAVES = 2 (default): the workgroup is TWO waves.  Wave 0 runs phase A for the 64 envs (wave 1 waits at the barrier
+// and takes no issue slot); in phase B each wave finishes ONE of the two 32-env tiles in an obs tile of its own, side by side on
+// two SIMDs, instead of wave 0 finishing them one after the other (phase B is ~40 % of the step's fixed cost).  1 = the r02 form (A/B).
+#ifndef PNR_DYN_STEP_WAVES
+#define PNR_DYN_STEP_WAVES 2
+#endif
+constexpr int kDynStepWaves = PNR_DYN_STEP_WAVES;
+static_assert(kDynStepWaves == 1 || kDynStepWaves == 2, "one or two waves per dynamics-step workgroup");
+
 template <bool OBS_EM, bool ACT_EM, bool RAND, int PHYS>
-__global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
+__global__ __launch_bounds__(kWave * kDynStepWaves) void dyn_step_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
                                                          const float* __restrict__ actions_, const long long n_,
                                                          const double dt_, const double eps_, const float max_v_to_r_,
                                                          const KParams P, const DynParams D)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float lds[kDynStepWaves * kTileFloats];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
     const long long n = n_;
     const long long base = (long long)blockIdx.x * kDynEnvsPerWg;
-    float4* hrec = reinterpret_cast<float4*>(tile);               // [3][2 * 64] records, index 2 * env + p
-    float* hq = tile + kHandRecFloats;                            // [12][64]: q then qd
+    float* tile = lds + wv * kTileFloats;                         // this wave's obs tile
+    float4* hrec = reinterpret_cast<float4*>(lds);                // hand-off (head of tile 0): [3][2 * 64] records, index 2 * env + p
+    float* hq = lds + kHandRecFloats;                             // [12][64]: q then qd
+    const auto handoff_sync = [] { if (kDynStepWaves == 1) wave_lds_sync(); else __syncthreads(); };
 
-    // ---- phase A: one env per lane
-    {
+    // ---- phase A: one env per lane (wave 0)
+    if (wv == 0) {
         const long long e = base + lane;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 k0[2] = {z4, z4}, k1[2] = {z4, z4}, k2[2] = {z4, z4};
         float q[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, qd[kDof] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
-        if (e < n) dyn_substeps_lane<ACT_EM, RAND, PHYS>(lead, D, e, k0, k1, k2, q, qd, tile);   // tile: free during phase A
+        if (e < n) dyn_substeps_lane<ACT_EM, RAND, PHYS>(lead, D, e, k0, k1, k2, q, qd, lds);   // the LDS is free during phase A
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             hrec[2 * lane + p] = k0[p];
@@ -314,33 +325,39 @@ __global__ __launch_bounds__(kWave) void dyn_step_kernel(const float4* __restric
             hq[(kDof + i) * kDynEnvsPerWg + lane] = qd[i];
         }
     }
-    wave_lds_sync();
+    handoff_sync();
 
-    // ---- phase B: lane pairs; both tiles' hand-off records leave LDS before the tile is reused
+    // ---- phase B: lane pairs; every tile's hand-off records leave LDS before tile 0 (which they alias) is reused
     const int p = lane & 1, el = lane >> 1;
     RawState raw0, raw1;
     float dq0[kJpl], dqd0[kJpl], dq1[kJpl], dqd1[kJpl];
     {
-        const int r0 = lane, r1 = 2 * kEnvsPerWave + lane;        // record 2 * env + p of env el / env 32 + el
+        // one wave: tiles 0 and 1; two waves: wave wv takes tile wv (raw0 / dq0 / dqd0)
+        const int t0 = kDynStepWaves == 1 ? 0 : wv;
+        const int r0 = 2 * kEnvsPerWave * t0 + lane, r1 = 2 * kEnvsPerWave + lane;        // record 2 * env + p
         raw0 = {hrec[r0], hrec[2 * kDynEnvsPerWg + r0], hrec[4 * kDynEnvsPerWg + r0]};
         raw1 = {hrec[r1], hrec[2 * kDynEnvsPerWg + r1], hrec[4 * kDynEnvsPerWg + r1]};
 #pragma unroll
         for (int i = 0; i < kJpl; ++i) {
-            dq0[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + el];
-            dqd0[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + el];
+            dq0[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave * t0 + el];
+            dqd0[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave * t0 + el];
             dq1[i] = hq[(kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave + el];
             dqd1[i] = hq[(kDof + kJpl * p + i) * kDynEnvsPerWg + kEnvsPerWave + el];
         }
     }
-    wave_lds_sync();
+    handoff_sync();
     const LaneConsts K = lane_consts(p);
     // the 36 constant obs entries of this lane's tile slots: once per kernel
     if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K, sink); }
     else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K, sink); }
 
-    dyn_finish_tile<OBS_EM>(P, D, K, raw0, dq0, dqd0, tile, base, lane, false);
-    if (base + kEnvsPerWave < n)
-        dyn_finish_tile<OBS_EM>(P, D, K, raw1, dq1, dqd1, tile, base + kEnvsPerWave, lane, true);
+    if (kDynStepWaves == 1) {
+        dyn_finish_tile<OBS_EM>(P, D, K, raw0, dq0, dqd0, tile, base, lane, false);
+        if (base + kEnvsPerWave < n)
+            dyn_finish_tile<OBS_EM>(P, D, K, raw1, dq1, dqd1, tile, base + kEnvsPerWave, lane, true);
+    } else if (base + (long long)kEnvsPerWave * wv < n) {
+        dyn_finish_tile<OBS_EM>(P, D, K, raw0, dq0, dqd0, tile, base + (long long)kEnvsPerWave * wv, lane, false);
+    }
 }
 
 

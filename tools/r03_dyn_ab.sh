@@ -1,0 +1,11 @@
+set -e
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+for lib in default "$@"; do
+  if [ "$lib" != default ]; then export PNR_LIB_PATH=$R/pioneer_amd/csrc/$lib; else unset PNR_LIB_PATH; fi
+  for n in 65536 8192; do
+    python $R/bench.py --mode dynamic --randomize --gravity 9.81 --envs $n --no-cpu-baseline --ppo-iters 0 --steps 2000 --warmup 200 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$lib', $n, 'us/step %.2f' % (d['roofline']['avg_launch_ms']*1e3), 'value %.3e' % d['value'])"
+  done
+done
