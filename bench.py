@@ -617,7 +617,8 @@ def run_rank(args):
                 "hip_graph": graphed, "iters": iters, "losses_finite": finite,
                 "grad_allreduce": ({"backend": backend, "world_size": world,
                                     "bytes": 4 * (int(_lib.load_library().pnr_mlp_grad_floats()) if hip_learner else 205581),
-                                    "per": "minibatch, one flat bucket" + (" (the kernels' padded layout)" if hip_learner else "")}
+                                    "per": ("minibatch; the two nets as two chains on two streams, each all-reducing its half of the bucket "
+                                            "(the kernels' padded layout)" if hip_learner else "minibatch, one flat bucket")}
                                    if world > 1 else None),
                 "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                 "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
