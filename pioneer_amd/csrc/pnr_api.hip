@@ -424,7 +424,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     KParams P = h->base;
     P.diag = h->diag;
     P.T = T; P.actions = actions; P.obs = obs; P.reward = reward; P.done = done; P.trunc = truncated; P.info = info;
-    const dim3 grid(step_grid_for(h->n, T)), block(kWave);
+    const dim3 grid((step_grid_for(h->n, T) + kStepWaves - 1) / kStepWaves), block(kWave * kStepWaves);   // the cap counts WAVES
     hipStream_t st = (hipStream_t)stream;
     const DynParams& D = h->dbase;
     const bool oem = h->cfg.obs_layout == PNR_ENV_MAJOR, aem = h->cfg.action_layout == PNR_ENV_MAJOR;
@@ -439,7 +439,7 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
             // T > 1: dyn_rollout_kernel loops over the steps inside the launch (state in registers, stores of step t
             // under the sub-steps of t + 1); T == 1: the lean single-step kernel
 #define PNR_DYN_LAUNCH2(O, A, R, C) do { \
-        if (T > 1) hipLaunchKernelGGL((dyn_rollout_kernel<O, A, R, C>), gridD, block, 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
+        if (T > 1) hipLaunchKernelGGL((dyn_rollout_kernel<O, A, R, C>), dim3((gridD.x + kDynRolloutWaves - 1) / kDynRolloutWaves), dim3(kWave * kDynRolloutWaves), 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                       Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); \
         else hipLaunchKernelGGL((dyn_step_kernel<O, A, R, C>), gridD, dim3(kWave * kDynStepWaves), 0, st, Pt.state, D.dyn, Pt.actions, Pt.n, Pt.dt, \
                                 Pt.eps, (float)h->cfg.max_v_to_r, Pt, D); } while (0)

@@ -25,14 +25,24 @@ namespace pnr {
 // is formed from it and the constexpr limits): plain leading arguments (up to 14 dwords) are preloaded into SGPRs by the command processor (-mllvm
 // -amdgpu-kernarg-preload-count), so neither the first state and action loads nor the integrator wait for
 // a kernarg fetch; the by-value struct, needed from the reward block on, is fetched behind them.
+// PNR_STEP_WAVES waves per workgroup (default 4).  The waves of a workgroup share nothing — each has its own obs tile and walks its
+// own tiles, no barrier — so this only changes what the dispatcher places: with four-wave workgroups a rollout's 1 024 waves are 256
+// workgroups = exactly one per CU, one wave per SIMD, where 1 024 one-wave workgroups landed unevenly (A/B r03 in one run, twice:
+// 7.36 -> 6.33 us per rollout step at 65 536 envs; single steps unchanged, 10.38 vs 10.31 us).
+#ifndef PNR_STEP_WAVES
+#define PNR_STEP_WAVES 4
+#endif
+constexpr int kStepWaves = PNR_STEP_WAVES;
+
 template <bool OBS_EM, bool ACT_EM>
-__global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_, const float* __restrict__ actions_,
+__global__ __launch_bounds__(kWave * kStepWaves) void step_kernel(float4* __restrict__ state_, const float* __restrict__ actions_,
                                                      const long long n_, const double dt_, const double eps_,
                                                      const float max_v_to_r_, const KParams P)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+    __shared__ __attribute__((aligned(16))) float tiles_[kStepWaves * kTileFloats];
+    float* tile = tiles_ + (threadIdx.x >> 6) * kTileFloats;
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
     const int p = lane & 1;                 // which half of the env's joints
     const int el = lane >> 1;               // env within the wave's tile
     const long long n = n_;
@@ -61,7 +71,8 @@ __global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_
         }
     };
 
-    long long tix = blockIdx.x;
+    const long long tstride = (long long)gridDim.x * kStepWaves;
+    long long tix = (long long)blockIdx.x * kStepWaves + (threadIdx.x >> 6);
     RawState raw = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float act0[kJpl] = {0.f, 0.f, 0.f};
     if (tix < ntiles && tix * kEnvsPerWave + el < n) {
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_
     if (OBS_EM) { SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p}; emit_obs_const(K, sink); }
     else { SinkLdsFeatureTile sink{tile + el, kJpl * p, p}; emit_obs_const(K, sink); }
 
-    for (; tix < ntiles; tix += gridDim.x) {
+    for (; tix < ntiles; tix += tstride) {
     const long long tile0 = tix * kEnvsPerWave;
     const long long e = tile0 + el;
     const long long rec = 2 * tile0 + lane; // state record index (2e + p)
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(float4* __restrict__ state_
 
     // prefetch the next tile
     {
-        const long long nt = tix + gridDim.x;
+        const long long nt = tix + tstride;
         if (nt < ntiles && nt * kEnvsPerWave + el < n) {
             raw = load_state_raw(state_, n, 2 * nt * kEnvsPerWave + lane);
             load_act0(nt * kEnvsPerWave + el, act0);
@@ -361,6 +372,13 @@ __global__ __launch_bounds__(kWave * kDynStepWaves) void dyn_step_kernel(const f
 }
 
 
+// independent waves per workgroup of dyn_rollout_kernel (own LDS slice, own 64 envs each).  A/B r03 in one run, twice: 25.60 us per
+// rollout step with four (256 workgroups = one wave per SIMD by construction) against 25.65 with one: its waves already landed one per
+// SIMD, so the r02 form stays.
+#ifndef PNR_DYN_ROLLOUT_WAVES
+#define PNR_DYN_ROLLOUT_WAVES 1
+#endif
+constexpr int kDynRolloutWaves = PNR_DYN_ROLLOUT_WAVES;
 constexpr int kComFloats = 2 * kWave * 4;                  // common words of each lane's two envs between steps: float4 [2][64]
 constexpr int kRstFloats = (1 + kDof) * kDynEnvsPerWg;     // reset notes: episode flag + new r [7][64]
 
@@ -510,20 +528,24 @@ __device__ __forceinline__ void dyn_rollout_tile(const KParams& P, const DynPara
 // kernel runs one wave per SIMD anyway), so a tile's values are read right before that tile is finished and
 // nothing of phase B is live during the sub-steps.
 template <bool OBS_EM, bool ACT_EM, bool RAND, int PHYS>
-__global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
+__global__ __launch_bounds__(kWave * kDynRolloutWaves) void dyn_rollout_kernel(const float4* __restrict__ state_, const float* __restrict__ dyn_,
                                                          const float* __restrict__ actions_, const long long n_,
                                                          const double dt_, const double eps_, const float max_v_to_r_,
                                                          const KParams P, const DynParams D)
 {
-    __shared__ __attribute__((aligned(16))) float lds[kTileFloats + kComFloats + kRstFloats + kHandFloats + (PNR_DYN_LDS_MODEL ? kDynStageWords * 64 : 0)];
+    // kDynRolloutWaves independent waves per workgroup (each with its own LDS slice and its own 64 envs; no barrier between them):
+    // at 65 536 envs the 1 024 waves are 256 workgroups = exactly one wave per SIMD, whatever the dispatcher does
+    constexpr int kPerWave = kTileFloats + kComFloats + kRstFloats + kHandFloats + (PNR_DYN_LDS_MODEL ? kDynStageWords * 64 : 0);
+    __shared__ __attribute__((aligned(16))) float lds_all[kDynRolloutWaves * kPerWave];
+    float* lds = lds_all + (threadIdx.x >> 6) * kPerWave;
     float* tile = lds;
     float4* com = reinterpret_cast<float4*>(lds + kTileFloats);   // [2][64] common words between steps, index tile * 64 + lane
     float* rst = lds + kTileFloats + kComFloats;                  // [7][64] reset notes, phase B -> phase A
     float* hand = lds + kTileFloats + kComFloats + kRstFloats;    // records + q, qd planes (kHandFloats)
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
     const int p = lane & 1, el = lane >> 1;
     const long long n = n_;
-    const long long base = (long long)blockIdx.x * kDynEnvsPerWg;
+    const long long base = ((long long)blockIdx.x * kDynRolloutWaves + (threadIdx.x >> 6)) * kDynEnvsPerWg;
     const long long eA = base + lane;                             // phase A: this lane's env
     const bool liveA = eA < n;
     const DynLead lead = {state_, dyn_, actions_, n_, dt_, eps_, max_v_to_r_};
@@ -545,6 +567,7 @@ __global__ __launch_bounds__(kWave) void dyn_rollout_kernel(const float4* __rest
     }
 
     const int T = P.T;
+    if (base >= n) return;          // a wave past the end of the batch (whole wave: no barrier follows in this kernel)
     for (int t = 0; t < T; ++t) {
         // ---- phase A: one env per lane
         if (liveA) dyn_lane_advance<ACT_EM, RAND, PHYS>(lead, D, base, lane, t + 1 < T ? actions_ + (long long)(t + 1) * n * kDof : nullptr, L,
