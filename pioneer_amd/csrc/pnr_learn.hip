@@ -4,6 +4,7 @@
 // gfx950 only; no CPU fallback.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -374,7 +375,20 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
 #if PNR_MLP_STAMPS
     F.stamps = g_mlp_stamps;
 #endif
-    hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, dim3(kFwdThreads), 0, st, F);
+    if (F.xs_in && kTrainStationary) {
+        // contiguous inputs: the weight-stationary form, one workgroup per CU and net walking the tiles
+        static int cus = 0;                                      // (every GPU of a node is the same part)
+        if (!cus) {
+            int dev = 0, n = 0;
+            HIP_TRY(nullptr, hipGetDevice(&dev));
+            HIP_TRY(nullptr, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            cus = n;
+        }
+        const unsigned per_net = (unsigned)std::max(1, cus / kMlpNets);
+        hipLaunchKernelGGL(mlp_train_kernel, dim3(std::min(tiles.x, per_net), nets), dim3(kFwdThreads), 0, st, F);
+    } else {
+        hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, dim3(kFwdThreads), 0, st, F);
+    }
     if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
         hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
                            s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);

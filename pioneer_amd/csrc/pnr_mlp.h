@@ -57,6 +57,14 @@ static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implem
 #ifndef PNR_MLP_DIAG
 #define PNR_MLP_DIAG 0
 #endif
+#ifndef PNR_MLP_STATIONARY
+#define PNR_MLP_STATIONARY 0      // 1: pnr_mlp_train_step on contiguous inputs runs mlp_train_kernel (weight-stationary; r03f A/B: bit-identical, 58 us
+                                  // against mlp_forward_kernel<true>'s 51 us per 32 768-sample update — kept as the measured alternative)
+#endif
+constexpr bool kTrainStationary = PNR_MLP_STATIONARY != 0;
+#ifndef PNR_MLP_TRAIN_LOOKAHEAD
+#define PNR_MLP_TRAIN_LOOKAHEAD 1     // k-steps between a sample fragment's LDS read and its MFMA in mlp_train_kernel (3: no faster, r03f)
+#endif
 constexpr int kMlpThreads = 256;  // four waves
 // PNR_MLP_STAMPS=1 (a diagnostic variant, tools/mlp_stamps.py): every wave of the fused kernel writes s_memtime at its phase
 // boundaries into a buffer of its own (no output depends on it).  The product build carries none of it.
@@ -165,6 +173,39 @@ __device__ __forceinline__ float tanh_fast(float x)
 {
     const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // 2 log2(e)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// The same for two values, the three non-transcendental steps as packed instructions (v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32:
+// one issue slot for both): per element the roundings of tanh_fast (2 r is exact, so the fused last step changes nothing).
+// The learner kernels are bound by vector-instruction ISSUE (r03f: ~900 vector + 112 transcendental instructions per wave and
+// tile against 84 MFMAs), not by the matrix pipe: every instruction taken out of the epilogues is time.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 tanh_fast2(f32x2 x)
+{
+    const f32x2 t = x * (f32x2){2.885390081777927f, 2.885390081777927f};
+    f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    e = e + (f32x2){1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return __builtin_elementwise_fma(r, (f32x2){-2.0f, -2.0f}, (f32x2){1.0f, 1.0f});
+}
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// tanh of accumulator quad q (four consecutive features of one sample), rounded to bf16
+template <class ACC>
+__device__ __forceinline__ bf16x4_t tanh_quad(const ACC& acc, int q)
+{
+    const f32x2 lo = tanh_fast2((f32x2){acc[4 * q], acc[4 * q + 1]}), hi = tanh_fast2((f32x2){acc[4 * q + 2], acc[4 * q + 3]});
+    return (bf16x4_t){(__bf16)lo[0], (__bf16)lo[1], (__bf16)hi[0], (__bf16)hi[1]};
+}
+// accumulator quad q times tanh' = 1 - h^2 of the stored activations hv, rounded to bf16.  h has 8 significant bits, h * h is
+// exact in float32: the fused 1 - h * h rounds once, like the product-then-subtract it replaces — same bits, half the instructions
+template <class ACC>
+__device__ __forceinline__ bf16x4_t dtanh_quad(const ACC& acc, int q, bf16x4_t hv)
+{
+    const f32x2 h0 = {(float)hv[0], (float)hv[1]}, h1 = {(float)hv[2], (float)hv[3]};
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 d0 = __builtin_elementwise_fma(-h0, h0, one), d1 = __builtin_elementwise_fma(-h1, h1, one);
+    const f32x2 p0 = (f32x2){acc[4 * q], acc[4 * q + 1]} * d0, p1 = (f32x2){acc[4 * q + 2], acc[4 * q + 3]} * d1;
+    return (bf16x4_t){(__bf16)p0[0], (__bf16)p0[1], (__bf16)p1[0], (__bf16)p1[1]};
 }
 
 __device__ __forceinline__ bf16x8 ld_global_bf16x8(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -452,8 +493,10 @@ struct MlpGemm1 {
         for (int p = 0; p < D - 1; ++p)
             if (p < KS) a[p] = ld_global_bf16x8(wa + 512 * p);
     }
+    // init: what every column block's accumulators start from (the bias rows of this wave, the same for every sample), read as
+    // the FIRST MFMA's C operand — 16 copies per column block and product less than accumulators initialised beforehand; or null
     template <class F>
-    __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[kMlpCB], int lane, F&& after_loads)
+    __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[kMlpCB], int lane, F&& after_loads, const f32x16* init = nullptr)
     {
         const int r = lane & 31, h = lane >> 5;
         const __bf16* tb = tile + r * STRIDE + 8 * h;
@@ -472,7 +515,7 @@ struct MlpGemm1 {
             for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
 #pragma unroll
             for (int cb = 0; cb < kMlpCB; ++cb)
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], b[cb], acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], b[cb], (ks == 0 && init) ? *init : acc[cb], 0, 0, 0);
         }
     }
 };
@@ -487,6 +530,92 @@ __device__ __forceinline__ void mlp_store_htile_nt(const __bf16* tile, __bf16* _
         if (row0 + row < n_rows)
             *reinterpret_cast<uint4*>(dst + (row0 + row) * kMlpHid + cc * 8) = *reinterpret_cast<const uint4*>(tile + row * kHS + cc * 8);
     }
+}
+
+// The tile's loss on all 512 threads of the fused kernels: eight lanes per sample, lane d < 6 = action dimension d of the policy head
+// (ppo_policy_sample's arithmetic, its sums over the dimensions as three xor-shuffles inside the group), lane 0 the value head
+// (ppo_value_sample).  hd: the tile's head rows [64][16] float32, gt: its head gradients [64][kGS] bf16 (written here, with the
+// float32 copy to g_head), rl: the parked record (rec_early) — all LDS; wsum [8 waves][4]: the waves' partial loss sums.
+// As one thread per sample on wave 0 the other seven waves waited 4 300 cycles of a tile's 38 000 for it (profiles/r03_d_mlp_stamps.json).
+__device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, long long row0, int tid, const float* hd, __bf16* gt, const float* rl,
+                                              float* wsum, bool rec_early)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    const int sl = tid >> 3, d = tid & 7;                     // sample of the tile, lane of its group
+    const long long b = row0 + sl;
+    const bool live = b < P.B && !(PNR_MLP_DIAG & 256);
+    const float invB = 1.0f / (float)P.B;
+    const long long r = (!rec_early && live && P.idx) ? P.idx[b] : b;
+    float g0 = 0.f, g1 = 0.f;                                 // head-gradient entries d and 6 + d (lanes 6, 7: padding 12 + ..)
+    float s_surr = 0.f, s_vf = 0.f, s_kl = 0.f, s_ent = 0.f;  // the sample's loss terms (meaningful on lane 0 of the group)
+    if (net == 0) {
+        const bool dim = d < kMlpAct;
+        float m = 0.f, raw = 0.f, a = 0.f, m0 = 0.f, l0 = 0.f, adv = 0.f, lp0 = 0.f;
+        if (live) {
+            if (dim) { m = hd[sl * kMlpHead + d]; raw = hd[sl * kMlpHead + kMlpAct + d]; }
+            if (rec_early) {
+                if (dim) { a = rl[sl * 6 + d]; m0 = rl[384 + sl * 6 + d]; l0 = rl[768 + sl * 6 + d]; }
+                adv = rl[1152 + sl]; lp0 = rl[1216 + sl];
+            } else {
+                if (dim) { a = P.rec_actions[r * 6 + d]; m0 = P.rec_mean[r * 6 + d]; l0 = P.rec_log_std[r * 6 + d]; }
+                adv = P.rec_adv[r]; lp0 = P.rec_logp[r];
+            }
+        }
+        const bool pass = raw >= -20.0f && raw <= 2.0f;           // torch.clamp passes the gradient on [min, max]
+        const float ls = fminf(fmaxf(raw, -20.0f), 2.0f);
+        const float si = expf(-ls);
+        const float z = (a - m) * si;
+        const float ivar = si * si;
+        const float dm = m0 - m;
+        const float q = (expf(2.0f * l0) + dm * dm) * ivar;        // (var0 + (m0 - m)^2) / var
+        float lp = dim ? (-0.5f * z * z - ls) : 0.f;
+        float kl = dim ? (ls - l0 + 0.5f * q - 0.5f) : 0.f;
+        float en = dim ? ls : 0.f;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { lp += __shfl_xor(lp, o, 64); kl += __shfl_xor(kl, o, 64); en += __shfl_xor(en, o, 64); }
+        const float logp = lp - 0.5f * 6.0f * 1.8378770664093453f;  // -3 log(2 pi)
+        const float ent = en + 6.0f * 1.4189385332046727f;          // 6 * 0.5 log(2 pi e)
+        const float ratio = expf(logp - lp0);
+        const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
+        const float s1 = adv * ratio, s2 = adv * rc;
+        const float surr = fminf(s1, s2);
+        const bool inrange = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
+        // torch.minimum: the smaller argument takes the gradient, a tie splits it; the clipped branch is constant outside the range
+        float dsurr;
+        if (s1 < s2) dsurr = s1;
+        else if (s1 == s2) dsurr = 0.5f * s1 + (inrange ? 0.5f * s1 : 0.f);
+        else dsurr = inrange ? s1 : 0.f;
+        const float klc = *P.kl_coeff, entc = *P.ent_coeff;
+        if (live && dim) {
+            g0 = (-dsurr * z * si + klc * (-dm * ivar)) * invB;
+            g1 = pass ? (-dsurr * (z * z - 1.0f) + klc * (1.0f - q) - entc) * invB : 0.f;
+        }
+        if (live) { s_surr = -surr; s_kl = kl; s_ent = ent; }
+    } else if (d == 0 && live) {
+        const float vt = rec_early ? rl[1152 + sl] : P.rec_vtarg[r], v0 = rec_early ? rl[1216 + sl] : P.rec_values[r];
+        float dvf;
+        ppo_value_sample(hd[sl * kMlpHead], vt, v0, P.vf_clip, s_vf, dvf);
+        g0 = P.vf_coeff * dvf * invB;
+    }
+    // head gradients: entries d and 6 + d of the sample's row (lanes 6, 7: the zero padding 12 .. 15), float32 for the
+    // weight-gradient kernel, bf16 for this tile's backward products
+    const int e0 = d < kMlpAct ? d : 12 + 2 * (d - 6), e1 = d < kMlpAct ? kMlpAct + d : 13 + 2 * (d - 6);
+    if (b < P.B) {
+        float* gp = P.g_head + ((size_t)net * P.B + b) * kMlpHead;
+        gp[e0] = g0; gp[e1] = g1;
+    }
+    gt[sl * kGS + e0] = (__bf16)g0;
+    gt[sl * kGS + e1] = (__bf16)g1;
+    // the tile's sums: lane 0 of every group, then across the wave's eight samples; the waves' partial sums meet in LDS
+    float sums[4] = {d == 0 ? s_surr : 0.f, d == 0 ? s_vf : 0.f, d == 0 ? s_kl : 0.f, d == 0 ? s_ent : 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x = sums[k];
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
+        sums[k] = x;
+    }
+    if (lane == 0) *reinterpret_cast<f32x4*>(wsum + 4 * w) = (f32x4){sums[0], sums[1], sums[2], sums[3]};
 }
 
 // Forward pass of one 64-sample tile through one net: grid (ceil(B / 64), nets), 512 threads.
@@ -513,13 +642,18 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(b + 32 * w + 8 * k + 4 * h);
     };
-    const auto bias_init = [&](f32x16 (&acc)[kMlpCB], const f32x4 (&q)[4]) {
+    // .. as ONE 16-register value: the first MFMA of each column block reads it as its C operand (MlpGemm1::run's `init`)
+    const auto bias16 = [&](const f32x4 (&q)[4]) {
+        f32x16 b;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
+            for (int j = 0; j < 4; ++j) b[4 * k + j] = q[k][j];
+        return b;
+    };
+    const auto bias_init = [&](f32x16 (&acc)[kMlpCB], const f32x16& b) {       // (timing-only builds that skip a product)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[cb][4 * k + j] = q[k][j];
+        for (int cb = 0; cb < kMlpCB; ++cb) acc[cb] = b;
     };
     // layer 1's bias and first weight fragments do not depend on the tile: requested before anything else
     MLP_STAMP(0);
@@ -630,16 +764,23 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bf16x4 pk;
+                if (PNR_MLP_DIAG & 1) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pk[j] = (__bf16)((PNR_MLP_DIAG & 1) ? acc[cb][4 * q + j] : tanh_fast(acc[cb][4 * q + j]));
+                    for (int j = 0; j < 4; ++j) pk[j] = (__bf16)acc[cb][4 * q + j];
+                } else {
+                    pk = tanh_quad(acc[cb], q);
+                }
                 *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk;
                 if constexpr (FUSED) { if (keep) h1keep[4 * cb + q] = pk; }
             }
     };
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
-    bias_init(acc, bq1);
-    if (!(PNR_MLP_DIAG & 8)) g1.run(xt, acc, lane, [] {});
+    {
+        const f32x16 b16 = bias16(bq1);
+        if (!(PNR_MLP_DIAG & 8)) g1.run(xt, acc, lane, [] {}, &b16);
+        else bias_init(acc, b16);
+    }
     MLP_STAMP(2);                         // layer-1 product issued
     if (!(PNR_MLP_DIAG & 32)) epilogue(true);
     MLP_STAMP(3);                         // layer-1 epilogue
@@ -656,7 +797,8 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
 
     // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it.  The H1 tile leaves for
     // HBM from INSIDE the product, behind its last weight-fragment load, and the tile's record is requested there too
-    bias_init(acc, bq2);
+    const f32x16 b16_2 = bias16(bq2);
+    if (PNR_MLP_DIAG & 4) bias_init(acc, b16_2);
     MlpRecordTile<kFwdThreads> rect;
     const bool rec_early = FUSED && !P.idx && !(PNR_MLP_DIAG & 256);
     if (!(PNR_MLP_DIAG & 4)) g2.run(ht, acc, lane, [&] {
@@ -668,7 +810,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
             }
         }
         if (P.h1 && !(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
-    });
+    }, &b16_2);
     if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
         if (rec_early) rect.park(reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
     }
@@ -757,87 +899,8 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
         mlp_barrier();
         MLP_STAMP(12);                    // barrier before the loss
-        // ---- the tile's loss on all 512 threads: eight lanes per sample, lane d < 6 = action dimension d of the policy head
-        // (ppo_policy_sample's arithmetic, its sums over the dimensions as three xor-shuffles inside the group), lane 0 the
-        // value head (ppo_value_sample).  As one thread per sample on wave 0 the other seven waves waited 4 300 cycles of a
-        // tile's 38 000 for it (profiles/r03_d_mlp_stamps.json).
-        {
-            const int sl = tid >> 3, d = tid & 7;                     // sample of the tile, lane of its group
-            const long long b = row0 + sl;
-            const bool live = b < P.B && !(PNR_MLP_DIAG & 256);
-            const float invB = 1.0f / (float)P.B;
-            const long long r = (!rec_early && live && P.idx) ? P.idx[b] : b;
-            float g0 = 0.f, g1 = 0.f;                                 // head-gradient entries d and 6 + d (lanes 6, 7: padding 12 + ..)
-            float s_surr = 0.f, s_vf = 0.f, s_kl = 0.f, s_ent = 0.f;  // the sample's loss terms (meaningful on lane 0 of the group)
-            if (net == 0) {
-                const bool dim = d < kMlpAct;
-                float m = 0.f, raw = 0.f, a = 0.f, m0 = 0.f, l0 = 0.f, adv = 0.f, lp0 = 0.f;
-                if (live) {
-                    if (dim) { m = hd[sl * kMlpHead + d]; raw = hd[sl * kMlpHead + kMlpAct + d]; }
-                    if (rec_early) {
-                        if (dim) { a = rl[sl * 6 + d]; m0 = rl[384 + sl * 6 + d]; l0 = rl[768 + sl * 6 + d]; }
-                        adv = rl[1152 + sl]; lp0 = rl[1216 + sl];
-                    } else {
-                        if (dim) { a = P.rec_actions[r * 6 + d]; m0 = P.rec_mean[r * 6 + d]; l0 = P.rec_log_std[r * 6 + d]; }
-                        adv = P.rec_adv[r]; lp0 = P.rec_logp[r];
-                    }
-                }
-                const bool pass = raw >= -20.0f && raw <= 2.0f;           // torch.clamp passes the gradient on [min, max]
-                const float ls = fminf(fmaxf(raw, -20.0f), 2.0f);
-                const float si = expf(-ls);
-                const float z = (a - m) * si;
-                const float ivar = si * si;
-                const float dm = m0 - m;
-                const float q = (expf(2.0f * l0) + dm * dm) * ivar;        // (var0 + (m0 - m)^2) / var
-                float lp = dim ? (-0.5f * z * z - ls) : 0.f;
-                float kl = dim ? (ls - l0 + 0.5f * q - 0.5f) : 0.f;
-                float en = dim ? ls : 0.f;
-#pragma unroll
-                for (int o = 1; o < 8; o <<= 1) { lp += __shfl_xor(lp, o, 64); kl += __shfl_xor(kl, o, 64); en += __shfl_xor(en, o, 64); }
-                const float logp = lp - 0.5f * 6.0f * 1.8378770664093453f;  // -3 log(2 pi)
-                const float ent = en + 6.0f * 1.4189385332046727f;          // 6 * 0.5 log(2 pi e)
-                const float ratio = expf(logp - lp0);
-                const float rc = fminf(fmaxf(ratio, 1.0f - P.clip), 1.0f + P.clip);
-                const float s1 = adv * ratio, s2 = adv * rc;
-                const float surr = fminf(s1, s2);
-                const bool inrange = ratio >= 1.0f - P.clip && ratio <= 1.0f + P.clip;
-                // torch.minimum: the smaller argument takes the gradient, a tie splits it; the clipped branch is constant outside the range
-                float dsurr;
-                if (s1 < s2) dsurr = s1;
-                else if (s1 == s2) dsurr = 0.5f * s1 + (inrange ? 0.5f * s1 : 0.f);
-                else dsurr = inrange ? s1 : 0.f;
-                const float klc = *P.kl_coeff, entc = *P.ent_coeff;
-                if (live && dim) {
-                    g0 = (-dsurr * z * si + klc * (-dm * ivar)) * invB;
-                    g1 = pass ? (-dsurr * (z * z - 1.0f) + klc * (1.0f - q) - entc) * invB : 0.f;
-                }
-                if (live) { s_surr = -surr; s_kl = kl; s_ent = ent; }
-            } else if (d == 0 && live) {
-                const float vt = rec_early ? rl[1152 + sl] : P.rec_vtarg[r], v0 = rec_early ? rl[1216 + sl] : P.rec_values[r];
-                float dvf;
-                ppo_value_sample(hd[sl * kMlpHead], vt, v0, P.vf_clip, s_vf, dvf);
-                g0 = P.vf_coeff * dvf * invB;
-            }
-            // head gradients: entries d and 6 + d of the sample's row (lanes 6, 7: the zero padding 12 .. 15), float32 for the
-            // weight-gradient kernel, bf16 for this tile's backward products
-            const int e0 = d < kMlpAct ? d : 12 + 2 * (d - 6), e1 = d < kMlpAct ? kMlpAct + d : 13 + 2 * (d - 6);
-            if (b < P.B) {
-                float* gp = P.g_head + ((size_t)net * P.B + b) * kMlpHead;
-                gp[e0] = g0; gp[e1] = g1;
-            }
-            gt[sl * kGS + e0] = (__bf16)g0;
-            gt[sl * kGS + e1] = (__bf16)g1;
-            // the tile's sums: lane 0 of every group, then across the wave's eight samples; the waves' partial sums meet in LDS
-            float sums[4] = {d == 0 ? s_surr : 0.f, d == 0 ? s_vf : 0.f, d == 0 ? s_kl : 0.f, d == 0 ? s_ent : 0.f};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float x = sums[k];
-#pragma unroll
-                for (int off = 8; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
-                sums[k] = x;
-            }
-            if (lane == 0) *reinterpret_cast<f32x4*>(wsum + 4 * w) = (f32x4){sums[0], sums[1], sums[2], sums[3]};
-        }
+        // ---- the tile's loss on all 512 threads (mlp_tile_loss)
+        mlp_tile_loss(P, net, row0, tid, hd, gt, rl, wsum, rec_early);
         MLP_STAMP(13);                    // loss done
         mlp_barrier();
         MLP_STAMP(14);                    // barrier after the loss
@@ -858,10 +921,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
                 for (int q = 0; q < 4; ++q) {
                     __bf16* at = ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h;
                     const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at);
-                    bf16x4 pk;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float hf = (float)hv[j]; pk[j] = (__bf16)(acc[cb][4 * q + j] * (1.0f - hf * hf)); }
-                    *reinterpret_cast<bf16x4*>(at) = pk;
+                    *reinterpret_cast<bf16x4*>(at) = dtanh_quad(acc[cb], q, hv);
                 }
         };
         const auto zero_acc = [&]() {
@@ -903,17 +963,316 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bf16x4 hv = h1keep[4 * cb + q];
-                bf16x4 pk;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float hf = (float)hv[j]; pk[j] = (__bf16)(acc[cb][4 * q + j] * (1.0f - hf * hf)); }
-                *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk;
+                *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = dtanh_quad(acc[cb], q, h1keep[4 * cb + q]);
             }
         MLP_STAMP(21);
         mlp_barrier();
         if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
         MLP_STAMP(22);                    // end
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fused training tile, WEIGHT-STATIONARY (r03f): grid (G, nets), 512 threads, ONE workgroup per CU that walks the tiles
+// g, g + G, .. of its net.  mlp_forward_kernel<true> streams a tile's 344 KB of weight fragments from L2 while it multiplies
+// (1 KiB per wave and k-step for two MFMAs: the products ran at 1/6 of their MFMA time, paced by those loads — 42 B/clk/CU,
+// the L2 -> CU rate — and two co-resident workgroups were all the overlap 125 registers allowed).  Here a wave keeps ITS
+// 32-row blocks of W1, W2 and W2^T in registers (36 + 64 + 64) for the whole launch: the products read LDS and registers
+// only.  The 160 KB of LDS (one workgroup per CU) buy separate tiles for X, H1, H2 / dZ2 and dZ1 (six barriers per tile
+// instead of ten: no product -> epilogue barrier, nothing is overwritten in place under a reader) and the next tile's input
+// arrives under the last product.  Same arithmetic in the same order as mlp_forward_kernel<true>: the outputs are bit-identical
+// (tests/test_gpu_mlp.py).  Contiguous inputs only (xs_in, no idx: what pnr_mlp_gather prepares once per epoch).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kTrainMiscFloats = kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats + 4 * kFwdWaves + 2 * kMlpHid;
+constexpr int kTrainLdsElems = kMlpBM * kXS + 3 * kMlpBM * kHS + 2 * kTrainMiscFloats + 2 * kMlpHead * kMlpHid;     // + W3 and W3^T
+static_assert(kTrainLdsElems * 2 <= 160 * 1024, "the training tile's LDS fits one CU");
+
+// acc[cb] += A[32 rows of this wave][16 KS] . tile[BM samples][16 KS]^T with the wave's A fragments in registers.  The sample fragments
+// are read one k-step ahead of their MFMAs and the k-steps stay in order (sched_barrier): left alone, the scheduler hoists a whole
+// product's LDS reads (128 registers) above its first MFMA and spills the stationary weights.
+template <int KS, int STRIDE>
+__device__ __forceinline__ void mlp_gemm_regs(const bf16x8 (&a)[KS], const __bf16* tile, f32x16 (&acc)[kMlpCB], int lane)
+{
+    const int r = lane & 31, h = lane >> 5;
+    const __bf16* tb = tile + r * STRIDE + 8 * h;
+    bf16x8 b[2][kMlpCB];
+#pragma unroll
+    for (int cb = 0; cb < kMlpCB; ++cb) b[0][cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb) b[(ks + 1) & 1][cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * (ks + 1));
+        }
+#pragma unroll
+        for (int cb = 0; cb < kMlpCB; ++cb)
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks & 1][cb], acc[cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(kFwdThreads, 2) void mlp_train_kernel(const MlpFwdParams P)
+{
+    static_assert(kMlpBM == 64, "written for 64-sample tiles");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[kTrainLdsElems];
+    __bf16* xt = lds;                                               // [64][144] the tile's input
+    __bf16* h1t = xt + kMlpBM * kXS;                                // [64][256] H1
+    __bf16* h2t = h1t + kMlpBM * kHS;                               // H2, then dZ2 in place (a lane's own quads)
+    __bf16* d1t = h2t + kMlpBM * kHS;                               // dZ1
+    float* hd = reinterpret_cast<float*>(d1t + kMlpBM * kHS);       // [64][16] float32 head rows
+    __bf16* gt = reinterpret_cast<__bf16*>(hd + kMlpBM * kMlpHead); // [64][kGS] bf16 head gradients
+    float* rl = hd + kMlpBM * kMlpHead + kMlpBM * kGS / 2;          // the tile's record
+    float* wsum = rl + kRecLdsFloats;                               // [8 waves][4] loss sums
+    float* bl = wsum + 4 * kFwdWaves;                               // b1 | b2
+    __bf16* w3l = reinterpret_cast<__bf16*>(bl + 2 * kMlpHid);      // W3 and W3^T as they are packed (fragment-native, 8 KB each):
+    __bf16* w3tl = w3l + kMlpHead * kMlpHid;                        // read per tile with no register and no L2 round trip
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int net = blockIdx.y + P.first_net;
+    const long long tiles = (P.B + kMlpBM - 1) / kMlpBM;
+    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    const float* bias = P.bias + net * kBiasElems;
+    const int c = lane & 31, h = lane >> 5;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;   // one optimiser update per launch
+    MLP_STAMP(0);
+
+    // a tile's 18 KB of contiguous input rows: requested into registers, written to LDS when the tile before it is done with xt
+    constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFwdThreads - 1) / kFwdThreads;
+    uint4 xv[kIt];
+    const auto x_load = [&](long long r0, int tid) {
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+            xv[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (ch < kCh && r0 + row < P.B) xv[i] = *reinterpret_cast<const uint4*>(P.xs_in + (r0 + row) * kMlpInPad + cc * 8);
+        }
+    };
+    const auto x_park = [&](int tid) {
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+            if (ch < kCh) *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = xv[i];
+        }
+    };
+    long long t = blockIdx.x;
+    x_load(t * kMlpBM, tid);                                             // the oldest requests: waited for alone
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 2 * kMlpHid / 4) bv = *reinterpret_cast<const f32x4*>(bias + 4 * tid);
+    static_assert(kMlpHead * kMlpHid / 8 == kFwdThreads, "W3, W3^T: one 16-byte piece per thread each");
+    const uint4 w3v0 = *reinterpret_cast<const uint4*>(wp + kOffW3 + 8 * tid), w3v1 = *reinterpret_cast<const uint4*>(wp + kOffW3T + 8 * tid);
+    // W1 streams through the ring as in mlp_forward_kernel (its first fragments requested a product ahead) ..
+    MlpGemm1<kMlpInPad, kXS> g1;
+    g1.prefetch(wp + kOffW1 + w * (kMlpInPad / 16) * 512, lane);
+    // .. this wave's row blocks of W2 and W2^T (fragment-native: k-step ks at ks * 512) stay in registers for every tile of the launch
+    bf16x8 w2f[kMlpHid / 16], w2tf[kMlpHid / 16];
+#pragma unroll
+    for (int ks = 0; ks < kMlpHid / 16; ++ks) w2f[ks] = ld_global_bf16x8(wp + kOffW2 + (w * (kMlpHid / 16) + ks) * 512 + lane * 8);
+#pragma unroll
+    for (int ks = 0; ks < kMlpHid / 16; ++ks) w2tf[ks] = ld_global_bf16x8(wp + kOffW2T + (w * (kMlpHid / 16) + ks) * 512 + lane * 8);
+    x_park(tid);
+    if (tid < 2 * kMlpHid / 4) *reinterpret_cast<f32x4*>(bl + 4 * tid) = bv;
+    *reinterpret_cast<uint4*>(w3l + 8 * tid) = w3v0;
+    *reinterpret_cast<uint4*>(w3tl + 8 * tid) = w3v1;
+    mlp_barrier();
+    MLP_STAMP(1);                                                   // weights, biases and the first input landed
+
+    const f32x4 b3q = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * (lane >> 4));     // the head rows' bias (rows 4 g ..)
+    // ---- the stages of one 32-sample HALF of the tile (column block hb; acc = that half's accumulators)
+    const auto bias_half = [&](f32x16& acc, const float* b) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(b + 32 * w + 8 * k + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * k + j] = q[j];
+        }
+    };
+    // acc += A[32 rows of this wave][256] . tile[32 samples of the half][256]^T, the wave's A fragments in registers, the sample
+    // fragments read one k-step ahead of their MFMA
+    const auto prod_half = [&](const bf16x8 (&a)[kMlpHid / 16], const __bf16* tile, int hb, f32x16& acc) {
+        constexpr int LA = PNR_MLP_TRAIN_LOOKAHEAD;      // k-steps between a sample fragment's LDS read and its MFMA
+        const __bf16* tb = tile + (32 * hb + c) * kHS + 8 * h;
+        bf16x8 b[LA + 1];
+#pragma unroll
+        for (int p = 0; p < LA; ++p) b[p] = *reinterpret_cast<const bf16x8*>(tb + 16 * p);
+#pragma unroll
+        for (int ks = 0; ks < kMlpHid / 16; ++ks) {
+            if (ks + LA < kMlpHid / 16) b[(ks + LA) % (LA + 1)] = *reinterpret_cast<const bf16x8*>(tb + 16 * (ks + LA));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks % (LA + 1)], acc, 0, 0, 0);
+        }
+    };
+    // tanh in registers, each register quad = four consecutive features of one sample -> one ds_write_b64
+    const auto tanh_half = [&](const f32x16& acc, __bf16* tile, int hb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<bf16x4*>(tile + (32 * hb + c) * kHS + 32 * w + 8 * q + 4 * h) = tanh_quad(acc, q);
+        }
+    };
+    // acc * (1 - h^2), h at this lane's own quads of `htile`, the product into `dst` (which may be htile itself)
+    const auto bwd_half = [&](const f32x16& acc, const __bf16* htile, __bf16* dst, int hb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = (32 * hb + c) * kHS + 32 * w + 8 * q + 4 * h;
+            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(htile + o);
+            *reinterpret_cast<bf16x4*>(dst + o) = dtanh_quad(acc, q, hv);
+        }
+    };
+    // head^T [16][16 samples sb ..] = W3 . H2^T + b3 by one wave (16 x 16 x 32 MFMAs, W3's fragments from LDS)
+    const auto head16 = [&](int sb, long long row0) {
+        const int r16 = lane & 15, g = lane >> 4;
+        f32x4 a3 = b3q;
+#pragma unroll
+        for (int ks = 0; ks < kMlpHid / 32; ++ks) {
+            const bf16x8 bq = *reinterpret_cast<const bf16x8*>(h2t + (sb + r16) * kHS + 32 * ks + 8 * g);
+            a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(w3l + 512 * ks + lane * 8), bq, a3, 0, 0, 0);
+        }
+        const long long bb = row0 + sb + r16;
+        if (bb < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + bb) * kMlpHead + 4 * g) = a3;
+        *reinterpret_cast<f32x4*>(hd + (sb + r16) * kMlpHead + 4 * g) = a3;
+    };
+    // dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2: one half
+    const auto dh2_half = [&](f32x16& acc, int hb) {
+        const bf16x8 w3t = *reinterpret_cast<const bf16x8*>(w3tl + w * 512 + lane * 8);
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(gt + (32 * hb + c) * kGS + 8 * h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t, bq, acc, 0, 0, 0);
+        bwd_half(acc, h2t, h2t, hb);
+    };
+    const auto zero_half = [&](f32x16& acc) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    };
+
+    // ---- The tile loop, software-pipelined over the two halves: half 1 runs one slot behind half 0, so that every slot has a
+    // matrix job (a product of one half) and a vector job (an epilogue, the loss, the tile stores of the other half) that share
+    // nothing.  The two waves of a SIMD (w and w + 4) take them in OPPOSITE order — waves 0-3 the product first, waves 4-7 the
+    // vector job first — so the SIMD's matrix pipe and its vector ALU are busy together instead of in turn (as whole-tile phases,
+    // one workgroup per CU, nothing overlapped: 25 400 cycles per tile, profiles/r03_f_train_stamps_phases.json).  One barrier per
+    // slot; a half's rows of a tile are only ever written a slot (and a barrier) after their last reader.
+    //   s1  P1(T, both halves: W1 streams once)   | dZ1 epilogue (T-1, 1)
+    //   s2                                         | tanh1(T, 0); dZ1 store (T-1)
+    //   s3  P2(T, 0)                               | tanh1(T, 1); record request
+    //   s4  P2(T, 1)                               | tanh2(T, 0); H1 store
+    //   s5  head(T, 0) [waves 0, 1]                | tanh2(T, 1); record park
+    //   s6  head(T, 1) [waves 4, 5]                | loss(T, 0) [waves 0-3]; H2 store
+    //   s7  dH2 + dZ2 epilogue (T, 0)              | loss(T, 1) [waves 4-7]
+    //   s8  P5(T, 0) = W2^T . dZ2^T                | dH2 + dZ2 epilogue (T, 1); loss sums; next input + W1 requested
+    //   s9  P5(T, 1)                               | dZ1 epilogue (T, 0); dZ2 store; next input parked
+    const bool mfirst = w < 4;
+#define TRAIN_SLOT(M, V) do { if (mfirst) { M; V; } else { V; M; } } while (0)
+    f32x16 acc0, acc1;
+    bool prev = false;
+    long long prow0 = 0;
+    for (; t < tiles; t += gridDim.x) {
+        const long long row0 = t * kMlpBM, next0 = (t + gridDim.x) * kMlpBM;
+        // the thread id as the loop body sees it: opaque, so that the ~40 per-thread global addresses of a tile (tile stores, record
+        // pieces, input rows) are computed where they are used instead of being hoisted out of the loop — as loop invariants they
+        // took 80 registers from the stationary weights and went to scratch
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+#if PNR_MLP_STAMPS
+        const bool stamped = t == (long long)blockIdx.x + gridDim.x || tiles <= gridDim.x;   // the workgroup's second tile (or its only one)
+#define TRAIN_STAMP(i) do { if (stamped) MLP_STAMP(i); } while (0)
+#else
+#define TRAIN_STAMP(i) do { } while (0)
+#endif
+        TRAIN_STAMP(2);
+        // ---- s1 (the dZ1 epilogue of the tile before reads acc1, which layer 1 then overwrites: it goes first on every wave)
+        if (prev) bwd_half(acc1, h1t, d1t, 1);
+        {
+            f32x16 l1[kMlpCB], b16;
+            bias_half(b16, bl);
+            g1.run(xt, l1, lane, [] {}, &b16);
+            acc0 = l1[0]; acc1 = l1[1];
+        }
+        mlp_barrier();
+        TRAIN_STAMP(3);
+        // ---- s2
+        tanh_half(acc0, h1t, 0);
+        if (prev) mlp_store_htile_nt<kFwdThreads>(d1t, P.dz1 + (size_t)net * P.B * kMlpHid, prow0, P.B, tv);
+        mlp_barrier();
+        TRAIN_STAMP(4);
+        // ---- s3
+        MlpRecordTile<kFwdThreads> rect;
+        {
+            const float* const src[5] = {P.rec_actions, P.rec_mean, P.rec_log_std, net == 0 ? P.rec_adv : P.rec_vtarg, net == 0 ? P.rec_logp : P.rec_values};
+            rect.load(src, net, row0, P.B, tv);
+        }
+        {
+            f32x16 nxt;
+            bias_half(nxt, bl + kMlpHid);
+            TRAIN_SLOT(prod_half(w2f, h1t, 0, nxt), tanh_half(acc1, h1t, 1));
+            acc0 = nxt;
+        }
+        mlp_barrier();
+        TRAIN_STAMP(5);
+        // ---- s4
+        {
+            f32x16 nxt;
+            bias_half(nxt, bl + kMlpHid);
+            TRAIN_SLOT(prod_half(w2f, h1t, 1, nxt), tanh_half(acc0, h2t, 0));
+            acc1 = nxt;
+        }
+        mlp_store_htile_nt<kFwdThreads>(h1t, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tv);
+        mlp_barrier();
+        TRAIN_STAMP(6);
+        // ---- s5
+        if (w < 2) head16(16 * w, row0);
+        tanh_half(acc1, h2t, 1);
+        rect.park(rl, net, tv);
+        mlp_barrier();
+        TRAIN_STAMP(7);
+        // ---- s6
+        if (w == 4 || w == 5) head16(32 + 16 * (w - 4), row0);
+        if (w < 4) mlp_tile_loss(P, net, row0, tv, hd, gt, rl, wsum, true);
+        mlp_store_htile_nt<kFwdThreads>(h2t, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tv);
+        mlp_barrier();
+        TRAIN_STAMP(8);
+        // ---- s7
+        if (w >= 4) mlp_tile_loss(P, net, row0, tv, hd, gt, rl, wsum, true);
+        dh2_half(acc0, 0);
+        mlp_barrier();
+        TRAIN_STAMP(9);
+        // ---- s8
+        if (tv == 0) {                                              // the eight waves' sums in wave order: one row per tile and net
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < kFwdWaves; ++k) s4 += *reinterpret_cast<const f32x4*>(wsum + 4 * k);
+            float* pr = P.partials + ((size_t)t * P.n_nets + blockIdx.y) * 8;
+            *reinterpret_cast<f32x4*>(pr) = s4;
+            *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // (both unconditional: behind an `if (more)` the old values of 32 registers would stay live around the whole loop; past the
+        // batch's end x_load requests nothing and returns zeros)
+        x_load(next0, tv);
+        g1.prefetch(wp + kOffW1 + (tv >> 6) * (kMlpInPad / 16) * 512, tv & 63);
+        {
+            zero_half(acc0);
+            TRAIN_SLOT(prod_half(w2tf, h2t, 0, acc0), dh2_half(acc1, 1));
+        }
+        mlp_barrier();
+        TRAIN_STAMP(10);
+        // ---- s9
+        {
+            f32x16 nxt;
+            zero_half(nxt);
+            TRAIN_SLOT(prod_half(w2tf, h2t, 1, nxt), bwd_half(acc0, h1t, d1t, 0));
+            acc1 = nxt;
+        }
+        mlp_store_htile_nt<kFwdThreads>(h2t, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tv);
+        x_park(tv);
+        mlp_barrier();
+        TRAIN_STAMP(11);
+        prev = true;
+        prow0 = row0;
+    }
+    if (prev) {                                                     // the last tile's second half of dZ1
+        bwd_half(acc1, h1t, d1t, 1);
+        mlp_barrier();
+        mlp_store_htile_nt<kFwdThreads>(d1t, P.dz1 + (size_t)net * P.B * kMlpHid, prow0, P.B, tid);
+    }
+    MLP_STAMP(22);
+#undef TRAIN_STAMP
+#undef TRAIN_SLOT
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -263,7 +263,12 @@ class HipMLP:
         s.clip_param, s.vf_clip_param, s.vf_loss_coeff = float(clip), float(vf_clip), float(vf_coeff)
         s.head, s.g_head = ws["head"].data_ptr(), ws["g"].data_ptr()
         s.xs, s.h1, s.h2, s.dz1, s.dz2 = (ws[k].data_ptr() for k in ("xs", "h1", "h2", "dz1", "dz2"))
-        s.partials, s.partial_rows = ws["partials"].data_ptr(), ws["partials"].shape[0]
+        # one row of loss sums per (tile, net); a one-net call (two-chain mode: the other net's launch may run at the same time on
+        # another stream) gets that net's half of the rows to itself
+        part = ws["partials"]
+        if nets is not None and tuple(nets) == (1, 1):
+            part = part[part.shape[0] // 2:]
+        s.partials, s.partial_rows = part.data_ptr(), part.shape[0]
         s.slabs, s.slab_floats = ws["slabs"].data_ptr(), ws["slabs"].numel()
         s.means = means_out.data_ptr()
         if flat_grad is not None:

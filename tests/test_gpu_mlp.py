@@ -257,11 +257,14 @@ def test_train_step_equals_autograd_plus_torch_adam(B):
     assert torch.equal(w_now, mlp.wpack) and torch.equal(b_now, mlp.bias)         # the refreshed bf16 copies are exact
 
 
-@pytest.mark.parametrize("B", [8192, 4099])
+@pytest.mark.parametrize("B", [8192, 4099, 16421])
 def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
     """pnr_mlp_gather + train_step(xs_in=...) against train_step(obs, idx, filt): the same filter arithmetic and rounding,
     the same record rows, so gradients, loss means and updated weights are bit-identical — on a minibatch that is a slice
-    of a longer gathered epoch (pointer offsets into the gathered arrays)."""
+    of a longer gathered epoch (pointer offsets into the gathered arrays).  In the PNR_MLP_STATIONARY=1 variant
+    (test_weight_stationary_training_kernel_is_bit_identical runs this test on it) the two calls also run two different
+    kernels: mlp_forward_kernel<true> (one workgroup per tile, weights streamed) and mlp_train_kernel (one workgroup per CU
+    walking its tiles — one, a partial last one, or up to three of them at these sizes — with its weights in registers)."""
     import copy
     from pioneer_amd.mlp import HipMLP
     R, lr = 20000, 1e-3
@@ -301,3 +304,22 @@ def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
         mlp.adam(flat, 1.0, lr); mlp_g.adam(flat_g, 1.0, lr)
     for a, b in zip(mlp.params, mlp_g.params):
         assert torch.equal(a, b)
+
+
+def test_weight_stationary_training_kernel_is_bit_identical(tmp_path):
+    """mlp_train_kernel — the weight-stationary, half-tile-pipelined form of the fused learner kernel, kept behind
+    -DPNR_MLP_STATIONARY=1 as the measured alternative (58 us against 51) — produces the same bits as
+    mlp_forward_kernel<true>: the learner translation unit is rebuilt with the switch (seconds) and the comparison above,
+    whose pre-gathered calls then run mlp_train_kernel, is run on that library in a child process."""
+    import os
+    import subprocess
+    import sys
+    from pioneer_amd import _lib
+    out = str(tmp_path / "libpioneer_amd_stationary.so")
+    _lib.build_library(units=("pnr_learn.hip",), extra_flags=["-DPNR_MLP_STATIONARY=1"], out_path=out)
+    env = dict(os.environ, PNR_LIB_PATH=out)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_mlp.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "pre_gathered or graph_replay", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "4 passed" in r.stdout, r.stdout[-1000:]

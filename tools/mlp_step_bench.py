@@ -34,18 +34,38 @@ entc = torch.tensor(0.01, device=dev)
 means = torch.zeros(8, device=dev)
 
 
+CHAINS = os.environ.get("CHAINS", "0") == "1"      # the two nets as two chains on two streams (single GPU, Adam fused per net)
+streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+means2 = torch.zeros(2, 8, device=dev)
+
+
 def step(i):
     s = (i % 16) * B
+    if CHAINS:
+        for net, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                mlp.train_step(None, None, None, {k: g[k][s:s + B] for k in mlp.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means2[net], 2e-5,
+                               xs_in=g["xs"][s:s + B], nets=(net, 1))
+        return
     mlp.train_step(None, None, None, {k: g[k][s:s + B] for k in mlp.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means, 2e-5, xs_in=g["xs"][s:s + B])
 
 
+if CHAINS:
+    mlp.sync_step_counters(True)
 for i in range(20):
     step(i)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
 e0.record()
+if CHAINS:
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
 for i in range(N):
     step(i)
+if CHAINS:
+    for st in streams:
+        torch.cuda.current_stream(dev).wait_stream(st)
+    means = means2.sum(0)
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / N * 1e3
@@ -70,5 +90,6 @@ for _ in range(N):
     act_call()
 e1.record()
 torch.cuda.synchronize()
-print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
+print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "chains": CHAINS, "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
+                  "param_sums": [round(float(p_.double().sum()), 6) for p_ in mlp.params[:2]] + [round(float(p_.double().sum()), 6) for p_ in mlp.params[6:8]],
                   "means_finite": bool(torch.isfinite(means[:5]).all()), "means": [round(float(x), 5) for x in means[:5]]}))
