@@ -194,10 +194,12 @@ class HipMLP:
                                                 self._stream()))
         return self._rec_rows[:R]
 
-    def gather_epoch(self, obs, idx, filt, rec, rec_rows: Optional[torch.Tensor] = None, xs_rows: Optional[torch.Tensor] = None) -> dict:
+    def gather_epoch(self, obs, idx, filt, rec, rec_rows: Optional[torch.Tensor] = None, xs_rows: Optional[torch.Tensor] = None,
+                     slot: int = 0) -> dict:
         """An SGD epoch's shuffle applied ONCE (pnr_mlp_gather): returns {"xs": bf16 [n, 144] — the filtered, rounded net
         inputs of rows ``idx`` —, and the record fields gathered the same way}.  Slices of it feed ``train_step(xs_in=...)``.
-        The buffers live in this object and are overwritten by the next call."""
+        The buffers live in this object (one set per ``slot``: the learner gathers epoch e + 1 into the other set while epoch e's
+        updates read this one) and are overwritten by the next call with the same slot."""
         if xs_rows is not None:       # the sampler's saved net inputs (act(xs_out=...)): copied, nothing is filtered
             assert xs_rows.dtype == torch.bfloat16 and xs_rows.is_contiguous() and xs_rows.shape[1] == 144 and xs_rows.device == self.device
             assert idx.dtype == torch.int64 and idx.is_contiguous()
@@ -206,13 +208,16 @@ class HipMLP:
             self._check_inputs(obs, idx, filt, self.device)
             obs_p, R = _p(obs), obs.shape[0]
         n = int(idx.numel())
-        g = getattr(self, "_gathered", None)
+        sets = getattr(self, "_gathered", None)
+        if sets is None:
+            sets = self._gathered = {}
+        g = sets.get(slot)
         if g is None or g["xs"].shape[0] < n:
             f32 = dict(dtype=torch.float32, device=self.device)
             g = {"xs": torch.empty((n, 144), dtype=torch.bfloat16, device=self.device)}
             for k in self.REC_KEYS:
                 g[k] = torch.empty((n, 6) if k in ("actions", "mean", "log_std") else (n,), **f32)
-            self._gathered = g
+            sets[slot] = g
         f = filt if filt is not None else (None, None, None, None)
         if rec_rows is not None:
             assert rec_rows.dtype == torch.float32 and rec_rows.is_contiguous() and tuple(rec_rows.shape) == (R, 24) and rec_rows.device == self.device

@@ -270,6 +270,7 @@ class PPOLearner:
         self._hip_dirty = True      # the packed bf16 weights are stale (construction, restore)
         self.net_chains = True      # several ranks: the two nets as two SGD chains on two streams (False: one bucket, serial)
         self._net_streams = None
+        self._side = None           # the stream the next epoch's gather runs on (HIP path)
 
     def entropy_coeff(self) -> float:
         frac = min(1.0, self.timesteps_total / max(1, self.cfg.entropy_decay_steps))
@@ -405,8 +406,8 @@ class PPOLearner:
         world = pdist.dist.get_world_size() if multi else 1
         if multi and self._flat_grad is None:
             self._flat_grad = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), dtype=torch.float32, device=dev)
-        if self._perm is None or self._perm.numel() != B:
-            self._perm = torch.empty(B, dtype=torch.int64, device=dev)
+        if self._perm is None or self._perm.shape[1] != B:
+            self._perm = torch.empty((2, B), dtype=torch.int64, device=dev)
         rows = mlp.pack_record(rec, *adv_scalars)
         chains = multi and self.net_chains
         cur = torch.cuda.current_stream(dev)
@@ -419,11 +420,32 @@ class PPOLearner:
             mlp.sync_step_counters(True)
         ge = int(mlp.lib.pnr_mlp_grad_floats()) // 2
         k = 0
-        for _ in range(cfg.num_sgd_iter):
-            # each epoch's shuffle: pnr_permutation keyed by (seed, rank, epoch counter) — one launch, no sort
-            perm = hip_permutation(B, cfg.seed * 1000003 + (pdist.dist.get_rank() if multi else 0), self._epochs, self._perm)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        side = self._side
+
+        def gather(e):
+            # an epoch's shuffle: pnr_permutation keyed by (seed, rank, epoch counter) — one launch, no sort — and its application
+            perm = hip_permutation(B, cfg.seed * 1000003 + (pdist.dist.get_rank() if multi else 0), self._epochs, self._perm[e % 2])
             self._epochs += 1
-            g = mlp.gather_epoch(rec["obs"], perm, filt, None, rec_rows=rows, xs_rows=rec.get("xs"))
+            return mlp.gather_epoch(rec["obs"], perm, filt, None, rec_rows=rows, xs_rows=rec.get("xs"), slot=e % 2)
+
+        nxt, nxt_ready = gather(0), None
+        for e in range(cfg.num_sgd_iter):
+            g = nxt
+            if nxt_ready is not None:
+                cur.wait_event(nxt_ready)
+            if e + 1 < cfg.num_sgd_iter:
+                # The next epoch's gather depends on the rollout and the shuffle, not on the weights: it runs on a side stream
+                # under this epoch's updates, into the other buffer set (whose last readers, epoch e - 1's updates, are already
+                # enqueued on the main stream in front of the event the side stream waits for).  102 us per epoch off the chain.
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    nxt = gather(e + 1)
+                    nxt_ready = torch.cuda.Event()
+                    nxt_ready.record(side)
             if chains:
                 # The two nets share nothing but their input, so each is its own SGD chain on its own stream: fused kernel ->
                 # weight gradients -> all-reduce of ITS half of the bucket -> Adam.  One net's all-reduce (latency-bound: 0.43 MB
