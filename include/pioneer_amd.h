@@ -347,6 +347,21 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
 int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
                 const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
                 float* log_std, float* values, float* actions, float* env_actions, void* xs_out, void* stream);
+/*
+ * The sampler's closed loop as ONE resident launch: T x (pnr_mlp_act, pnr_step) for every env of handle `h` — per step both nets
+ * on the observation in slot t of `obs`, the DiagGaussian draw and clip as in pnr_mlp_act, then BulletEnv.step
+ * (bullet_env.py:192-197) with that action: reward / done / truncated [T][n] and the next observation into slot t + 1.  A
+ * workgroup owns 64 envs for all T steps (env state, observation tile and both nets' W2 stay on the CU).  Replaces the RLlib
+ * rollout worker's act -> env.step loop (the reference: one env per worker process, pioneer_knm_train.py:49) for kinematic-mode
+ * handles with env-major layouts; results equal the per-step calls bit for bit.
+ *   obs [T + 1][n][137]: slot 0 = where the rollout starts (what the last pnr_step / pnr_reset / rollout left), slots 1..T written
+ *   noise [T][n][6] standard-normal draws; a_max [6] or NULL (no clipping); f_loc..f_hi [137] each or all NULL
+ *   mean / log_std / actions [T][n][6] (8-byte aligned), values [T][n], xs_out [T][n][144] bf16 or NULL
+ */
+int pnr_ppo_rollout(pnr_handle h, int32_t T, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
+                    const void* wpack, const float* bias, const float* noise, const float* a_max, float* obs, float* mean,
+                    float* log_std, float* values, float* actions, void* xs_out, float* reward, uint8_t* done, uint8_t* truncated,
+                    void* stream);
 int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, const void* xs, const void* h1, const void* h2,
                      void* dz1, void* dz2, float* slabs, int64_t slab_floats, float* const* grads, int32_t n3_policy,
                      int32_t n3_value, int32_t accumulate, const float* scale, void* stream);

@@ -148,6 +148,7 @@ SIGNATURES = {
     "pnr_filter_merge": (C.c_int, [_VP] * 8),
     "pnr_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _VP, _VP]),
     "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 17),
+    "pnr_ppo_rollout": (C.c_int, [_VP, C.c_int32] + [_VP] * 18),
     "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "pnr_mlp_grad_floats": (C.c_int64, []),
     "pnr_ppo_pack_record": (C.c_int, [C.c_int64] + [_VP] * 11),
@@ -162,7 +163,7 @@ SIGNATURES = {
 # the library's translation units and what each includes: a unit is recompiled when one of its files is newer than its object
 UNITS = {
     "pnr_api.hip": ["pnr_api.hip", "pnr_host.h", "pnr_device.h", "pnr_model.h", "pnr_dyn.h", "pnr_env_kernels.h"],
-    "pnr_learn.hip": ["pnr_learn.hip", "pnr_host.h", "pnr_device.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h"],
+    "pnr_learn.hip": ["pnr_learn.hip", "pnr_host.h", "pnr_device.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h", "pnr_sampler.h"],
 }
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
                "-mllvm", "-amdgpu-kernarg-preload-count=16",      # leading scalar kernel args arrive preloaded in SGPRs

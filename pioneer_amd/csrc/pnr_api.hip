@@ -469,6 +469,25 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     return PNR_OK;
 }
 
+}  // extern "C"
+
+int pnr_env_rollout_params(pnr_handle h, pnr::KParams* out, float* max_v_to_r, int* device)
+{
+    if (!h || !out || !max_v_to_r || !device) return fail(nullptr, PNR_ERR_INVALID, "pnr_ppo_rollout: null handle");
+    if (h->cfg.mode != PNR_MODE_KINEMATIC)
+        return fail(h, PNR_ERR_INVALID, "pnr_ppo_rollout runs kinematic-mode handles (dynamics mode: pnr_mlp_act + pnr_step per step)");
+    if (h->cfg.obs_layout != PNR_ENV_MAJOR || h->cfg.action_layout != PNR_ENV_MAJOR)
+        return fail(h, PNR_ERR_INVALID, "pnr_ppo_rollout needs env-major observations and actions");
+    if (!h->ready) return fail(h, PNR_ERR_INVALID, "pnr_ppo_rollout before the first pnr_reset (or pnr_set_state)");
+    *out = h->base;
+    out->diag = 0;
+    *max_v_to_r = (float)h->cfg.max_v_to_r;
+    *device = h->device;
+    return PNR_OK;
+}
+
+extern "C" {
+
 int pnr_step(pnr_handle h, const float* actions, float* obs, float* reward, uint8_t* done,
              uint8_t* truncated, float* info, void* stream)
 {

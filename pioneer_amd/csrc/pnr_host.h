@@ -18,6 +18,12 @@ __attribute__((visibility("hidden"))) int pnr_failv(char* handle_err, int code, 
             return fail(h, PNR_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
     } while (0)
 
+// pnr_ppo_rollout (pnr_learn.hip) steps a handle's envs from inside its own kernel: the env engine (pnr_api.hip) checks the handle
+// (kinematic mode, env-major layouts, reset done) and hands out its kernel constants (state pointer, counts, reward constants, seed)
+// as a pnr::KParams, plus max_v_to_r and the device.  Returns PNR_OK or the error it recorded in the handle.
+namespace pnr { struct KParams; }
+__attribute__((visibility("hidden"))) int pnr_env_rollout_params(pnr_handle h, pnr::KParams* out, float* max_v_to_r, int* device);
+
 // RAII current-device switch: launches and allocations go to the handle's device.
 struct DeviceGuard {
     int prev = -1; bool switched = false;

@@ -14,6 +14,7 @@
 #include "pnr_device.h"
 #include "pnr_ppo.h"
 #include "pnr_mlp.h"
+#include "pnr_sampler.h"
 
 using namespace pnr;
 
@@ -218,6 +219,36 @@ int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float
     P.xs = static_cast<__bf16*>(xs_out);                     // the nets' input as they saw it, for the learner (or null)
     hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kFwdThreads), 0,
                        (hipStream_t)stream, P);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_ppo_rollout(pnr_handle h, int32_t T, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
+                    const void* wpack, const float* bias, const float* noise, const float* a_max, float* obs, float* mean,
+                    float* log_std, float* values, float* actions, void* xs_out, float* reward, uint8_t* done, uint8_t* truncated,
+                    void* stream)
+{
+    RolloutParams S = {};
+    int device = 0;
+    int rc = pnr_env_rollout_params(h, &S.K, &S.max_v_to_r, &device);
+    if (rc) return rc;
+    const auto hfail = [&](const char* msg) { return fail(nullptr, PNR_ERR_INVALID, "%s", msg); };
+    if (T < 1) return hfail("pnr_ppo_rollout: T must be >= 1");
+    if (!wpack || !bias || !noise || !obs || !mean || !log_std || !values || !actions || !reward || !done)
+        return hfail("pnr_ppo_rollout: null argument");
+    if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
+        return hfail("pnr_ppo_rollout: the four filter vectors come together or not at all");
+    if (reinterpret_cast<uintptr_t>(mean) & 7u || reinterpret_cast<uintptr_t>(log_std) & 7u || reinterpret_cast<uintptr_t>(actions) & 7u)
+        return hfail("pnr_ppo_rollout: mean, log_std and actions must be 8-byte aligned");
+    S.T = T;
+    S.obs0 = obs;
+    S.K.obs = obs + (size_t)S.K.n * kObsDim;                 // slot 1: where step 0 leaves its observation
+    S.K.reward = reward; S.K.done = done; S.K.trunc = truncated; S.K.info = nullptr; S.K.actions = nullptr; S.K.T = T;
+    S.f_loc = f_loc; S.f_inv = f_inv; S.f_lo = f_lo; S.f_hi = f_hi;
+    S.wpack = static_cast<const __bf16*>(wpack); S.bias = bias; S.noise = noise; S.a_max = a_max;
+    S.mean = mean; S.log_std = log_std; S.values = values; S.actions = actions; S.xs = static_cast<__bf16*>(xs_out);
+    DeviceGuard g(device);
+    hipLaunchKernelGGL(ppo_rollout_kernel, dim3((unsigned)((S.K.n + kMlpBM - 1) / kMlpBM)), dim3(kFwdThreads), 0, (hipStream_t)stream, S);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }

@@ -134,6 +134,29 @@ class HipMLP:
                                         _p(a_max), _p(head), _p(mean), _p(log_std), _p(values), _p(actions), _p(env_actions),
                                         _p(xs_out), self._stream()))
 
+    @torch.no_grad()
+    def rollout(self, env, filt, noise: torch.Tensor, a_max: Optional[torch.Tensor], *, obs: torch.Tensor, mean: torch.Tensor,
+                log_std: torch.Tensor, values: torch.Tensor, actions: torch.Tensor, reward: torch.Tensor, done: torch.Tensor,
+                truncated: Optional[torch.Tensor], xs_out: Optional[torch.Tensor] = None) -> None:
+        """The sampler's closed loop for T steps in ONE resident launch (pnr_ppo_rollout): per step both nets on slot t of ``obs``
+        [T + 1, N, 137], the draw and clip of ``act``, and the step of ``env`` (a kinematic-mode PioneerVectorEnv with env-major
+        layouts) with that action — reward / done / truncated [T, N], the next observation into slot t + 1.  Equals T x (act,
+        env.vector_step) bit for bit; the env's state advances as if they had been called."""
+        T, N = int(noise.shape[0]), int(env.num_envs)
+        f = filt if filt is not None else (None, None, None, None)
+        for name, x, shape in (("noise", noise, (T, N, 6)), ("mean", mean, (T, N, 6)), ("log_std", log_std, (T, N, 6)), ("values", values, (T, N)),
+                               ("actions", actions, (T, N, 6)), ("obs", obs, (T + 1, N, 137)), ("reward", reward, (T, N)), ("a_max", a_max, (6,))):
+            if x is not None:
+                assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == shape and x.device == self.device, name
+        for name, x in (("done", done), ("truncated", truncated)):
+            assert x is None or (x.dtype == torch.uint8 and x.is_contiguous() and tuple(x.shape) == (T, N) and x.device == self.device), name
+        for v in f:
+            assert v is None or (v.dtype == torch.float32 and v.is_contiguous() and v.numel() == 137 and v.device == self.device)
+        assert xs_out is None or (xs_out.dtype == torch.bfloat16 and xs_out.is_contiguous() and tuple(xs_out.shape) == (T, N, 144))
+        _lib.check(self.lib.pnr_ppo_rollout(env._h, T, _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(self.wpack), _p(self.bias), _p(noise),
+                                            _p(a_max), _p(obs), _p(mean), _p(log_std), _p(values), _p(actions), _p(xs_out), _p(reward),
+                                            _p(done), _p(truncated), self._stream()))
+
     # -- the learner path -------------------------------------------------------------------------------------
     def apply(self, obs: torch.Tensor, idx: Optional[torch.Tensor] = None, filt=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """(head_policy [B, 16], head_value [B, 16]) with autograd through the HIP backward kernels.  Packs the

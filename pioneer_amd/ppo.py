@@ -514,6 +514,10 @@ class PPOTrainer:
         self.a_max = torch.from_numpy(env.a_max).to(self.device)
         self.iteration = 0
         self.use_graph = bool(use_graph) and self.hip
+        # kinematic mode with env-major layouts: the sampler's T steps are one resident launch (dynamics mode keeps the per-step
+        # pnr_mlp_act + pnr_step pair); False forces the per-step form (the A/B and the equality test)
+        ec = env.engine_config
+        self.resident_rollout = self.hip and ec.mode == "kinematic" and ec.obs_layout == "env_major" and ec.action_layout == "env_major"
         self._graph = None
         T, N, D, A = self.cfg.rollout_fragment_length, env.num_envs, self.cfg.obs_dim, self.cfg.act_dim
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -572,7 +576,12 @@ class PPOTrainer:
         if self.hip:
             mlp, filt = self.sample_mlp, self._filt()
             mlp.pack()
-            for t in range(T):
+            if self.resident_rollout:
+                # the whole closed loop in ONE launch: a workgroup owns 64 envs for all T steps (pnr_ppo_rollout)
+                mlp.rollout(self.env, filt, noise, self.a_max if clip else None, obs=self.raw_in, mean=buf["mean"], log_std=buf["log_std"],
+                            values=buf["values"], actions=buf["actions"], reward=buf["reward"], done=buf["done"], truncated=buf["trunc"],
+                            xs_out=buf["xs"])
+            for t in range(0 if not self.resident_rollout else T, T):
                 mlp.act(self.raw_in[t], filt, noise[t], self.a_max if clip else None, mean=buf["mean"][t], log_std=buf["log_std"][t],
                         values=buf["values"][t], actions=buf["actions"][t], env_actions=self._env_act if clip else None,
                         xs_out=buf["xs"][t])

@@ -73,6 +73,32 @@ def test_hip_trainer_learns_the_reach_task_at_the_contract_batching(use_graph):
     env.close()
 
 
+@pytest.mark.parametrize("n_envs,max_steps", [(4096, 25), (1000, 7)])
+def test_resident_rollout_equals_the_two_launch_sampler(n_envs, max_steps):
+    """pnr_ppo_rollout (the sampler's T steps as ONE resident launch: a workgroup owns 64 envs, both nets' W2 and the env state
+    stay on the CU) against T x (pnr_mlp_act, pnr_step): every buffer of the rollout — observations, actions, means, log-stds,
+    values, rewards, flags, the nets' saved inputs, advantages — the env state and, after the update, the weights are identical
+    over three iterations, with episodes ending (auto-reset) inside the rollouts and a last workgroup that is only partly full."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    from pioneer_amd.ppo import PPOConfig, PPOTrainer
+    cfg = PPOConfig(rollout_fragment_length=16, num_sgd_iter=2, sgd_minibatch_size=n_envs * 4, lr=3e-4, seed=4)
+    mk = lambda: PioneerVectorEnv(n_envs, device="cuda:0", seed=9, engine_config=EngineConfig(max_episode_steps=max_steps))   # noqa: E731
+    a, b = PPOTrainer(mk(), cfg), PPOTrainer(mk(), cfg)
+    assert a.resident_rollout
+    b.resident_rollout = False
+    for it in range(3):
+        ra, rb = a.train(), b.train()
+        assert torch.equal(a.raw_in, b.raw_in), it
+        for k in a.buf:
+            assert torch.equal(a.buf[k], b.buf[k]), (it, k)
+        assert torch.equal(a.env.get_state(), b.env.get_state()), it
+        assert ra["episodes_this_iter"] == rb["episodes_this_iter"]
+    assert ra["episodes_total"] == rb["episodes_total"] and ra["episodes_total"] >= n_envs       # every env was cut and re-drawn at least once
+    flat = lambda t: torch.cat([p.detach().reshape(-1) for p in t.learner.model.parameters()])   # noqa: E731
+    assert torch.equal(flat(a), flat(b))
+    a.env.close(); b.env.close()
+
+
 def test_hip_trainer_restore_continues_bit_identically(tmp_path):
     """save -> restore(restore_env=True) into a FRESH trainer -> the next iteration equals the uninterrupted run bit for
     bit: master weights, Adam's moments and update count (`hip_adam`), the shuffle's epoch counter, filter, KL coefficient,
