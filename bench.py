@@ -602,6 +602,8 @@ def run_rank(args):
         barrier()
         tp = max_over_ranks(time.perf_counter() - tp)
         graphed = {"sampling": tr._graph is not None,
+                   "sampler": ("pnr_ppo_rollout: the T-step closed loop (both nets, action draw, env step) as one resident launch"
+                               if getattr(tr, "resident_rollout", False) else "pnr_mlp_act + pnr_step per step"),
                    "learner": ("hip kernels: pnr_mlp_train_step, 3 launches per update, no graph needed" if tr.learner.hip
                                else "torch autograd, eager"),
                    "learner_split_around_allreduce": bool(tr.learner.hip and world > 1)}

@@ -16,6 +16,13 @@
 #include "pnr_device.h"
 #include "pnr_mlp.h"
 
+#ifndef PNR_ROLL_HOOKS
+#define PNR_ROLL_HOOKS 1          // 1: the step's global stores are issued from inside the layer-1 products (0: where they arise; the A/B)
+#endif
+#ifndef PNR_ROLL_DIAG
+#define PNR_ROLL_DIAG 0           // timing-only ablations of ppo_rollout_kernel (variant builds; results are wrong when set): 1 no next-input
+#endif                            // construction, 2 no xs store, 4 no env step, 8 no value net, 16 no policy head / draw
+
 namespace pnr {
 
 struct RolloutParams {
@@ -97,11 +104,15 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
     constexpr int TPR = kFwdThreads / kMlpBM, CPT = kMlpInPad / TPR;
     static_assert(CPT == 18, "18 columns per thread");
     const auto make_x = [&](const float* row_ptr, bool live, int row, int part) {
+        // (every load unconditional, from an address that exists — the padding columns re-read column 136 — and masked afterwards:
+        // a load under a per-element condition becomes a branch with its own s_waitcnt, i.e. 18 round trips in a row)
         float x[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) x[j] = row_ptr[CPT * part + j < kMlpIn ? CPT * part + j : kMlpIn - 1];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int col = CPT * part + j;
-            float y = (live && col < kMlpIn) ? row_ptr[col] : 0.f;
+            float y = x[j];
             if (filt) y = fminf(fmaxf((y - fv[col]) * fv[kMlpInPad + col], fv[2 * kMlpInPad + col]), fv[3 * kMlpInPad + col]);
             x[j] = (live && col < kMlpIn) ? y : 0.f;
         }
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
     {
         const int row = tid / TPR, part = tid % TPR;
         const bool live = e0 + row < n;
-        make_x(S.obs0 + (live ? e0 + row : 0) * kMlpIn, live, row, part);
+        make_x(S.obs0 + (live ? e0 + row : e0) * kMlpIn, live, row, part);
     }
     mlp_barrier();
 
@@ -139,11 +150,14 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
             }
     };
     // layers 1 and 2 of one net on the tile in xt: H2 in h2t, behind a barrier
-    const auto hidden_layers = [&](int net, const bf16x8 (&w2)[kMlpHid / 16], const __bf16* next_w1) {
+    // (`hook` runs inside layer 1's product, right behind its last weight-fragment request: where this step's global STORES go — a
+    // wave's vector-memory operations retire in order, so a fragment requested behind a store waits for that store's acknowledgement
+    // from HBM, ~2 us per step as first written: profiles/r03_g_rollout_ablation.json)
+    const auto hidden_layers = [&](int net, const bf16x8 (&w2)[kMlpHid / 16], const __bf16* next_w1, auto&& hook) {
         f32x16 acc[kMlpCB];
         {
             const f32x16 b16 = bias16(bl + net * kBiasElems);
-            g1.run(xt, acc, lane, [] {}, &b16);
+            g1.run(xt, acc, lane, hook, &b16);
         }
         g1.prefetch(next_w1, lane);                                   // the ring is free: the next forward's first fragments
         tanh_tile(acc, h1t);
@@ -188,16 +202,30 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
         int tv = tid;
         asm volatile("" : "+v"(tv));
         const long long tn = (long long)t * n;
-        if (S.xs) {                                                   // the nets' input as they see it, for the learner
-            for (int ch = tv; ch < kMlpBM * (kMlpInPad / 8); ch += kFwdThreads) {
-                const int row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                if (e0 + row < n)
-                    *reinterpret_cast<uint4*>(S.xs + (tn + e0 + row) * kMlpInPad + cc * 8) = *reinterpret_cast<const uint4*>(xt + row * kXS + cc * 8);
+        const auto xs_store = [&] {
+            if (S.xs && !(PNR_ROLL_DIAG & 2)) {                           // the nets' input as they see it, for the learner: 1 152 16-byte pieces
+                constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFwdThreads - 1) / kFwdThreads;
+                uint4 v[kIt];
+    #pragma unroll
+                for (int i = 0; i < kIt; ++i) {
+                    const int ch = tv + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                    if (ch < kCh) v[i] = *reinterpret_cast<const uint4*>(xt + row * kXS + cc * 8);
+                }
+    #pragma unroll
+                for (int i = 0; i < kIt; ++i) {
+                    const int ch = tv + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                    if (ch < kCh && e0 + row < n) *reinterpret_cast<uint4*>(S.xs + (tn + e0 + row) * kMlpInPad + cc * 8) = v[i];
+                }
             }
-        }
+        };
         // ---- policy net, the DiagGaussian draw in its head's epilogue (mlp_forward_kernel<false>'s, to the letter)
-        hidden_layers(0, w2p, S.wpack + kPackElems + kOffW1 + (tv >> 6) * (kMlpInPad / 16) * 512);
-        if (w < 4) {
+        if (!PNR_ROLL_HOOKS) xs_store();
+        hidden_layers(0, w2p, S.wpack + kPackElems + kOffW1 + (tv >> 6) * (kMlpInPad / 16) * 512, [&] { if (PNR_ROLL_HOOKS) xs_store(); });
+        // the head's outputs wait in registers for the value net's layer-1 hook (pm / pa: what this lane stores to mean | log_std / actions)
+        f32x4 pm = {0.f, 0.f, 0.f, 0.f}, pa = pm;
+        size_t po = 0;
+        bool plive = false;
+        if (w < 4 && !(PNR_ROLL_DIAG & 16)) {
             const f32x4 hq = head16(0);
             const int r16 = lane & 15, g = lane >> 4;
             const long long b = e0 + 16 * w + r16;
@@ -210,39 +238,53 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
             if (g <= 2) {
                 const bool live = b < n;
                 const size_t o = (size_t)(tn + (live ? b : 0)) * kMlpAct;
-                typedef float f32x2s __attribute__((ext_vector_type(2)));
-                const auto st2 = [&](float* dst, float x, float y) { if (live) *reinterpret_cast<f32x2s*>(dst) = (f32x2s){x, y}; };
                 const auto draw = [&](int j, float m, float l, float& a, float& e) {
                     a = fmaf(expf(l), live ? S.noise[o + j] : 0.f, m);
                     e = S.a_max ? fminf(fmaxf(a, -S.a_max[j]), S.a_max[j]) : a;
                 };
                 float* al = actl + (16 * w + r16) * 8;
+                plive = live; po = o;
                 if (g == 0) {
                     float a[4], e[4];
                     draw(0, hq[0], l0, a[0], e[0]); draw(1, hq[1], l1, a[1], e[1]);
                     draw(2, hq[2], l2, a[2], e[2]); draw(3, hq[3], l3, a[3], e[3]);
-                    st2(S.mean + o, hq[0], hq[1]); st2(S.mean + o + 2, hq[2], hq[3]);
-                    st2(S.actions + o, a[0], a[1]); st2(S.actions + o + 2, a[2], a[3]);
+                    pm = hq; pa = (f32x4){a[0], a[1], a[2], a[3]};
                     *reinterpret_cast<f32x4*>(al) = (f32x4){e[0], e[1], e[2], e[3]};
                 } else if (g == 1) {
                     float a[2], e[2];
                     draw(4, hq[0], l4, a[0], e[0]); draw(5, hq[1], l5, a[1], e[1]);
-                    st2(S.mean + o + 4, hq[0], hq[1]);
-                    st2(S.actions + o + 4, a[0], a[1]);
-                    st2(S.log_std + o, ls(hq[2]), ls(hq[3]));
+                    pm = (f32x4){hq[0], hq[1], ls(hq[2]), ls(hq[3])}; pa = (f32x4){a[0], a[1], 0.f, 0.f};
                     al[4] = e[0]; al[5] = e[1];
                 } else {
-                    st2(S.log_std + o + 2, ls(hq[0]), ls(hq[1])); st2(S.log_std + o + 4, ls(hq[2]), ls(hq[3]));
+                    pm = (f32x4){ls(hq[0]), ls(hq[1]), ls(hq[2]), ls(hq[3])};
                 }
             }
         }
+        const auto head_store = [&] {
+            if (w < 4 && plive) {
+                const int g = lane >> 4;
+                typedef float f32x2s __attribute__((ext_vector_type(2)));
+                const auto st2 = [&](float* dst, float x, float y) { *reinterpret_cast<f32x2s*>(dst) = (f32x2s){x, y}; };
+                if (g == 0) {
+                    st2(S.mean + po, pm[0], pm[1]); st2(S.mean + po + 2, pm[2], pm[3]);
+                    st2(S.actions + po, pa[0], pa[1]); st2(S.actions + po + 2, pa[2], pa[3]);
+                } else if (g == 1) {
+                    st2(S.mean + po + 4, pm[0], pm[1]);
+                    st2(S.actions + po + 4, pa[0], pa[1]);
+                    st2(S.log_std + po, pm[2], pm[3]);
+                } else if (g == 2) {
+                    st2(S.log_std + po + 2, pm[0], pm[1]); st2(S.log_std + po + 4, pm[2], pm[3]);
+                }
+            }
+        };
         // ---- value net
-        hidden_layers(1, w2v, S.wpack + kOffW1 + (tv >> 6) * (kMlpInPad / 16) * 512);
+        if (!PNR_ROLL_HOOKS || (PNR_ROLL_DIAG & 8)) head_store();
+        if (!(PNR_ROLL_DIAG & 8)) hidden_layers(1, w2v, S.wpack + kOffW1 + (tv >> 6) * (kMlpInPad / 16) * 512, [&] { if (PNR_ROLL_HOOKS) head_store(); });
         if (w < 4) {
             const f32x4 hq = head16(1);
             const long long b = e0 + 16 * w + (lane & 15);
             if (b < n && (lane >> 4) == 0) S.values[tn + b] = hq[0];
-        } else if (env_wave) {
+        } else if (env_wave && !(PNR_ROLL_DIAG & 4)) {
             // ---- the env step of this wave's 32 envs (step_kernel's loop body: BulletEnv.step, bullet_env.py:192-197), lane pair per env
             const int p = lane & 1, el = lane >> 1;
             const long long tile0 = e0 + kEnvsPerWave * wv, e = tile0 + el;
@@ -297,10 +339,36 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
             if (nvalid > 0) flush_tile(tile, S.K.obs + (tn + tile0) * kObsDim, nvalid, lane);
         }
         mlp_barrier();                                                // the observation tiles are complete
-        // ---- the next step's input, from the tiles
-        {
-            const int row = tv / TPR, part = tv % TPR;
-            make_x(ot + (row >> 5) * kTileFloats + (row & 31) * kObsDim, e0 + row < n, row, part);
+        // ---- the next step's input, from the tiles: thread = (column quad, group of eight rows) — the filter vectors of its four
+        // columns are read once (16-byte LDS reads), the tile entries one by one (a row starts on a 4-byte boundary only)
+        if (tv < (kMlpInPad / 4) * 8 && !(PNR_ROLL_DIAG & 1)) {
+            const int cq = tv % (kMlpInPad / 4), rg = tv / (kMlpInPad / 4), col = 4 * cq;
+            f32x4 loc = {0.f, 0.f, 0.f, 0.f}, inv = loc, lo = loc, hi = loc;
+            if (filt) {
+                loc = *reinterpret_cast<const f32x4*>(fv + col); inv = *reinterpret_cast<const f32x4*>(fv + kMlpInPad + col);
+                lo = *reinterpret_cast<const f32x4*>(fv + 2 * kMlpInPad + col); hi = *reinterpret_cast<const f32x4*>(fv + 3 * kMlpInPad + col);
+            }
+            // (loads unconditional and all in flight before the first use; columns 137.. re-read column 136 and are masked)
+            float raw[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* src = ot + ((8 * rg + k) >> 5) * kTileFloats + ((8 * rg + k) & 31) * kObsDim;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[k][j] = src[col + j < kMlpIn ? col + j : kMlpIn - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int row = 8 * rg + k;
+                const bool live = e0 + row < n;
+                bf16x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float y = raw[k][j];
+                    if (filt) y = fminf(fmaxf((y - loc[j]) * inv[j], lo[j]), hi[j]);
+                    pk[j] = (__bf16)((live && col + j < kMlpIn) ? y : 0.f);
+                }
+                *reinterpret_cast<bf16x4*>(xt + row * kXS + col) = pk;
+            }
         }
         mlp_barrier();
     }

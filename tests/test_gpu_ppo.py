@@ -73,15 +73,16 @@ def test_hip_trainer_learns_the_reach_task_at_the_contract_batching(use_graph):
     env.close()
 
 
-@pytest.mark.parametrize("n_envs,max_steps", [(4096, 25), (1000, 7)])
-def test_resident_rollout_equals_the_two_launch_sampler(n_envs, max_steps):
+@pytest.mark.parametrize("n_envs,max_steps,plain", [(4096, 25, False), (1000, 7, False), (777, 5, True)])
+def test_resident_rollout_equals_the_two_launch_sampler(n_envs, max_steps, plain):
     """pnr_ppo_rollout (the sampler's T steps as ONE resident launch: a workgroup owns 64 envs, both nets' W2 and the env state
     stay on the CU) against T x (pnr_mlp_act, pnr_step): every buffer of the rollout — observations, actions, means, log-stds,
     values, rewards, flags, the nets' saved inputs, advantages — the env state and, after the update, the weights are identical
     over three iterations, with episodes ending (auto-reset) inside the rollouts and a last workgroup that is only partly full."""
     from pioneer_amd import PioneerVectorEnv, EngineConfig
     from pioneer_amd.ppo import PPOConfig, PPOTrainer
-    cfg = PPOConfig(rollout_fragment_length=16, num_sgd_iter=2, sgd_minibatch_size=n_envs * 4, lr=3e-4, seed=4)
+    cfg = PPOConfig(rollout_fragment_length=16, num_sgd_iter=2, sgd_minibatch_size=n_envs * 4, lr=3e-4, seed=4,
+                    **(dict(observation_filter="NoFilter", clip_actions=False) if plain else {}))      # plain: no filter vectors, no a_max
     mk = lambda: PioneerVectorEnv(n_envs, device="cuda:0", seed=9, engine_config=EngineConfig(max_episode_steps=max_steps))   # noqa: E731
     a, b = PPOTrainer(mk(), cfg), PPOTrainer(mk(), cfg)
     assert a.resident_rollout
