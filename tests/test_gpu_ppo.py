@@ -100,6 +100,39 @@ def test_resident_rollout_equals_the_two_launch_sampler(n_envs, max_steps, plain
     a.env.close(); b.env.close()
 
 
+def test_resident_rollout_refuses_what_it_does_not_implement():
+    """pnr_ppo_rollout is the kinematic, env-major form: a dynamics-mode or feature-major handle, a handle that was never reset and
+    T < 1 are reported as errors (PnrError) instead of being run; the trainer falls back to the per-step pair by itself."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig, SimulationConfig, _lib
+    from pioneer_amd.mlp import HipMLP
+    from pioneer_amd.ppo import ActorCritic, PPOConfig, PPOTrainer
+    dev = torch.device("cuda:0")
+    N, T = 128, 2
+    mlp = HipMLP(ActorCritic(PPOConfig()).to(dev), N, dev)
+    mlp.pack()
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)   # noqa: E731
+    def call(env, T=T):
+        mlp.rollout(env, None, z(T, N, 6), None, obs=z(T + 1, N, 137), mean=z(T, N, 6), log_std=z(T, N, 6), values=z(T, N),
+                    actions=z(T, N, 6), reward=z(T, N), done=z(T, N, dt=torch.uint8), truncated=z(T, N, dt=torch.uint8))
+    dyn = PioneerVectorEnv(N, device=dev, seed=0, simulation_config=SimulationConfig(gravity=9.81), engine_config=EngineConfig(mode="dynamic"))
+    dyn.reset()
+    with pytest.raises(_lib.PnrError, match="kinematic"):
+        call(dyn)
+    fm = PioneerVectorEnv(N, device=dev, seed=0, engine_config=EngineConfig(obs_layout="feature_major"))
+    fm.reset()
+    with pytest.raises(_lib.PnrError, match="env-major"):
+        call(fm)
+    fresh = PioneerVectorEnv(N, device=dev, seed=0)
+    with pytest.raises(_lib.PnrError, match="before the first pnr_reset"):
+        call(fresh)
+    fresh.reset()
+    call(fresh)                                                  # and the plain case runs
+    torch.cuda.synchronize()
+    assert not PPOTrainer(dyn, PPOConfig(rollout_fragment_length=2, sgd_minibatch_size=N)).resident_rollout
+    for e in (dyn, fm, fresh):
+        e.close()
+
+
 def test_hip_trainer_restore_continues_bit_identically(tmp_path):
     """save -> restore(restore_env=True) into a FRESH trainer -> the next iteration equals the uninterrupted run bit for
     bit: master weights, Adam's moments and update count (`hip_adam`), the shuffle's epoch counter, filter, KL coefficient,
