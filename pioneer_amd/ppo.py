@@ -492,11 +492,12 @@ _CAPTURE_MODE = "thread_local"
 class PPOTrainer:
     """Rollout + learn loop over a PioneerVectorEnv shard (one process per GPU).
 
-    With the reference's nets (``PPOLearner.hip``) everything runs on the hand-written kernels: per sampler step TWO
-    launches — pnr_mlp_act (both nets on the RAW observation the env kernel left in the rollout buffer, the
-    MeanStdFilter applied on load, the action draw and clip in the policy net's epilogue) and pnr_step — then one
-    pnr_ppo_gae launch for log-probs, GAE and the episode statistics; ``use_graph=True`` replays that whole T-step loop
-    from ONE hipGraph after an eager warm-up iteration.  The torch formulation (``hip_kernels=False`` or other net
+    With the reference's nets (``PPOLearner.hip``) everything runs on the hand-written kernels.  Kinematic mode: the
+    sampler's T steps are ONE resident launch (pnr_ppo_rollout: a workgroup owns 64 envs — both nets on the RAW
+    observation, the MeanStdFilter applied on load, the action draw and clip in the policy net's epilogue, the env step
+    — for the whole rollout); dynamics mode: per step two launches, pnr_mlp_act and pnr_step, with the same arithmetic.
+    Then one pnr_ppo_gae launch for log-probs, GAE and the episode statistics; ``use_graph=True`` replays the whole
+    sampling phase from ONE hipGraph after an eager warm-up iteration.  The torch formulation (``hip_kernels=False`` or other net
     shapes) samples eagerly with float32 torch ops."""
 
     def __init__(self, env, cfg: Optional[PPOConfig] = None, use_graph: bool = False):
