@@ -146,6 +146,7 @@ SIGNATURES = {
     "pnr_filter_moments_scratch": (C.c_int64, [C.c_int64]),
     "pnr_filter_moments": (C.c_int, [C.c_int64, _VP, _VP, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     "pnr_filter_merge": (C.c_int, [_VP] * 8),
+    "pnr_filter_prepare": (C.c_int, [_VP, _VP, _VP, C.c_double, _VP, _VP, _VP, _VP, _VP]),
     "pnr_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _VP, _VP]),
     "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 17),
     "pnr_ppo_rollout": (C.c_int, [_VP, C.c_int32] + [_VP] * 18),

@@ -187,6 +187,15 @@ int pnr_filter_merge(double* dn, double* dsum, double* dsq, const float* pivot, 
     return PNR_OK;
 }
 
+int pnr_filter_prepare(const double* n, const double* mean, const double* m2, double clip, float* loc, float* inv, float* lo, float* hi,
+                       void* stream)
+{
+    if (!n || !mean || !m2 || !loc || !inv || !lo || !hi) return fail(nullptr, PNR_ERR_INVALID, "pnr_filter_prepare: null argument");
+    hipLaunchKernelGGL(filter_prepare_kernel, dim3(1), dim3(kFmThreads), 0, (hipStream_t)stream, n, mean, m2, clip, loc, inv, lo, hi);
+    HIP_TRY(nullptr, hipGetLastError());
+    return PNR_OK;
+}
+
 int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, void* stream)
 {
     if (n < 1 || !out) return fail(nullptr, PNR_ERR_INVALID, "pnr_permutation: null argument or n < 1");

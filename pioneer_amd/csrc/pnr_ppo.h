@@ -511,4 +511,25 @@ __global__ __launch_bounds__(kFmThreads) void filter_merge_kernel(double* __rest
     if (c == 0) { *n_p = n + dn_r; *dn_p = 0.0; }
 }
 
+// MeanStdFilter.prepare(): the vectors the kernels filter with — x' = clamp((x - loc) * inv, lo, hi) — from the running statistics:
+// loc = mean, inv = 1 / (std + 1e-8) with std = sqrt(max(m2 / max(n - 1, 1), 0)), hi = clip (or +inf), lo = -hi; the identity
+// (0, 1, -inf, +inf) until two samples exist.  float64 like the torch formulation it replaces (17 element-wise launches), rounded to
+// float32 once: the same bits.
+__global__ __launch_bounds__(kFmThreads) void filter_prepare_kernel(const double* __restrict__ n_p, const double* __restrict__ mean,
+                                                                   const double* __restrict__ m2, double clip, float* __restrict__ loc,
+                                                                   float* __restrict__ inv, float* __restrict__ lo, float* __restrict__ hi)
+{
+    const int c = threadIdx.x;
+    if (c >= kFmCols) return;
+    const double n = *n_p;
+    const bool ident = n < 2.0;
+    const double var = m2[c] / fmax(n - 1.0, 1.0);
+    const double sd = sqrt(fmax(var, 0.0));
+    const float h = ident ? __builtin_inff() : (float)clip;
+    loc[c] = ident ? 0.f : (float)mean[c];
+    inv[c] = ident ? 1.f : (float)(1.0 / (sd + 1e-8));
+    hi[c] = h;
+    lo[c] = -h;
+}
+
 }  // namespace pnr

@@ -546,3 +546,31 @@ def test_filter_merge_kernel_equals_the_host_formulation_bit_for_bit(monkeypatch
         assert torch.equal(a.n, b.n) and torch.equal(a.mean, b.mean) and torch.equal(a.m2, b.m2)
         assert float(a._dn) == 0.0 and not bool(a._dsum.any()) and not bool(a._dsq.any())
     assert bool((a.std[18:54] == 0).all())
+
+
+@pytest.mark.parametrize("clip", [10.0, 0.0])
+def test_filter_prepare_kernel_equals_the_host_formulation_bit_for_bit(clip):
+    """MeanStdFilter.prepare() through pnr_filter_prepare against the element-wise float64 formulation it replaces: the identity
+    before two samples exist, then mean / 1 / (std + 1e-8) / +-clip (or +-inf) rounded to float32 once — constant columns (std 0) included."""
+    from pioneer_amd.ppo import MeanStdFilter
+    dev = torch.device("cuda", 0)
+    f = MeanStdFilter(137, dev, clip=clip)
+
+    def expected():
+        ident = f.n < 2
+        c = clip if clip else float("inf")
+        loc = torch.where(ident, torch.zeros_like(f.mean), f.mean).float()
+        inv = torch.where(ident, torch.ones_like(f.mean), 1.0 / (f.std + 1e-8)).float()
+        hi = torch.where(ident, torch.full_like(f.mean, float("inf")), torch.full_like(f.mean, c)).float()
+        return loc, inv, -hi, hi
+
+    g = torch.Generator(device=dev).manual_seed(3)
+    for it in range(3):
+        f.prepare()
+        for got, want in zip((f._loc, f._inv, f._lo, f._hi), expected()):
+            assert torch.equal(got, want), it
+        x = torch.randn(2048, 137, generator=g, device=dev) * (0.01 + it) + 3.0 * it
+        x[:, 18:54] = -0.75
+        f.observe(x); f.sync()
+    f.prepare()
+    assert bool((f._inv[18:54] == 1e8).all()) and float(f._loc[20]) == -0.75
