@@ -73,7 +73,7 @@ def test_hip_trainer_learns_the_reach_task_at_the_contract_batching(use_graph):
     env.close()
 
 
-@pytest.mark.parametrize("n_envs,max_steps,plain", [(4096, 25, False), (1000, 7, False), (777, 5, True)])
+@pytest.mark.parametrize("n_envs,max_steps,plain", [(4096, 25, False), (1000, 7, False), (777, 5, True), (65, 4, False), (1, 3, False)])
 def test_resident_rollout_equals_the_two_launch_sampler(n_envs, max_steps, plain):
     """pnr_ppo_rollout (the sampler's T steps as ONE resident launch: a workgroup owns 64 envs, both nets' W2 and the env state
     stay on the CU) against T x (pnr_mlp_act, pnr_step): every buffer of the rollout — observations, actions, means, log-stds,
