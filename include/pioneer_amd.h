@@ -31,7 +31,7 @@ extern "C" {
  * PNR_ABI_VERSION it was compiled against before any other call (pnr_config carries it too).
  *   1  round 1
  *   2  pnr_ppo_loss gained `idx` (argument 2) and `means` (before `stream`); pnr_config grew (guarded by struct_size) */
-#define PNR_ABI_VERSION 2
+#define PNR_ABI_VERSION 3
 
 #define PNR_DOF 6          /* revolute joints of pioneer_knm_6dof.urdf:209-264 */
 #define PNR_OBS_DIM 137    /* pioneer_knm_env.py:194-211 (26 pieces)         */
@@ -413,7 +413,12 @@ typedef struct pnr_mlp_step {
                              * in *adam_step: two chains need two counters.  `means` of a one-net call holds that net's terms only
                              * (policy: policy_loss, kl, entropy and their share of total; value: vf_loss and its share): the
                              * update's means are the element-wise sum of the two rows.  partial_rows >= n_nets * ceil(batch / 64) */
+    float* w3_partials;     /* optional scratch, w3_partial_floats >= pnr_mlp_w3_partial_floats(batch): the fused kernel then leaves layer 3's */
+    int64_t w3_partial_floats; /* weight-gradient products per 64-sample tile there (17 KB) instead of storing H2 (32 KB per tile) for the
+                             * weight-gradient kernel, which adds them in tile order: the same sums bit for bit, 30 % fewer bytes in that
+                             * kernel.  NULL: H2 is stored to h2 and read back (h2 must be given either way) */
 } pnr_mlp_step;
+int64_t pnr_mlp_w3_partial_floats(int64_t batch);
 /*
  * An SGD epoch's shuffle applied once: row i of every output is row idx[i] of the corresponding input — the observation
  * filtered and rounded to the nets' input layout (xs_out [batch][144] bf16) and the rollout record — so that the epoch's

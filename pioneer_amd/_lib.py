@@ -114,6 +114,7 @@ class PnrMlpStep(C.Structure):
         ("partials", C.c_void_p), ("partial_rows", C.c_int64), ("slabs", C.c_void_p), ("slab_floats", C.c_int64),
         ("means", C.c_void_p), ("flat_grad", C.c_void_p), ("xs_in", C.c_void_p),
         ("first_net", C.c_int32), ("n_nets", C.c_int32),
+        ("w3_partials", C.c_void_p), ("w3_partial_floats", C.c_int64),
     ]
 
 
@@ -139,6 +140,7 @@ SIGNATURES = {
     "pnr_mlp_pack_elems": (C.c_int64, []),
     "pnr_mlp_bias_elems": (C.c_int64, []),
     "pnr_mlp_slab_floats": (C.c_int64, [C.c_int64]),
+    "pnr_mlp_w3_partial_floats": (C.c_int64, [C.c_int64]),
     "pnr_mlp_pack": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     "pnr_mlp_forward": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_int32, C.c_int32, _VP]),
     "pnr_ppo_gae_scratch": (C.c_int64, [C.c_int64]),

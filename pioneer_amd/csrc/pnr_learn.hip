@@ -78,6 +78,8 @@ static inline void mlp_slicing(long long B, long long* slices, long long* slice_
     *slices = (B + rows - 1) / rows;
 }
 
+int64_t pnr_mlp_w3_partial_floats(int64_t batch) { return batch < 1 ? 0 : ((batch + kMlpBM - 1) / kMlpBM) * kMlpNets * (int64_t)kW3PartFloats; }
+
 int64_t pnr_mlp_slab_floats(int64_t batch)
 {
     if (batch < 1) return 0;
@@ -280,7 +282,7 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0, st, Bp);
     MlpWgradParams Wp;
     Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
-    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows; Wp.first_net = 0;
+    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows; Wp.first_net = 0; Wp.w3part = nullptr; Wp.n_nets = kMlpNets;
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kWgThreads), 0, st, Wp);
     MlpReduceParams Rp;
     Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate; Rp.scale = scale;
@@ -412,10 +414,20 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     F.clip = s->clip_param; F.vf_clip = s->vf_clip_param; F.vf_coeff = s->vf_loss_coeff;
     F.g_head = s->g_head; F.partials = s->partials; F.adam_step = s->adam_step;
     F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
+    // layer 3's weight gradients per tile from the fused kernel (then H2 never leaves the CU) when the caller gave the scratch for it;
+    // the weight-stationary variant of the fused kernel stores H2 as before (the two forms give the same bits)
+    const bool stationary = F.xs_in && kTrainStationary;
+    if (s->w3_partials && !stationary) {
+        if (s->w3_partial_floats < (long long)tiles.x * nets * kW3PartFloats)
+            return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: w3_partials hold %lld floats, the launch needs %lld",
+                        (long long)s->w3_partial_floats, (long long)tiles.x * nets * kW3PartFloats);
+        F.w3part = s->w3_partials;
+        F.h2 = nullptr;
+    }
 #if PNR_MLP_STAMPS
     F.stamps = g_mlp_stamps;
 #endif
-    if (F.xs_in && kTrainStationary) {
+    if (stationary) {
         // contiguous inputs: the weight-stationary form, one workgroup per CU and net walking the tiles
         static int cus = 0;                                      // (every GPU of a node is the same part)
         if (!cus) {
@@ -434,7 +446,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
                            s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
     MlpWgradParams Wp;
     Wp.g_head = s->g_head; Wp.xs = F.xs_in ? F.xs_in : F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
-    Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows; Wp.first_net = s->first_net;
+    Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows; Wp.first_net = s->first_net; Wp.w3part = F.w3part; Wp.n_nets = nets;
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, nets), dim3(kWgThreads), 0, st, Wp);
     if (s->flat_grad)
         hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((nets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad,

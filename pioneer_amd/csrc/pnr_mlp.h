@@ -461,6 +461,7 @@ struct MlpFwdParams {
     float* adam_step;          // the optimiser's update count (device scalar), incremented once per launch; or null
     __bf16* dz1;               // [2][B][256]
     __bf16* dz2;
+    float* w3part;             // [tiles * nets][kW3PartFloats] layer 3's weight-gradient partials per tile (then h2 may be null), or null
     unsigned long long* stamps; // PNR_MLP_STAMPS builds only: [workgroups][4 waves][kMlpStampSlots] cycle stamps, or null
 };
 
@@ -530,6 +531,69 @@ __device__ __forceinline__ void mlp_store_htile_nt(const __bf16* tile, __bf16* _
         if (row0 + row < n_rows)
             *reinterpret_cast<uint4*>(dst + (row0 + row) * kMlpHid + cc * 8) = *reinterpret_cast<const uint4*>(tile + row * kHS + cc * 8);
     }
+}
+
+// a 16x16x32 operand fragment whose k index is the SAMPLE: eight consecutive rows s0 + 8g .. +7 (g = lane >> 4) of column
+// col0 + (lane & 15) of a row-major LDS tile, by two transposed 4x16 reads (cdna_hip_programming.md T10; wg_frag32 below is the
+// 32x32x16 form)
+__device__ __forceinline__ bf16x8 wg_frag16(const __bf16* tile, int tstride, int s0, int col0, int lane)
+{
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const __bf16* a = tile + (s0 + 8 * g + q) * tstride + col0 + 4 * p;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * tstride));
+    // whole-vector bit cast: built element by element (f[j] = bit_cast<__bf16>(lo[j])), hipcc 7.2 replicated element 0
+    // of each read into all four slots (v_perm_b32 0x05040100 of one register with itself) — found in the ISA after
+    // every sample = 0 mod 4 came out weighted four times and the others not at all
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+
+// ---- layer 3's weight gradients per TILE (r03h).  dW3 = G^T . H2 is the only consumer of H2 outside the tile that made it: 32 KB
+// of every tile's 128 KB of activation stores, read back by the weight-gradient kernel together with a second copy of dZ2 (for
+// db2) — 30 % of that kernel's bytes, and it runs at HBM / Infinity-Cache bandwidth (215 MB per 32 768-sample update in 35 us).
+// The fused kernel has G, H2 and dZ2 in LDS anyway: each wave multiplies its own 32 feature columns (the columns only it
+// overwrites) with 16x16x32 MFMAs and writes the tile's partials — dW3 [16][256] | db2 [256] | db3 [16] float32, 17 KB — and the
+// weight-gradient kernel's third role just adds a slice's 16 partial rows in tile order.  Both forms define the slice sum the same way
+// (per 64-sample tile a product chained over its two 32-sample k-steps from zero, the tiles added in order), so they agree bit for bit.
+constexpr int kW3PartFloats = kMlpHead * kMlpHid + kMlpHid + kMlpHead;
+__device__ __forceinline__ bf16x8 bf16x8_ones()
+{
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)1.0f;
+    return o;
+}
+// dW3 (this wave's feature columns 32 w ..) and db3 (wave 0) of one 64-sample tile: G tile [64][16] bf16, H2 tile [64][256] bf16
+__device__ __forceinline__ void mlp_tile_w3_products(const __bf16* gtile, int gstride, const __bf16* htile, int hstride, int lane, int w,
+                                                     f32x4 (&aw3)[2], f32x4& ab3)
+{
+    const bf16x8 ones = bf16x8_ones();
+    aw3[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw3[1] = aw3[0]; ab3 = aw3[0];
+#pragma unroll
+    for (int ks = 0; ks < kMlpBM / 32; ++ks) {
+        const bf16x8 fg = wg_frag16(gtile, gstride, 32 * ks, 0, lane);            // A: rows = head entries
+        if (w == 0) ab3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, ones, ab3, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const bf16x8 fh = wg_frag16(htile, hstride, 32 * ks, 32 * w + 16 * b, lane);
+            aw3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, fh, aw3[b], 0, 0, 0);
+        }
+    }
+}
+// db2 (this wave's feature columns) of one tile: every row of 1^T . dZ2
+__device__ __forceinline__ void mlp_tile_b2_products(const __bf16* ztile, int zstride, int lane, int w, f32x4 (&ab2)[2])
+{
+    const bf16x8 ones = bf16x8_ones();
+    ab2[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab2[1] = ab2[0];
+#pragma unroll
+    for (int ks = 0; ks < kMlpBM / 32; ++ks)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const bf16x8 fz = wg_frag16(ztile, zstride, 32 * ks, 32 * w + 16 * b, lane);
+            ab2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fz, ab2[b], 0, 0, 0);
+        }
 }
 
 // The tile's loss on all 512 threads of the fused kernels: eight lanes per sample, lane d < 6 = action dimension d of the policy head
@@ -896,7 +960,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         // W3^T's fragment for the first backward product: requested before the H2 store and the loss
         const bf16x8 w3t = ld_global_bf16x8(wp + kOffW3T + w * 512 + lane * 8);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        if (P.h2 && !(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);      // (null: layer 3's gradients are made here, below)
         mlp_barrier();
         MLP_STAMP(12);                    // barrier before the loss
         // ---- the tile's loss on all 512 threads (mlp_tile_loss)
@@ -930,6 +994,22 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[cb][i] = 0.f;
         };
+        // ---- layer 3's weight-gradient partials of this tile (dW3 = G^T . H2, db3 = G^T . 1), while H2 is still in the tile: this wave's
+        // 32 feature columns are the ones only it overwrites below
+        float* w3p = P.w3part ? P.w3part + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * kW3PartFloats : nullptr;
+        if (w3p) {
+            f32x4 aw3[2], ab3;
+            mlp_tile_w3_products(gt, kGS, ht, kHS, lane, w, aw3, ab3);
+            const int c16 = lane & 15, g = lane >> 4;              // C: col = lane & 15, rows 4g .. 4g+3
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w3p[(4 * g + j) * kMlpHid + 32 * w + 16 * b + c16] = aw3[b][j];
+            if (w == 0 && c16 == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w3p[kMlpHead * kMlpHid + kMlpHid + 4 * g + j] = ab3[j];     // every column of G^T . 1 is db3
+            }
+        }
         // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
         zero_acc();
         {
@@ -941,6 +1021,14 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
                 acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t, b[cb], acc[cb], 0, 0, 0);
         }
         bwd_epilogue();
+        if (w3p) {                                                 // db2 = 1^T . dZ2 of this wave's columns, now that they hold dZ2
+            f32x4 ab2[2];
+            mlp_tile_b2_products(ht, kHS, lane, w, ab2);
+            if ((lane >> 4) == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * w + 16 * b + (lane & 15)] = ab2[b][0];
+            }
+        }
         MLP_STAMP(15);                    // dH2 product + its epilogue
         MlpGemm1<kMlpHid, kHS> g4;                // W2^T's first fragments ahead of the barrier
         g4.prefetch(wp + kOffW2T + w * (kMlpHid / 16) * 512, lane);
@@ -1520,6 +1608,8 @@ struct MlpWgradParams {
     long long B;
     long long slice_rows;      // samples per slice, a multiple of kWgChunk
     int first_net;             // blockIdx.z + first_net = net
+    const float* w3part;       // [tiles * n_nets][kW3PartFloats] the fused kernel's per-tile layer-3 partials (then h2 is not read), or null
+    int n_nets;                // nets of the launch that wrote w3part (its row index is tile * n_nets + blockIdx.z)
 };
 
 // A 64-row chunk of COLS bf16 columns (a multiple of 8) on its way from row-major global memory (row stride src_stride)
@@ -1567,20 +1657,6 @@ __device__ __forceinline__ bf16x8 wg_frag32(const __bf16* tile, int tstride, int
     // every sample = 0 mod 4 came out weighted four times and the others not at all
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-// the 16x16x32 form: rows s0 + 8g .. +7 (g = lane >> 4) of column col0 + (lane & 15)
-__device__ __forceinline__ bf16x8 wg_frag16(const __bf16* tile, int tstride, int s0, int col0, int lane)
-{
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const __bf16* a = tile + (s0 + 8 * g + q) * tstride + col0 + 4 * p;
-    typedef s16x4 __attribute__((address_space(3))) * lds_p;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * tstride));
-    // whole-vector bit cast: built element by element (f[j] = bit_cast<__bf16>(lo[j])), hipcc 7.2 replicated element 0
-    // of each read into all four slots (v_perm_b32 0x05040100 of one register with itself) — found in the ISA after
-    // every sample = 0 mod 4 came out weighted four times and the others not at all
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
 // store a 32x32 accumulator block to a row-major float32 matrix: rows row0.., cols col0.. (cols < ncols kept)
 __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, int row0, int col0, int ncols, const f32x16& a, int lane)
 {
@@ -1625,6 +1701,7 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
                 ca.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
                 cb.load(P.h1 + nb + 128 * part, kMlpHid, s + kWgChunk, s_end, tid);
             }
+            // (two chunks in flight instead of one — two register sets, 218 VGPRs — changed nothing: 35.6 vs 35.1 us, r03h)
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 16; ++ks) {
                 bf16x8 fa[2], fb[2];
@@ -1692,16 +1769,34 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
             }
         }
     } else {
-        // dW3 [16][256] = G^T . H2, db3 = G^T . 1, db2 = 1^T . dZ2, all with 16x16x32 MFMAs (32 samples per k-step)
+        // dW3 [16][256] = G^T . H2, db3 = G^T . 1, db2 = 1^T . dZ2 of the slice.  Either the fused kernel left each tile's products
+        // (w3part: added here in tile order), or they are made here from the stored H2 / dZ2 / G with 16x16x32 MFMAs — per 64-sample
+        // chunk a product chained over its two 32-sample k-steps from zero, the chunks added in order: the same sums, the same bits.
+        if (P.w3part) {
+            const long long t0 = s_begin / kWgChunk, t1 = (s_end + kWgChunk - 1) / kWgChunk;
+            for (int e = tid; e < kW3PartFloats; e += kWgThreads) {
+                const float* pp = P.w3part + ((size_t)t0 * P.n_nets + blockIdx.z) * kW3PartFloats + e;
+                const size_t stride = (size_t)P.n_nets * kW3PartFloats;
+                float sum = 0.f;
+                long long t = t0;
+                for (; t + 8 <= t1; t += 8) {                             // tile order, eight loads in flight
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = pp[(size_t)(t - t0 + j) * stride];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += x[j];
+                }
+                for (; t < t1; ++t) sum += pp[(size_t)(t - t0) * stride];
+                slab[e < kMlpHead * kMlpHid ? kGW3 + e : (e < kMlpHead * kMlpHid + kMlpHid ? kGB2 + (e - kMlpHead * kMlpHid) : kGB3 + (e - kMlpHead * kMlpHid - kMlpHid))] = sum;
+            }
+            return;
+        }
         __bf16* th = lds;                        // H2 chunk [64][256]
         __bf16* tz = lds + kWgChunk * kTrH;      // dZ2 chunk [64][256]
         __bf16* tg = lds + 2 * kWgChunk * kTrH;  // G chunk [64][16] as bf16
         f32x4 aw3[2], ab2[2], ab3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < 2; ++b) { aw3[b] = ab3; ab2[b] = ab3; }
-        bf16x8 ones;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
         WgChunk<kMlpHid> ch2, cz2;
         ch2.load(P.h2 + nb, kMlpHid, s_begin, s_end, tid);
         cz2.load(P.dz2 + nb, kMlpHid, s_begin, s_end, tid);
@@ -1725,18 +1820,12 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
                 ch2.load(P.h2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
                 cz2.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
             }
+            f32x4 tw3[2], tb2[2], tb3;
+            mlp_tile_w3_products(tg, kTrG, th, kTrH, lane, w, tw3, tb3);
+            mlp_tile_b2_products(tz, kTrH, lane, w, tb2);
 #pragma unroll
-            for (int ks = 0; ks < kWgChunk / 32; ++ks) {
-                const bf16x8 fg = wg_frag16(tg, kTrG, 32 * ks, 0, lane);          // A: rows = head entries
-                if (w == 0) ab3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, ones, ab3, 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {                                      // wave w: feature columns 32w + 16b ..
-                    const bf16x8 fh = wg_frag16(th, kTrH, 32 * ks, 32 * w + 16 * b, lane);
-                    aw3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, fh, aw3[b], 0, 0, 0);
-                    const bf16x8 fz = wg_frag16(tz, kTrH, 32 * ks, 32 * w + 16 * b, lane);
-                    ab2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fz, ab2[b], 0, 0, 0);
-                }
-            }
+            for (int b = 0; b < 2; ++b) { aw3[b] += tw3[b]; ab2[b] += tb2[b]; }
+            ab3 += tb3;
         }
         const int c16 = lane & 15, g = lane >> 4;                  // C: col = lane & 15, rows 4g .. 4g+3
 #pragma unroll

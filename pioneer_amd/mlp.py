@@ -71,6 +71,7 @@ class HipMLP:
                 "slabs": torch.empty(int(self.lib.pnr_mlp_slab_floats(B)), **f32),
                 "head": torch.empty(2 * B * HEAD, **f32), "g": torch.empty(2 * B * HEAD, **f32),
                 "partials": torch.empty((2 * ((B + 63) // 64), 8), **f32),      # one row per (64-sample tile, net)
+                "w3part": torch.empty(int(self.lib.pnr_mlp_w3_partial_floats(B)), **f32),   # layer 3's weight-gradient products per tile
             }
         return self._train_ws
 
@@ -201,6 +202,7 @@ class HipMLP:
             self._step_value_net.copy_(step)
 
     REC_KEYS = ("actions", "logp", "mean", "log_std", "adv", "vtarg", "values")
+    w3_partials = True          # train_step: layer 3's weight gradients per tile from the fused kernel (pnr_mlp_step.w3_partials)
 
     def pack_record(self, rec, adv_mu: Optional[torch.Tensor] = None, adv_den: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The rollout record as one 24-float row per sample (pnr_ppo_pack_record), advantages standardised as
@@ -298,6 +300,12 @@ class HipMLP:
             part = part[part.shape[0] // 2:]
         s.partials, s.partial_rows = part.data_ptr(), part.shape[0]
         s.slabs, s.slab_floats = ws["slabs"].data_ptr(), ws["slabs"].numel()
+        # the per-tile layer-3 partials: each net's one-net call gets its own half, like the loss-sum rows
+        w3 = ws["w3part"]
+        if nets is not None and tuple(nets) == (1, 1):
+            w3 = w3[w3.numel() // 2:]
+        if self.w3_partials:                   # (False: H2 is stored and read back by the weight-gradient kernel — the A/B; same bits)
+            s.w3_partials, s.w3_partial_floats = w3.data_ptr(), w3.numel()
         s.means = means_out.data_ptr()
         if flat_grad is not None:
             assert flat_grad.dtype == torch.float32 and flat_grad.is_contiguous() and flat_grad.numel() == int(self.lib.pnr_mlp_grad_floats())

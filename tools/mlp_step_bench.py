@@ -19,6 +19,7 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = ActorCritic(PPOConfig()).to(dev)
 mlp = HipMLP(model, B, dev)
+mlp.w3_partials = os.environ.get("W3PART", "1") == "1"      # 0: H2 stored and read back (the A/B)
 mlp.pack()
 R = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
 rows = 16 * B
@@ -90,6 +91,6 @@ for _ in range(N):
     act_call()
 e1.record()
 torch.cuda.synchronize()
-print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "chains": CHAINS, "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
+print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "chains": CHAINS, "w3_partials": mlp.w3_partials, "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
                   "param_sums": [round(float(p_.double().sum()), 6) for p_ in mlp.params[:2]] + [round(float(p_.double().sum()), 6) for p_ in mlp.params[6:8]],
                   "means_finite": bool(torch.isfinite(means[:5]).all()), "means": [round(float(x), 5) for x in means[:5]]}))
