@@ -32,6 +32,8 @@ static int fail(pnr_handle, int code, const char* fmt, ...)
 // diagnostic variant only (tools/mlp_stamps.py): where the fused kernel's waves write their phase stamps
 static unsigned long long* g_mlp_stamps = nullptr;
 extern "C" int pnr_mlp_set_stamp_buffer(void* p) { g_mlp_stamps = static_cast<unsigned long long*>(p); return 0; }
+static unsigned long long* g_wg_stamps = nullptr;      // the weight-gradient kernel's: [2 nets][4 roles][slices][8 waves][26]
+extern "C" int pnr_mlp_set_wgrad_stamp_buffer(void* p) { g_wg_stamps = static_cast<unsigned long long*>(p); return 0; }
 #endif
 
 extern "C" {
@@ -282,7 +284,7 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0, st, Bp);
     MlpWgradParams Wp;
     Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
-    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows; Wp.first_net = 0; Wp.w3part = nullptr; Wp.n_nets = kMlpNets;
+    Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows; Wp.first_net = 0; Wp.w3part = nullptr; Wp.n_nets = kMlpNets; Wp.stamps = nullptr;
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kWgThreads), 0, st, Wp);
     MlpReduceParams Rp;
     Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate; Rp.scale = scale;
@@ -447,6 +449,10 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     MlpWgradParams Wp;
     Wp.g_head = s->g_head; Wp.xs = F.xs_in ? F.xs_in : F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
     Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows; Wp.first_net = s->first_net; Wp.w3part = F.w3part; Wp.n_nets = nets;
+    Wp.stamps = nullptr;
+#if PNR_MLP_STAMPS
+    Wp.stamps = g_wg_stamps;
+#endif
     hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, nets), dim3(kWgThreads), 0, st, Wp);
     if (s->flat_grad)
         hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((nets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad,

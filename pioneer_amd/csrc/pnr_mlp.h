@@ -1610,7 +1610,14 @@ struct MlpWgradParams {
     int first_net;             // blockIdx.z + first_net = net
     const float* w3part;       // [tiles * n_nets][kW3PartFloats] the fused kernel's per-tile layer-3 partials (then h2 is not read), or null
     int n_nets;                // nets of the launch that wrote w3part (its row index is tile * n_nets + blockIdx.z)
+    unsigned long long* stamps; // PNR_MLP_STAMPS builds only (tools/wgrad_stamps.py): [nets][roles][slices][8 waves][kMlpStampSlots], or null
 };
+#if PNR_MLP_STAMPS
+#define WG_STAMP(i) do { if (P.stamps && lane == 0) { unsigned long long* sp_ = P.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + w) * kMlpStampSlots; \
+    sp_[(i)] = __builtin_amdgcn_s_memtime(); if ((i) == 0) sp_[24] = __builtin_amdgcn_s_memrealtime(); if ((i) == 22) sp_[25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define WG_STAMP(i) do { } while (0)
+#endif
 
 // A 64-row chunk of COLS bf16 columns (a multiple of 8) on its way from row-major global memory (row stride src_stride)
 // into an LDS tile: loaded into registers first (every load of the chunk in flight together), written later — the
@@ -1657,13 +1664,21 @@ __device__ __forceinline__ bf16x8 wg_frag32(const __bf16* tile, int tstride, int
     // every sample = 0 mod 4 came out weighted four times and the others not at all
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+#ifndef PNR_SLAB_NT
+#define PNR_SLAB_NT 1
+#endif
+#if PNR_SLAB_NT
+#define PNR_SLAB_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define PNR_SLAB_STORE(p, v) (*(p) = (v))
+#endif
 // store a 32x32 accumulator block to a row-major float32 matrix: rows row0.., cols col0.. (cols < ncols kept)
 __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, int row0, int col0, int ncols, const f32x16& a, int lane)
 {
     const int c = lane & 31, h = lane >> 5;
     if (col0 + c < ncols) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) m[(size_t)(row0 + (i & 3) + 8 * (i >> 2) + 4 * h) * ld + col0 + c] = a[i];
+        for (int i = 0; i < 16; ++i) PNR_SLAB_STORE(m + (size_t)(row0 + (i & 3) + 8 * (i >> 2) + 4 * h) * ld + col0 + c, a[i]);
     }
 }
 
@@ -1690,18 +1705,25 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+        WG_STAMP(0);
+        int ci = 0;
         WgChunk<kMlpHid> ca; WgChunk<128> cb;
         ca.load(P.dz2 + nb, kMlpHid, s_begin, s_end, tid);
         cb.load(P.h1 + nb + 128 * part, kMlpHid, s_begin, s_end, tid);
         for (long long s = s_begin; s < s_end; s += kWgChunk) {
             mlp_barrier();                                         // every wave is done with the previous chunk
+            if (ci < 17) WG_STAMP(1 + ci);
+            ++ci;
             ca.store(ta, kTrH, tid); cb.store(tb, kTrHalf, tid);
             mlp_barrier();
             if (s + kWgChunk < s_end) {                              // the next chunk travels while this one is multiplied
                 ca.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
                 cb.load(P.h1 + nb + 128 * part, kMlpHid, s + kWgChunk, s_end, tid);
             }
-            // (two chunks in flight instead of one — two register sets, 218 VGPRs — changed nothing: 35.6 vs 35.1 us, r03h)
+            // Tried and dropped (r03h / r03i, each bit-identical, none faster: 35.0-35.6 us against 35.1): two chunks in flight (two register
+            // sets), two sets of LDS tiles with one barrier per chunk, and the two waves of a SIMD staging / multiplying in opposite order.  The
+            // stamps say why: a chunk takes 2 800 cycles whatever the schedule — 176 KB through the LDS port per chunk and CU (48 KB staged, 128 KB
+            // read back as transposed 8-byte fragments, each shared by only two or four waves) at ~64 B/clk; its 16 MFMAs per wave need 1 024.
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 16; ++ks) {
                 bf16x8 fa[2], fb[2];
@@ -1716,11 +1738,13 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
             }
         }
+        WG_STAMP(20);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
                 wg_store_block(slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
+        WG_STAMP(22);
     } else if (part == 2) {
         // dW1 = dZ1^T . X (144 columns) and db1 = dZ1^T . 1 (the tile's column 144 is all ones); wave w: rows 32w..
         __bf16* ta = lds;                        // dZ1 chunk [64][256]
