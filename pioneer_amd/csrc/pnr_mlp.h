@@ -1627,11 +1627,36 @@ struct MlpWgradParams {
 constexpr int kWgThreads = 512;
 template <int COLS>
 struct WgChunk {
-    static constexpr int kPerThread = (kWgChunk * (COLS / 8) + kWgThreads - 1) / kWgThreads;
+    static constexpr int kPieces = kWgChunk * (COLS / 8);
+    static constexpr int kPerThread = (kPieces + kWgThreads - 1) / kWgThreads;
+    static constexpr int kFull = kPieces / kWgThreads;             // iterations in which every thread has a piece
     uint4 v[kPerThread];
+    // A WHOLE chunk (the common case: slices are multiples of 64 rows, only the batch's last chunk can be short) is requested with no
+    // per-thread test and one per-thread offset that does not depend on the chunk: uniform base + thread offset + constant.  Written
+    // with a bounds test, a zero fill and a 64-bit row * stride per piece, requesting a chunk's nine pieces cost ~1 000 of its
+    // 3 150 cycles in address arithmetic alone (tools/wgrad_stamps.py, r03i).
     __device__ __forceinline__ void load(const __bf16* __restrict__ src, long long src_stride, long long row0, long long n_rows, int tid)
     {
         constexpr int cpr = COLS / 8;
+        if (row0 + kWgChunk <= n_rows) {                            // uniform
+            const __bf16* base = src + row0 * src_stride;
+            const unsigned off = (unsigned)(tid / cpr) * (unsigned)src_stride + (unsigned)(tid % cpr) * 8u;
+            const unsigned step = (unsigned)(kWgThreads / cpr) * (unsigned)src_stride;
+            static_assert(kWgThreads % cpr == 0 || kFull * kWgThreads == kPieces || true, "");
+#pragma unroll
+            for (int i = 0; i < kPerThread; ++i) {
+                if constexpr (kWgThreads % cpr == 0) {
+                    // rows advance by kWgThreads / cpr per iteration, the column piece stays
+                    if (i < kFull || tid < kPieces - kFull * kWgThreads) v[i] = *reinterpret_cast<const uint4*>(base + off + (size_t)i * step);
+                    else v[i] = make_uint4(0u, 0u, 0u, 0u);
+                } else {
+                    const int ch = tid + kWgThreads * i, row = ch / cpr, cc = ch % cpr;
+                    if (i < kFull || ch < kPieces) v[i] = *reinterpret_cast<const uint4*>(base + (unsigned)row * (unsigned)src_stride + (unsigned)cc * 8u);
+                    else v[i] = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kPerThread; ++i) {
             const int ch = tid + kWgThreads * i, row = ch / cpr, cc = ch % cpr;
@@ -1721,21 +1746,29 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
                 cb.load(P.h1 + nb + 128 * part, kMlpHid, s + kWgChunk, s_end, tid);
             }
             // Tried and dropped (r03h / r03i, each bit-identical, none faster: 35.0-35.6 us against 35.1): two chunks in flight (two register
-            // sets), two sets of LDS tiles with one barrier per chunk, and the two waves of a SIMD staging / multiplying in opposite order.  The
-            // stamps say why: a chunk takes 2 800 cycles whatever the schedule — 176 KB through the LDS port per chunk and CU (48 KB staged, 128 KB
-            // read back as transposed 8-byte fragments, each shared by only two or four waves) at ~64 B/clk; its 16 MFMAs per wave need 1 024.
+            // sets), two sets of LDS tiles with one barrier per chunk, and the two waves of a SIMD staging / multiplying in opposite order.
+            // Counters of the kernel: LDS active 20 % of the time (3 % of that bank conflicts), MFMA busy 18.5 %, waves waiting 41 %.
+            // the fragments of k-step ks + 1 are read before the MFMAs of k-step ks are issued (16 more registers): left to the
+            // compiler, every k-step began with the round trip of its own transposed reads (r03i)
+            bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) fa[0][a] = wg_frag32(ta, kTrH, 0, 64 * wo + 32 * a, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) fb[0][b] = wg_frag32(tb, kTrHalf, 0, 64 * wi + 32 * b, lane);
 #pragma unroll
             for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-                bf16x8 fa[2], fb[2];
+                if (ks + 1 < kWgChunk / 16) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) fa[a] = wg_frag32(ta, kTrH, 16 * ks, 64 * wo + 32 * a, lane);
+                    for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = wg_frag32(ta, kTrH, 16 * (ks + 1), 64 * wo + 32 * a, lane);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) fb[b] = wg_frag32(tb, kTrHalf, 16 * ks, 64 * wi + 32 * b, lane);
+                    for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = wg_frag32(tb, kTrHalf, 16 * (ks + 1), 64 * wi + 32 * b, lane);
+                }
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         WG_STAMP(20);

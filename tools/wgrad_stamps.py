@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where the dW2 roles of mlp_wgrad_kernel spend their cycles (diagnostic -DPNR_MLP_STAMPS=1 build): s_memtime at the start, at the top of
-every chunk (behind its first barrier), after the loop and after the slab stores.
+every chunk (behind its first barrier), after the loop and after the slab stores.  Caveat: a stamp is a global store, and the
+staging code's s_waitcnt vmcnt(0) waits for it like for any other vector-memory operation — the per-chunk times are upper bounds
+(the unstamped kernel's workgroups live shorter); finer stamps inside a chunk measured mostly their own acknowledgements and were removed.
   PNR_LIB_PATH=.../libpioneer_amd_stamps.so python tools/wgrad_stamps.py [OUT.json]"""
 import ctypes as C
 import json
