@@ -525,6 +525,17 @@ struct MlpGemm1 {
 template <int NT>
 __device__ __forceinline__ void mlp_store_htile_nt(const __bf16* tile, __bf16* __restrict__ dst, long long row0, long long n_rows, int tid)
 {
+    if (row0 + kMlpBM <= n_rows) {
+        // a whole tile (every tile but the batch's last): one uniform test, the tile's 32 KB are contiguous in global memory — thread
+        // offset + a constant per piece, no per-piece row test and no 64-bit row * stride (mlp_wgrad_kernel's lesson, r03i)
+        __bf16* base = dst + row0 * kMlpHid + tid * 8;
+#pragma unroll
+        for (int i = 0; i < kMlpBM * 32 / NT; ++i) {
+            const int ch = tid + NT * i, row = ch >> 5, cc = ch & 31;
+            *reinterpret_cast<uint4*>(base + (size_t)i * NT * 8) = *reinterpret_cast<const uint4*>(tile + row * kHS + cc * 8);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < kMlpBM * 32 / NT; ++i) {
         const int ch = tid + NT * i, row = ch >> 5, cc = ch & 31;
