@@ -749,11 +749,20 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
             // every load of the thread in flight before the first LDS write
             constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFwdThreads - 1) / kFwdThreads;
             uint4 v[kIt];
+            if (row0 + kMlpBM <= P.B) {            // a whole tile: 18 KB contiguous — thread offset + constant per piece, one uniform test
+                const __bf16* base = P.xs_in + row0 * kMlpInPad + tid * 8;
 #pragma unroll
-            for (int i = 0; i < kIt; ++i) {
-                const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                v[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (ch < kCh && row0 + row < P.B) v[i] = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
+                for (int i = 0; i < kIt; ++i) {
+                    v[i] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < kCh / kFwdThreads || tid + kFwdThreads * i < kCh) v[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * kFwdThreads * 8);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kIt; ++i) {
+                    const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                    v[i] = make_uint4(0u, 0u, 0u, 0u);
+                    if (ch < kCh && row0 + row < P.B) v[i] = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
+                }
             }
 #pragma unroll
             for (int i = 0; i < kIt; ++i) {

@@ -211,10 +211,17 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
                     const int ch = tv + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
                     if (ch < kCh) v[i] = *reinterpret_cast<const uint4*>(xt + row * kXS + cc * 8);
                 }
-    #pragma unroll
-                for (int i = 0; i < kIt; ++i) {
-                    const int ch = tv + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                    if (ch < kCh && e0 + row < n) *reinterpret_cast<uint4*>(S.xs + (tn + e0 + row) * kMlpInPad + cc * 8) = v[i];
+                    if (e0 + kMlpBM <= n) {                               // a whole tile: 18 KB contiguous in xs
+                    __bf16* base = S.xs + (tn + e0) * kMlpInPad + tv * 8;
+#pragma unroll
+                    for (int i = 0; i < kIt; ++i)
+                        if (i < kCh / kFwdThreads || tv + kFwdThreads * i < kCh) *reinterpret_cast<uint4*>(base + (size_t)i * kFwdThreads * 8) = v[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kIt; ++i) {
+                        const int ch = tv + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                        if (ch < kCh && e0 + row < n) *reinterpret_cast<uint4*>(S.xs + (tn + e0 + row) * kMlpInPad + cc * 8) = v[i];
+                    }
                 }
             }
         };
