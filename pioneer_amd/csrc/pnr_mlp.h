@@ -1798,10 +1798,104 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
             for (int b = 0; b < 2; ++b)
                 wg_store_block(slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
         WG_STAMP(22);
+    } else if (P.w3part) {
+        // ---- with the fused kernel's layer-3 partials the fourth role has next to nothing to do (9 us of adding 16 partial rows), and dW1 was the
+        // longest role (27 us against dW2's 23.5: five MFMAs per wave and k-step against four, tools/wgrad_stamps.py): roles 2 and 3 each take
+        // HALF of dW1's rows (128 output units = columns 128 (part - 2) .. of dZ1) and then adds half of the partials' elements.  Waves 4 (row blocks) x 2
+        // (column groups: blocks 0-2 | blocks 3-4 of X's 160 columns).  Every element's products are accumulated in the same order as in the
+        // one-role form below: the same bits.
+        const int half = part - 2;
+        __bf16* ta = lds;                        // dZ1 chunk, this half's columns: [64][128], stride kTrHalf
+        __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
+        WG_STAMP(0);
+        const int rb = w & 3, cg = w >> 2;       // row block of the half, column group
+        f32x16 acc[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        WgChunk<128> ca; WgChunk<kMlpInPad> cb;
+        ca.load(P.dz1 + nb + 128 * half, kMlpHid, s_begin, s_end, tid);
+        cb.load(P.xs, kMlpInPad, s_begin, s_end, tid);
+        for (long long s = s_begin; s < s_end; s += kWgChunk) {
+            mlp_barrier();
+            ca.store(ta, kTrHalf, tid); cb.store(tb, kTrX, tid);
+            if (tid < kWgChunk) {                                     // columns 144..159: a one (real rows only), zeros
+                bf16x8 one = {(__bf16)((s + tid < s_end) ? 1.0f : 0.0f), (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad) = one;
+                *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad + 8) = zero;
+            }
+            mlp_barrier();
+            if (s + kWgChunk < s_end) {
+                ca.load(P.dz1 + nb + 128 * half, kMlpHid, s + kWgChunk, s_end, tid);
+                cb.load(P.xs, kMlpInPad, s + kWgChunk, s_end, tid);
+            }
+#pragma unroll
+            for (int ks = 0; ks < kWgChunk / 16; ++ks) {
+                const bf16x8 fa = wg_frag32(ta, kTrHalf, 16 * ks, 32 * rb, lane);
+                if (cg == 0) {
+                    bf16x8 fb[3];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * b, lane);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+                } else {
+                    bf16x8 fb[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * (3 + b), lane);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+                }
+            }
+        }
+        {
+            const int row0 = 128 * half + 32 * rb;
+            if (cg == 0) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * b, kMlpInPad, acc[b], lane);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * (3 + b), kMlpInPad, acc[b], lane);
+                // column 144 of the product = db1: lane c == 16 of column block 4
+                if ((lane & 31) == 16) {
+                    const int hh = lane >> 5;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[1][i];
+                }
+            }
+        }
+        {   // the fused kernel's per-tile layer-3 products of this slice, added in tile order: each of the two roles takes half of the
+            // elements, a thread a quad of them — the 16 tiles' 16-byte pieces requested together (one round trip instead of the
+            // 2 x 4 of an element at a time, eight tiles in flight)
+            static_assert(kW3PartFloats % 8 == 0, "halves of whole quads");
+            const long long t0 = s_begin / kWgChunk, t1 = (s_end + kWgChunk - 1) / kWgChunk;
+            const size_t stride = (size_t)P.n_nets * kW3PartFloats;
+            for (int q = half * (kW3PartFloats / 8) + tid; q < (half + 1) * (kW3PartFloats / 8); q += kWgThreads) {
+                const float* pp = P.w3part + ((size_t)t0 * P.n_nets + blockIdx.z) * kW3PartFloats + 4 * q;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                long long t = t0;
+                for (; t + 16 <= t1; t += 16) {
+                    f32x4 x[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const f32x4*>(pp + (size_t)(t - t0 + j) * stride);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sum += x[j];
+                }
+                for (; t < t1; ++t) sum += *reinterpret_cast<const f32x4*>(pp + (size_t)(t - t0) * stride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * q + j;
+                    slab[e < kMlpHead * kMlpHid ? kGW3 + e : (e < kMlpHead * kMlpHid + kMlpHid ? kGB2 + (e - kMlpHead * kMlpHid) : kGB3 + (e - kMlpHead * kMlpHid - kMlpHid))] = sum[j];
+                }
+            }
+        }
+        WG_STAMP(22);
     } else if (part == 2) {
         // dW1 = dZ1^T . X (144 columns) and db1 = dZ1^T . 1 (the tile's column 144 is all ones); wave w: rows 32w..
         __bf16* ta = lds;                        // dZ1 chunk [64][256]
         __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
+        WG_STAMP(0);
         f32x16 acc[5];
 #pragma unroll
         for (int b = 0; b < 5; ++b)
@@ -1845,29 +1939,11 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
                 for (int i = 0; i < 16; ++i) slab[kGB1 + 32 * w + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[4][i];
             }
         }
+        WG_STAMP(22);
     } else {
-        // dW3 [16][256] = G^T . H2, db3 = G^T . 1, db2 = 1^T . dZ2 of the slice.  Either the fused kernel left each tile's products
-        // (w3part: added here in tile order), or they are made here from the stored H2 / dZ2 / G with 16x16x32 MFMAs — per 64-sample
-        // chunk a product chained over its two 32-sample k-steps from zero, the chunks added in order: the same sums, the same bits.
-        if (P.w3part) {
-            const long long t0 = s_begin / kWgChunk, t1 = (s_end + kWgChunk - 1) / kWgChunk;
-            for (int e = tid; e < kW3PartFloats; e += kWgThreads) {
-                const float* pp = P.w3part + ((size_t)t0 * P.n_nets + blockIdx.z) * kW3PartFloats + e;
-                const size_t stride = (size_t)P.n_nets * kW3PartFloats;
-                float sum = 0.f;
-                long long t = t0;
-                for (; t + 8 <= t1; t += 8) {                             // tile order, eight loads in flight
-                    float x[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = pp[(size_t)(t - t0 + j) * stride];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) sum += x[j];
-                }
-                for (; t < t1; ++t) sum += pp[(size_t)(t - t0) * stride];
-                slab[e < kMlpHead * kMlpHid ? kGW3 + e : (e < kMlpHead * kMlpHid + kMlpHid ? kGB2 + (e - kMlpHead * kMlpHid) : kGB3 + (e - kMlpHead * kMlpHid - kMlpHid))] = sum;
-            }
-            return;
-        }
+        // dW3 [16][256] = G^T . H2, db3 = G^T . 1, db2 = 1^T . dZ2 of the slice from the stored H2 / dZ2 / G (no w3part: the weight-stationary
+        // variant, pnr_mlp_backward) with 16x16x32 MFMAs — per 64-sample chunk a product chained over its two 32-sample k-steps from zero,
+        // the chunks added in order: the same sums, bit for bit, as the fused kernel's per-tile products added in tile order above.
         __bf16* th = lds;                        // H2 chunk [64][256]
         __bf16* tz = lds + kWgChunk * kTrH;      // dZ2 chunk [64][256]
         __bf16* tg = lds + 2 * kWgChunk * kTrH;  // G chunk [64][16] as bf16

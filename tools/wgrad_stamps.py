@@ -35,7 +35,13 @@ raw.pnr_mlp_set_wgrad_stamp_buffer(C.c_void_p(st.data_ptr()))
 for _ in range(10):
     mlp.train_step(None, None, None, rec, klc, entc, 0.3, 10.0, 1.0, means, 2e-5, xs_in=xs)
 torch.cuda.synchronize()
-s = st.cpu().numpy().astype(np.int64)[:, :2]          # the two dW2 roles
+full = st.cpu().numpy().astype(np.int64)
+t_first = full[..., 0, 24][full[..., 0, 24] > 0].min()
+for role, nm in enumerate(("dW2, input columns 0..127", "dW2, input columns 128..255", "dW1 + db1", "layer-3 partial sums")):
+    r = full[:, role]
+    life = (r[..., 0, 25] - r[..., 0, 24]) / 100.0
+    print(f"role {role} ({nm}): a workgroup lives {np.median(life):.1f} us (p90 {np.percentile(life, 90):.1f}); last one ends {(r[..., 0, 25].max() - t_first) / 100.0:.1f} us after the first workgroup of the launch started")
+s = full[:, :2]          # the two dW2 roles
 rt = (s[..., 25] - s[..., 24]) / 100.0
 print(f"a dW2 workgroup lives {np.median(rt):.1f} us (median; s_memrealtime), the launch spans {(s[..., 25].max() - s[..., 24].min()) / 100.0:.1f} us")
 names = ["first chunk: request, wait for it"] + [f"chunk {k}: stage, barrier, request the next, multiply, barrier" for k in range(15)] + ["chunk 15 (nothing to request)", "slab stores"]
