@@ -1,7 +1,7 @@
 // pnr_sampler.h — the PPO sampler's closed loop as ONE resident kernel (pnr_ppo_rollout).
 //
 // What it replaces: T x (pnr_mlp_act + pnr_step), two dependent launches per sampler step — 18.5 + 6.1 us of kernels and
-// 5.4 us of launch boundaries per step at 16 384 envs (profiles/r03_i_ppo_loop_kernel_stats.csv), 13 % of a PPO iteration.
+// 5.4 us of launch boundaries per step at 16 384 envs (profiles/r03_j_ppo_loop_kernel_stats.csv), 13 % of a PPO iteration.
 // Envs are independent and a 64-env tile needs nothing from any other tile, so ONE workgroup owns 64 envs for the whole
 // rollout: per step it runs both nets on the tile's observation (the forward pass of mlp_forward_kernel<false>, same
 // arithmetic in the same order), draws the action in the policy head's epilogue, steps its 64 envs (the body of
