@@ -73,10 +73,18 @@ constexpr int kMlpThreads = 256;  // four waves
 #endif
 constexpr int kMlpStampSlots = 26;   // 0..22 phase boundaries (s_memtime), 24 / 25 s_memrealtime (100 MHz) at start / end
 #if PNR_MLP_STAMPS
-#define MLP_STAMP(i) do { if (P.stamps && lane == 0) { unsigned long long* sp_ = P.stamps + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kFwdWaves + w) * kMlpStampSlots; \
-    sp_[(i)] = __builtin_amdgcn_s_memtime(); if ((i) == 0) sp_[24] = __builtin_amdgcn_s_memrealtime(); if ((i) == 22) sp_[25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+// The stamps wait in LDS and leave for global memory at the kernel's end: written to global memory where they are taken (r03b - r03i),
+// every stamp was a store that the next s_waitcnt vmcnt(..) of the wave — the weight ring's, in order — also waited for, i.e. the
+// instrument stretched exactly the phases it was pointed at (found on mlp_wgrad_kernel, r03i).
+#define MLP_STAMP_DECL __shared__ unsigned long long stamp_lds_[kFwdWaves][kMlpStampSlots]
+#define MLP_STAMP(i) do { if (P.stamps && lane == 0) { stamp_lds_[w][(i)] = __builtin_amdgcn_s_memtime(); \
+    if ((i) == 0) stamp_lds_[w][24] = __builtin_amdgcn_s_memrealtime(); if ((i) == 22) stamp_lds_[w][25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define MLP_STAMP_FLUSH do { if (P.stamps && lane < kMlpStampSlots) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    P.stamps[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kFwdWaves + w) * kMlpStampSlots + lane] = stamp_lds_[w][lane]; } } while (0)
 #else
+#define MLP_STAMP_DECL
 #define MLP_STAMP(i) do { } while (0)
+#define MLP_STAMP_FLUSH do { } while (0)
 #endif
 
 // packed bf16 weights of ONE net, element offsets.  Every matrix is stored FRAGMENT-NATIVE: the 32 x 16 (or 16 x 32) block
@@ -702,6 +710,7 @@ template <bool FUSED>
 __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
     __shared__ __attribute__((aligned(16))) __bf16 lds[kMlpBM * kXS + kMlpBM * kHS];
+    MLP_STAMP_DECL;
     __bf16* xt = lds;
     __bf16* ht = lds + kMlpBM * kXS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1077,6 +1086,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         mlp_barrier();
         if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
         MLP_STAMP(22);                    // end
+        MLP_STAMP_FLUSH;
     }
 }
 
@@ -1123,6 +1133,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void mlp_train_kernel(const MlpFwdP
 {
     static_assert(kMlpBM == 64, "written for 64-sample tiles");
     __shared__ __attribute__((aligned(16))) __bf16 lds[kTrainLdsElems];
+    MLP_STAMP_DECL;
     __bf16* xt = lds;                                               // [64][144] the tile's input
     __bf16* h1t = xt + kMlpBM * kXS;                                // [64][256] H1
     __bf16* h2t = h1t + kMlpBM * kHS;                               // H2, then dZ2 in place (a lane's own quads)
@@ -1379,6 +1390,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void mlp_train_kernel(const MlpFwdP
         mlp_store_htile_nt<kFwdThreads>(d1t, P.dz1 + (size_t)net * P.B * kMlpHid, prow0, P.B, tid);
     }
     MLP_STAMP(22);
+    MLP_STAMP_FLUSH;
 #undef TRAIN_STAMP
 #undef TRAIN_SLOT
 }
