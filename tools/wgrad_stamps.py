@@ -37,7 +37,7 @@ for _ in range(10):
 torch.cuda.synchronize()
 full = st.cpu().numpy().astype(np.int64)
 t_first = full[..., 0, 24][full[..., 0, 24] > 0].min()
-for role, nm in enumerate(("dW2, input columns 0..127", "dW2, input columns 128..255", "dW1 + db1", "layer-3 partial sums")):
+for role, nm in enumerate(("dW2, input columns 0..127", "dW2, input columns 128..255", "dW1 + db1 rows 0..127, half of the layer-3 partial sums", "dW1 + db1 rows 128..255, the other half")):
     r = full[:, role]
     life = (r[..., 0, 25] - r[..., 0, 24]) / 100.0
     print(f"role {role} ({nm}): a workgroup lives {np.median(life):.1f} us (p90 {np.percentile(life, 90):.1f}); last one ends {(r[..., 0, 25].max() - t_first) / 100.0:.1f} us after the first workgroup of the launch started")
