@@ -306,7 +306,8 @@ int pnr_filter_moments(int64_t rows, const float* obs, const float* pivot, float
  * pivot [137] into the running *n, mean / m2 [137] by Chan's update, float64, one launch. */
 int pnr_filter_merge(double* dn, double* dsum, double* dsq, const float* pivot, double* n, double* mean, double* m2, void* stream);
 
-/* MeanStdFilter.prepare() in one launch: the float32 vectors the kernels filter with, x' = clamp((x - loc) * inv, lo, hi), from the
+/* MeanStdFilter.prepare() in one launch ('observation_filter': 'ConcurrentMeanStdFilter', pioneer_knm_train.py:66): the float32 vectors
+ * the kernels filter with, x' = clamp((x - loc) * inv, lo, hi), from the
  * running statistics *n, mean / m2 [137] (RLlib MeanStdFilter: (x - mean) / (std + 1e-8), clipped to +-clip; clip = +inf: no clipping;
  * the identity until two samples exist). */
 int pnr_filter_prepare(const double* n, const double* mean, const double* m2, double clip, float* loc, float* inv, float* lo, float* hi,
