@@ -273,7 +273,14 @@ def run_rank(args):
     # one process per GPU; PNR_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box) maps every rank to the
     # devices that exist and uses gloo, because RCCL refuses two ranks on one device
     share = os.environ.get("PNR_BENCH_SHARE_GPU") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    ndev = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if ndev < 1 or (not share and local_rank >= ndev):
+        # a user error, not a GPU fault: say so in one line on every rank that cannot be placed, before any GPU call
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible devices (found {ndev}); rank {rank} (local rank {local_rank}) has "
+              "no device" + ("" if share or ndev < 1 else "  [PNR_BENCH_SHARE_GPU=1 rehearses N ranks on the devices that exist, over gloo]"),
+              file=sys.stderr, flush=True)
+        return 2
+    dev_index = local_rank % ndev if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -737,6 +744,12 @@ def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if os.environ.get("PNR_BENCH_DRYRUN") != "1" and os.environ.get("PNR_BENCH_SHARE_GPU") != "1":
+            import torch                                   # device_count() only: nothing here touches the GPU
+            ndev = torch.cuda.device_count()
+            if ndev < args.gpus:
+                print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible devices (found {ndev})", file=sys.stderr, flush=True)
+                return 2
         return self_launch(args, argv)
     return run_rank(args)
 

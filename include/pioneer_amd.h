@@ -13,7 +13,11 @@
  *   - all I/O buffers are caller-owned DEVICE pointers (plain pointers and
  *     sizes; no torch types); the library owns only the per-env state;
  *   - calls are asynchronous on the given HIP stream (passed as void*, i.e.
- *     a hipStream_t; NULL = the default stream) and never synchronise;
+ *     a hipStream_t; NULL = the default stream) and never synchronise — with
+ *     ONE exception: pnr_create zero-fills the state planes on the NULL stream
+ *     and waits for that fill (hipStreamSynchronize(NULL)) before it returns,
+ *     so that a first pnr_reset on ANY stream, blocking or not, finds them
+ *     zero (pnr_destroy frees memory and synchronises as hipFree does);
  *   - a handle is not thread-safe; distinct handles are independent;
  *   - there is NO CPU backend: pnr_create fails with PNR_ERR_NODEVICE when no
  *     gfx950 device is usable.
@@ -30,7 +34,10 @@ extern "C" {
 /* Bumped whenever an exported signature or struct changes incompatibly; a caller checks pnr_abi_version() == the
  * PNR_ABI_VERSION it was compiled against before any other call (pnr_config carries it too).
  *   1  round 1
- *   2  pnr_ppo_loss gained `idx` (argument 2) and `means` (before `stream`); pnr_config grew (guarded by struct_size) */
+ *   2  pnr_ppo_loss gained `idx` (argument 2) and `means` (before `stream`); pnr_config grew (guarded by struct_size)
+ *   3  pnr_mlp_step gained first_net / n_nets (the two nets as two chains) and w3_partials / w3_partial_floats (layer 3's
+ *      weight-gradient partials made by the fused kernel); new entry points pnr_ppo_rollout (the sampler's T steps as one
+ *      resident launch), pnr_filter_prepare, pnr_mlp_w3_partial_floats */
 #define PNR_ABI_VERSION 3
 
 #define PNR_DOF 6          /* revolute joints of pioneer_knm_6dof.urdf:209-264 */

@@ -11,7 +11,7 @@ from ._lib import PnrError, build_library, load_library  # noqa: F401
 
 __all__ = ["EngineConfig", "PioneerKinematicConfig", "RenderConfig", "SimulationConfig", "SceneBody", "scene_box", "scene_plane",
            "scene_sphere",
-           "PioneerVectorEnv", "PioneerKinematicEnv", "TimeLimit", "make_env",
+           "PioneerVectorEnv", "PioneerKinematicEnv", "TimeLimit", "make_env", "make_vector_env", "PioneerRLlibVectorEnv",
            "PnrError", "build_library", "load_library"]
 
 
@@ -20,7 +20,10 @@ def __getattr__(name):
     if name == "PioneerVectorEnv":
         from .vector_env import PioneerVectorEnv
         return PioneerVectorEnv
-    if name in ("PioneerKinematicEnv", "TimeLimit", "make_env"):
+    if name in ("PioneerKinematicEnv", "TimeLimit", "make_env", "make_vector_env"):
         from . import env
         return getattr(env, name)
+    if name == "PioneerRLlibVectorEnv":
+        from .rllib_env import PioneerRLlibVectorEnv
+        return PioneerRLlibVectorEnv
     raise AttributeError(name)

@@ -12,7 +12,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # PNR_LIB_PATH: load another build of the library (A/B experiments such as tools/build_variant.py's); default in-tree
 LIB_PATH = os.environ.get("PNR_LIB_PATH") or os.path.join(CSRC, "libpioneer_amd.so")
-SOURCES = ["pnr_api.hip", "pnr_learn.hip", "pnr_host.h", "pnr_env_kernels.h", "pnr_device.h", "pnr_dyn.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pioneer_amd.h")
 
 
@@ -168,11 +167,14 @@ UNITS = {
     "pnr_api.hip": ["pnr_api.hip", "pnr_host.h", "pnr_device.h", "pnr_model.h", "pnr_dyn.h", "pnr_env_kernels.h"],
     "pnr_learn.hip": ["pnr_learn.hip", "pnr_host.h", "pnr_device.h", "pnr_model.h", "pnr_ppo.h", "pnr_mlp.h", "pnr_sampler.h"],
 }
+SOURCES = sorted({f for deps in UNITS.values() for f in deps})      # every file a unit includes: what _stale() watches
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
                "-mllvm", "-amdgpu-kernarg-preload-count=16",      # leading scalar kernel args arrive preloaded in SGPRs
                "-Wall", "-Wno-unused-function"]
 # the sources that define the env-side kernels (what the counter passes under profiles/ were taken on)
 ENV_KERNEL_SOURCES = ["pnr_env_kernels.h", "pnr_device.h", "pnr_model.h", "pnr_dyn.h"]
+# .. and the learner's (profiles/*learner_pmc_traffic.json: the bytes bench.py quotes in ppo_loop.roofline)
+LEARNER_KERNEL_SOURCES = ["pnr_learn.hip", "pnr_mlp.h", "pnr_ppo.h"]
 
 
 def source_fingerprint(files=ENV_KERNEL_SOURCES) -> str:

@@ -305,6 +305,17 @@ int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, i
             if (e != hipSuccess) { (void)hipFree(h->dyn); (void)hipFree(h->state); delete h; return fail(nullptr, PNR_ERR_NOMEM, "hipMalloc(scene) failed: %s", hipGetErrorString(e)); }
         }
     }
+    // The zero fills above run on the NULL stream; the caller's first pnr_reset may be issued on a non-blocking stream (every
+    // torch.cuda.Stream is one), which is not ordered after NULL-stream work, and reset_env reads the episode counters from
+    // these planes.  pnr_create is the one call that synchronises (include/pioneer_amd.h, Conventions): when it returns, the
+    // planes are zero for every stream.
+    e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        if (h->scene) (void)hipFree(h->scene);
+        if (h->dyn) (void)hipFree(h->dyn);
+        (void)hipFree(h->state); delete h;
+        return fail(nullptr, PNR_ERR_HIP, "pnr_create: zero fill of the state planes failed: %s", hipGetErrorString(e));
+    }
 #if PNR_DIAG_BUILD
     { const char* e_ = getenv("PNR_DIAG"); h->diag = e_ ? atoi(e_) : 0; }
 #endif

@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import seeding
+from . import compat, seeding
 from .config import EngineConfig, PioneerKinematicConfig, RenderConfig, SimulationConfig
 from .spaces import Box
 from .vector_env import PioneerVectorEnv
@@ -27,7 +27,10 @@ def arr2str(arr, fmt: str = ".3f") -> str:
     return "[" + ", ".join([f"{x:{fmt}}" for x in arr]) + "]"
 
 
-class PioneerKinematicEnv:
+class PioneerKinematicEnv(compat.GymEnv):
+    """A ``gym.Env`` subclass where gym is importable (bullet_env.py:65, pioneer_knm_env.py:38: RLlib type-checks for it),
+    a plain class with the same surface otherwise; the spaces are real ``gym.spaces.Box`` objects in the first case."""
+
     def __init__(self,
                  headless: bool = True,
                  pioneer_config: Optional[PioneerKinematicConfig] = None,
@@ -69,8 +72,8 @@ class PioneerKinematicEnv:
         self.eps = self._vec.eps                                           # :61
 
         self._obs = self.reset_world()                                     # :69 (+ reset_simulator in BulletEnv.__init__)
-        self.action_space = Box(-self.a_max, self.a_max, dtype=np.float32)  # :72
-        self.observation_space = self.observation_to_space(self.observe())  # :73
+        self.action_space = compat.to_gym_space(Box(-self.a_max, self.a_max, dtype=np.float32))  # :72
+        self.observation_space = compat.to_gym_space(self.observation_to_space(self.observe()))  # :73
         self.reward_range = (-float("inf"), float("inf"))                  # :74
 
     # -- pickling: by constructor arguments, like gym.utils.EzPickle (pioneer_knm_env.py:38, :51) --
@@ -184,17 +187,20 @@ def _rebuild_env(ctor):
     return PioneerKinematicEnv(**ctor)
 
 
-class TimeLimit:
-    """gym.wrappers.TimeLimit semantics (pioneer_knm_train.py:27)."""
+class TimeLimit(compat.GymWrapper):
+    """gym.wrappers.TimeLimit semantics (pioneer_knm_train.py:27); a ``gym.Wrapper`` where gym is importable."""
 
     def __init__(self, env, max_episode_steps: int):
-        self.env = env
+        if compat.HAVE_GYM:
+            super().__init__(env)          # gym.Wrapper: env, spaces, reward_range, metadata
+        else:
+            self.env = env
+            self.action_space = env.action_space
+            self.observation_space = env.observation_space
+            self.reward_range = env.reward_range
+            self.metadata = env.metadata
         self._max_episode_steps = max_episode_steps
         self._elapsed_steps = None
-        self.action_space = env.action_space
-        self.observation_space = env.observation_space
-        self.reward_range = env.reward_range
-        self.metadata = env.metadata
 
     def step(self, action):
         assert self._elapsed_steps is not None, "Cannot call env.step() before calling reset()"
@@ -210,6 +216,8 @@ class TimeLimit:
         return self.env.reset(**kwargs)
 
     def __getattr__(self, name):
+        if name.startswith("_"):           # as gym.Wrapper: private names are not forwarded (and `env` itself may not be set yet)
+            raise AttributeError(name)
         return getattr(self.env, name)
 
 
@@ -221,3 +229,17 @@ def make_env(env_config: Dict) -> TimeLimit:
         penalty_step=float(env_config["penalty_step"]),
     )
     return TimeLimit(PioneerKinematicEnv(pioneer_config=pioneer_config), max_episode_steps=500)
+
+
+def make_vector_env(env_config: Dict):
+    """The same creator for the BATCHED engine: what ``register_env('Pioneer-v1', make_vector_env)`` hands RLlib as a
+    ``ray.rllib.env.VectorEnv`` (pioneer_amd/rllib_env.py).  ``env_config`` carries the reference's three reward keys
+    (pioneer_knm_train.py:20-26) plus ``num_envs`` (default 4 096), ``device``, ``seed``."""
+    from .rllib_env import PioneerRLlibVectorEnv
+    pioneer_config = PioneerKinematicConfig(
+        award_potential_slope=float(env_config["award_potential_slope"]),
+        award_done=float(env_config["award_done"]),
+        penalty_step=float(env_config["penalty_step"]),
+    )
+    return PioneerRLlibVectorEnv(int(env_config.get("num_envs", 4096)), device=env_config.get("device"),
+                                 seed=int(env_config.get("seed", 0)), pioneer_config=pioneer_config, max_episode_steps=500)

@@ -162,3 +162,50 @@ def test_spaces_and_helpers():
     o = Box(-np.inf, np.inf, shape=(137,), dtype=np.float64)
     assert o.shape == (137,) and o.dtype == np.float64
     assert arr2str(np.array([1.0, -2.5])) == "[1.000, -2.500]"     # collections_util.py:13-14
+
+
+def test_optional_base_classes_follow_what_is_importable():
+    """The façade derives from gym.Env / gym.Wrapper / ray.rllib.env.VectorEnv exactly where those packages can be imported
+    (bullet_env.py:65, pioneer_knm_train.py:27) and from object otherwise — decided by importlib.util.find_spec, no stubs."""
+    import collections
+    import importlib.util
+    from pioneer_amd import compat
+    # the mechanism, on modules that do exist / do not exist here
+    assert compat.optional_attr("collections", "OrderedDict") is collections.OrderedDict
+    assert compat.optional_attr("os", "path.join") is os.path.join
+    assert compat.optional_attr("no_such_module_xyz", "Env") is object
+    assert compat.optional_attr("collections", "NoSuchAttr") is object
+    # .. and its outcome in THIS interpreter, whichever it is
+    have_gym = importlib.util.find_spec("gym") is not None
+    have_ray = importlib.util.find_spec("ray") is not None
+    assert compat.HAVE_GYM == have_gym or not have_gym
+    from pioneer_amd.env import PioneerKinematicEnv, TimeLimit
+    from pioneer_amd.rllib_env import PioneerRLlibVectorEnv
+    if have_gym and compat.HAVE_GYM:
+        import gym
+        assert issubclass(PioneerKinematicEnv, gym.Env) and issubclass(TimeLimit, gym.Wrapper)
+    else:
+        assert PioneerKinematicEnv.__mro__[1] is object and TimeLimit.__mro__[1] is object
+    if have_ray and compat.HAVE_RLLIB:
+        from ray.rllib.env.vector_env import VectorEnv
+        assert issubclass(PioneerRLlibVectorEnv, VectorEnv)
+    else:
+        assert PioneerRLlibVectorEnv.__mro__[1] is object
+    # the VectorEnv contract's methods exist either way (RLlib 0.8.x names)
+    for name in ("vector_reset", "reset_at", "vector_step", "get_unwrapped"):
+        assert callable(getattr(PioneerRLlibVectorEnv, name))
+
+
+def test_abi_version_is_the_same_in_every_document():
+    """INTEGRATION.md's binding stub, DESIGN.md's boundary section and the header's changelog all name PNR_ABI_VERSION."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from pioneer_amd import _lib
+    v = _lib.ABI_VERSION
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert re.findall(r"pnr_abi_version\(\) == (\d+)", integ) == [str(v)], "INTEGRATION.md's stub checks another ABI version"
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    assert re.findall(r"ABI version (\d+)", design) and set(re.findall(r"ABI version (\d+)", design)) == {str(v)}
+    header = open(os.path.join(root, "include", "pioneer_amd.h")).read()
+    log = header[header.index("Bumped whenever"):header.index("#define PNR_ABI_VERSION")]
+    assert [int(x) for x in re.findall(r"^ \*\s+(\d+)  ", log, re.M)] == list(range(1, v + 1)), "the header's ABI changelog must list every version"

@@ -54,3 +54,30 @@ def test_a_failing_rank_fails_the_launcher():
     res = _run(["--gpus", "2", "--steps", "10"], env_extra={"PNR_BENCH_DRYRUN_FAIL_RANK": "1"})
     assert res.returncode != 0
     assert not [l for l in res.stdout.splitlines() if '"metric"' in l]
+
+
+def _run_real(extra, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "PNR_BENCH_DRYRUN",
+                                                              "PNR_BENCH_SHARE_GPU")}
+    env.update(OMP_NUM_THREADS="1")
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_more_ranks_than_devices_is_one_clear_line_and_exit_2():
+    """`bench.py --gpus N` on a node with fewer than N devices (the failure of gpurun_out/r03/bench_gpus2.err: rank 1 raised
+    `HIP error: invalid device ordinal` from torch.cuda.set_device): the launcher says what is wrong and exits 2 before any rank
+    starts; a rank started by an outside launcher says the same before its first GPU call."""
+    import torch
+    ndev = torch.cuda.device_count()
+    want = ndev + 2
+    res = _run_real(["--gpus", str(want), "--steps", "5", "--warmup", "1"])
+    assert res.returncode == 2, (res.returncode, res.stderr[-2000:])
+    assert f"--gpus {want} needs {want} visible devices (found {ndev})" in res.stderr
+    assert "torch.distributed.run" not in res.stderr and not res.stdout.strip()
+    # under an existing launcher environment: the rank itself reports it
+    res = _run_real(["--gpus", str(want), "--steps", "5", "--warmup", "1"],
+                    env_extra={"WORLD_SIZE": str(want), "RANK": str(want - 1), "LOCAL_RANK": str(want - 1), "MASTER_ADDR": "127.0.0.1",
+                               "MASTER_PORT": "29999"})
+    assert res.returncode == 2, (res.returncode, res.stderr[-2000:])
+    assert f"needs {want} visible devices (found {ndev})" in res.stderr and "Traceback" not in res.stderr

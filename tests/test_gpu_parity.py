@@ -526,3 +526,67 @@ def test_against_frozen_reference_precision_fixture():
     assert np.array_equal(w[22:], z["state_words"][22:])          # step_index, episode
     assert np.array_equal(w[6:12], z["state_words"][6:12])        # v bit-exact even across precisions
     env.close()
+
+
+def test_rllib_vector_env_adaptor_steps_4096_envs_against_the_oracle():
+    """PioneerRLlibVectorEnv (ray.rllib.env.VectorEnv's contract: lists of float64 rows / floats / bools / dicts, no auto-reset,
+    done = done | TimeLimit cut with info['TimeLimit.truncated'] as gym.wrappers.TimeLimit sets it, reset_at for finished envs)
+    against the oracle driven the way RLlib drives a VectorEnv: step, then reset every env that finished."""
+    from pioneer_amd.rllib_env import PioneerRLlibVectorEnv
+    n, limit = 4096, 12
+    venv = PioneerRLlibVectorEnv(n, device="cuda:0", seed=5, max_episode_steps=limit, info="numeric")
+    orc = COracle(n, seed=5, precision=ORC_DEV, auto_reset=False, max_episode_steps=limit, nthreads=8)
+    obs = venv.vector_reset()
+    oobs = orc.reset()
+    assert isinstance(obs, list) and len(obs) == n and obs[0].dtype == np.float64 and obs[0].shape == (137,)
+    assert venv.num_envs == n and venv.get_unwrapped() == [] and venv.observation_space.dtype == np.float64
+    check_obs(np.stack(obs), oobs)
+    rng = np.random.RandomState(3)
+    seen_trunc = seen_done = 0
+    for t in range(30):
+        act = [rng.uniform(-venv.vec.a_max, venv.vec.a_max).astype(np.float32) for _ in range(n)]     # a list of per-env actions
+        obs, rew, done, infos = venv.vector_step(act)
+        oobs, orew, odone, otrunc = orc.step(np.stack(act))
+        assert isinstance(rew[0], float) and isinstance(done[0], bool) and isinstance(infos[0], dict) and len(infos) == n
+        assert np.array_equal(np.array(done), (odone | otrunc).astype(bool))
+        check_obs(np.stack(obs), oobs)
+        assert np.abs(np.array(rew) - orew).max() <= REW_TOL
+        for i in np.nonzero(otrunc)[0]:
+            assert infos[i]["TimeLimit.truncated"] is True
+        for i in np.nonzero(odone)[0][:50]:
+            assert infos[i].get("TimeLimit.truncated", False) is False
+        quiet = np.nonzero(~(odone | otrunc).astype(bool))[0]
+        assert all("TimeLimit.truncated" not in infos[i] for i in quiet[:200])
+        seen_trunc += int(otrunc.sum()); seen_done += int(odone.sum())
+        fin = np.nonzero(np.array(done))[0]
+        if len(fin):        # RLlib: reset_at for every env it saw finish; the oracle resets the same set
+            mask = np.zeros(n, np.uint8); mask[fin] = 1
+            o_reset = orc.reset(mask=mask)
+            rows = np.stack([venv.reset_at(int(i)) for i in fin])
+            check_obs(rows, o_reset[fin])
+        check_state_exact(venv.vec, orc)
+    assert seen_trunc > n          # every env hit the 12-step limit at least twice in 30 steps
+    venv.close()
+
+
+def test_first_reset_on_a_fresh_non_blocking_stream_sees_the_zeroed_state():
+    """pnr_create zero-fills the state planes on the NULL stream and waits for it (include/pioneer_amd.h, Conventions): a first
+    pnr_reset issued on a fresh torch.cuda.Stream (non-blocking: not ordered after NULL-stream work) must find episode
+    counters of zero — every env's episode word is 1 afterwards and the state equals the default-stream run."""
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    n = 65536
+    ref = PioneerVectorEnv(n, device="cuda:0", seed=9, engine_config=EngineConfig(auto_reset=True))
+    o_ref = ref.reset()
+    w_ref = ref.get_state().cpu().numpy().view(np.uint32)
+    s = torch.cuda.Stream("cuda:0")
+    for _ in range(3):      # a few handles: fresh allocations, the memset freshly queued each time
+        with torch.cuda.stream(s):
+            env = PioneerVectorEnv(n, device="cuda:0", seed=9, engine_config=EngineConfig(auto_reset=True))
+            o = env.reset()
+            w = env.get_state()
+        s.synchronize()
+        w = w.cpu().numpy().view(np.uint32)
+        assert (w[23] == 1).all(), "episode counters must start from the zero fill"
+        assert np.array_equal(w, w_ref) and torch.equal(o, o_ref)
+        env.close()
+    ref.close()
