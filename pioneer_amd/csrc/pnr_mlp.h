@@ -57,6 +57,9 @@ static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implem
 #ifndef PNR_MLP_DIAG
 #define PNR_MLP_DIAG 0
 #endif
+#ifndef PNR_MLP_DEPHASE
+#define PNR_MLP_DEPHASE 0         // > 0: the fused kernel's second workgroup per CU starts this many x 64 cycles late (A/B r04)
+#endif
 #ifndef PNR_MLP_STATIONARY
 #define PNR_MLP_STATIONARY 0      // 1: pnr_mlp_train_step on contiguous inputs runs mlp_train_kernel (weight-stationary; r03f A/B: bit-identical, 58 us
                                   // against mlp_forward_kernel<true>'s 51 us per 32 768-sample update — kept as the measured alternative)
@@ -747,6 +750,18 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
     MlpGemm1<kMlpInPad, kXS> g1;
     g1.prefetch(wp + kOffW1 + w * (kMlpInPad / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
+#if PNR_MLP_DEPHASE
+    if constexpr (FUSED) {
+        // The two workgroups of a CU start together and walk the same phases in lock-step: four waves per SIMD want the matrix pipe
+        // in the product phases and the vector ALU in the epilogues, in turn instead of together.  The second workgroup of every CU
+        // (dispatch order = linear block id: the first 256 take a CU each) starts PNR_MLP_DEPHASE x 64 cycles late.
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((lin >> 8) == 1u) {
+#pragma unroll 1
+            for (int i = 0; i < PNR_MLP_DEPHASE; i += 100) __builtin_amdgcn_s_sleep(100);
+        }
+    }
+#endif
     if constexpr (FUSED) {       // this launch is one optimiser update: counted here, read by the Adam kernel two launches on
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
     }

@@ -67,10 +67,18 @@ def run_trials(num_samples: int, run_one, trial_parallel: bool = False):
     rank, _, world = world_info()
     if not (trial_parallel and is_dist()):
         return [run_one(t) for t in range(num_samples)]
+    # The ranks exchange nothing while they train, so the gather at the end waits for the SLOWEST rank — a whole trial longer than
+    # the fastest when num_samples % world != 0, or however far the trial times drift apart.  The default group's collective
+    # timeout (10 minutes on nccl / RCCL, whose watchdog then aborts the job with no result rows) is the wrong clock for that: the
+    # rows travel through a gloo group of their own (host objects anyway) whose timeout is days.  Created here, while the ranks
+    # are still together.
+    import datetime
+    rows_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(days=7))
     with solo():
         mine = [(t, run_one(t)) for t in range(rank, num_samples, world)]
     gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
+    dist.all_gather_object(gathered, mine, group=rows_group)
+    dist.destroy_process_group(rows_group)
     return [row for _, row in sorted((x for part in gathered for x in part), key=lambda tr: tr[0])]
 
 

@@ -14,6 +14,7 @@ tests, synthetic rollouts) and the numerical reference the kernels are tested ag
 only runs when asked for (``hip_kernels=False``) or for nets of another shape, eagerly.
 """
 import math
+import os
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -268,7 +269,10 @@ class PPOLearner:
         self._flat_grad = None      # several ranks: the gradient bucket that is all-reduced (HIP path)
         self._epochs = 0            # SGD epochs so far: the shuffle's stream id (saved with the optimiser state)
         self._hip_dirty = True      # the packed bf16 weights are stale (construction, restore)
-        self.net_chains = True      # several ranks: the two nets as two SGD chains on two streams (False: one bucket, serial)
+        # several ranks: the two nets as two SGD chains on two streams, each all-reducing its half of the bucket (False: one bucket,
+        # serial).  Bit-identical to the one-bucket form on gloo (tests/test_gpu_multirank.py); its overlap gain and its behaviour
+        # under real RCCL stream semantics are UNMEASURED (no multi-GPU node so far): PNR_NET_CHAINS=0 is the fallback switch.
+        self.net_chains = os.environ.get("PNR_NET_CHAINS", "1") != "0"
         self._net_streams = None
         self._side = None           # the stream the next epoch's gather runs on (HIP path)
 
@@ -520,6 +524,7 @@ class PPOTrainer:
         ec = env.engine_config
         self.resident_rollout = self.hip and ec.mode == "kinematic" and ec.obs_layout == "env_major" and ec.action_layout == "env_major"
         self._graph = None
+        self._eager_collects = 0        # eager (uncaptured) collects done by this trainer object: gates the graph capture
         T, N, D, A = self.cfg.rollout_fragment_length, env.num_envs, self.cfg.obs_dim, self.cfg.act_dim
         f32 = dict(dtype=torch.float32, device=self.device)
         self._env_act = torch.empty((N, A), **f32)
@@ -610,8 +615,10 @@ class PPOTrainer:
     _capturing = False
 
     def collect(self) -> Dict[str, torch.Tensor]:
-        if self.use_graph and self._graph is None and self.iteration >= 1:
-            # capture after one eager iteration (allocator and library warm-up done)
+        if self.use_graph and self._graph is None and self._eager_collects >= 1:
+            # capture after one eager collect BY THIS OBJECT (allocator and library warm-up done: first launches of pnr_ppo_rollout /
+            # pnr_ppo_gae / pnr_filter_prepare, the scratch allocations) — not `self.iteration`, which restore() sets from the
+            # checkpoint: a fresh trainer that restored would otherwise capture on its very first collect
             torch.cuda.synchronize(self.device)
             self._capturing = True
             torch.cuda.manual_seed(self.cfg.seed * 7919 + self.rank + 1)
@@ -624,6 +631,7 @@ class PPOTrainer:
             self._graph.replay()
         else:
             self._collect_impl()
+            self._eager_collects += 1
         # The filter's moment pass runs EAGERLY after the (possibly replayed) loop, never inside a captured graph: a torch
         # reduction over the middle axis of a large tensor returned wrong sums from the second replay of a hipGraph on (r01's
         # "NaNs after graph replay"; layout-dependent, cause not pinned below torch: tools/graph_reduce_probe.py,

@@ -194,3 +194,90 @@ def test_graph_captured_loop_with_an_rccl_process_group(tmp_path):
     assert r["sampling_graph"] and r["hip"] and r["flat_bucket"], r      # HIP learner: reduce -> RCCL all-reduce -> pnr_mlp_adam
     assert r["timesteps_total"] == 5 * 16 * 2048 and r["episodes_total"] > 0
     assert all(np.isfinite(x) for x in r["kl"] + r["total_loss"]), r
+
+
+CONFIG3_WORKER = r'''
+import json, os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["PNR_ROOT"])
+from pioneer_amd import PioneerVectorEnv, EngineConfig
+from pioneer_amd import dist as pdist
+from pioneer_amd.ppo import PPOConfig, PPOTrainer
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device(0)                       # every rank on the box's one GPU; gloo, because RCCL refuses two ranks per device
+dev = torch.device("cuda", 0)
+if world > 1:
+    dist.init_process_group("gloo")
+total, gmbs, iters = int(os.environ["PNR_TOTAL_ENVS"]), int(os.environ["PNR_GLOBAL_MBS"]), int(os.environ.get("PNR_ITERS", "1"))
+start, cnt = pdist.shard_range(total, world, rank)
+env = PioneerVectorEnv(cnt, device=dev, seed=0, env_id_offset=start, engine_config=EngineConfig(max_episode_steps=500, auto_reset=True))
+mbs = gmbs // world
+tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, seed=2), use_graph=False)
+assert tr.learner.hip
+rows = [tr.train() for _ in range(iters)]
+torch.cuda.synchronize()
+w = torch.cat([p.detach().reshape(-1).double().cpu() for p in tr.learner.model.parameters()])
+m, v, step = tr.learner.hip_mlp(1).adam_state()
+r = rows[-1]
+json.dump({"rank": rank, "world": world, "envs": cnt, "mbs": mbs, "chains": bool(world > 1 and tr.learner.net_chains and tr.learner._net_streams is not None),
+           "resident_rollout": bool(tr.resident_rollout), "updates": float(step), "timesteps_total": int(r["timesteps_total"]),
+           "wsum": float(w.sum()), "wabs": float(w.abs().sum()), "msum": float(m.double().sum()), "vsum": float(v.double().sum()),
+           "metrics": {k: float(r[k]) for k in ("kl", "total_loss", "vf_loss", "policy_loss", "entropy")},
+           "episodes_total": int(r["episodes_total"])},
+          open(os.path.join(os.environ["PNR_OUT"], f"c3_{world}_{rank}.json"), "w"))
+env.close()
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run_config3(tmp_path, world, total, gmbs):
+    script = tmp_path / "config3.py"
+    script.write_text(CONFIG3_WORKER)
+    env = dict(os.environ, PNR_ROOT=ROOT, PNR_OUT=str(tmp_path), OMP_NUM_THREADS="2", PNR_TOTAL_ENVS=str(total), PNR_GLOBAL_MBS=str(gmbs))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    if world == 1:
+        res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    else:
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                             env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return [json.load(open(tmp_path / f"c3_{world}_{r}.json")) for r in range(world)]
+
+
+def test_config3_whole_65536_envs_on_two_ranks(tmp_path):
+    """BASELINE configs[3] as a whole, in the only form one GPU allows: 65 536 envs in total on two ranks (32 768 each, gloo, both
+    on this GPU), T = 32, four epochs of 32 768-sample GLOBAL minibatches (16 384 per rank), the two-chain learner with one
+    gradient all-reduce per net and update: 256 updates.  Ranks end bit-identical; against the one-rank run of the same 65 536 envs
+    the update count is the same and the loss means agree statistically — NOT bit for bit: a rank shuffles its own shard and draws
+    its own action noise, so the minibatches hold different samples (the per-update identity of the averaged gradient with one
+    process on the concatenated batch is tests/test_ppo_dist_cpu.py's and test_hip_learner_keeps_two_ranks_in_lock_step's)."""
+    two = _run_config3(tmp_path, 2, 65536, 32768)
+    r0, r1 = two
+    for r in two:
+        assert r["envs"] == 32768 and r["mbs"] == 16384 and r["chains"] and r["resident_rollout"], r
+        assert r["updates"] == 4 * (32 * 32768) // 16384 == 256 and r["timesteps_total"] == 65536 * 32
+        assert all(np.isfinite(x) for x in r["metrics"].values()), r
+    for k in ("wsum", "wabs", "msum", "vsum", "metrics", "episodes_total"):
+        assert r0[k] == r1[k], (k, r0[k], r1[k])                   # lock-step, bit for bit
+    (one,) = _run_config3(tmp_path, 1, 65536, 32768)
+    assert one["updates"] == 256 and one["timesteps_total"] == 65536 * 32 and not one["chains"]
+    for k, tol in (("vf_loss", 0.05), ("total_loss", 0.05), ("entropy", 0.01)):
+        a, b = one["metrics"][k], r0["metrics"][k]
+        assert abs(a - b) <= tol * max(abs(a), abs(b)), (k, a, b)
+    assert abs(one["wabs"] - r0["wabs"]) <= 1e-3 * one["wabs"]       # 256 updates at lr 2e-5 from the same initial weights
+
+
+def test_config3_per_rank_shape_of_eight_gpus_on_two_ranks(tmp_path):
+    """The per-rank shape of configs[3] at N = 8 (8 192 envs and 4 096-sample minibatches per rank, 256 updates per iteration,
+    each with its two 0.43 MB all-reduces), run on the two ranks this box can hold."""
+    two = _run_config3(tmp_path, 2, 16384, 8192)
+    for r in two:
+        assert r["envs"] == 8192 and r["mbs"] == 4096 and r["chains"], r
+        assert r["updates"] == 4 * (32 * 8192) // 4096 == 256 and r["timesteps_total"] == 16384 * 32
+        assert all(np.isfinite(x) for x in r["metrics"].values()), r
+    for k in ("wsum", "wabs", "msum", "vsum", "metrics"):
+        assert two[0][k] == two[1][k], k

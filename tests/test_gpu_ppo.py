@@ -574,3 +574,58 @@ def test_filter_prepare_kernel_equals_the_host_formulation_bit_for_bit(clip):
         f.observe(x); f.sync()
     f.prepare()
     assert bool((f._inv[18:54] == 1e8).all()) and float(f._loc[20]) == -0.75
+
+
+RESTORE_CHILD = r'''
+import json, os, sys, torch
+sys.path.insert(0, os.environ["PNR_ROOT"])
+from pioneer_amd import PioneerVectorEnv, EngineConfig
+from pioneer_amd.ppo import PPOConfig, PPOTrainer
+cfg = PPOConfig(rollout_fragment_length=16, num_sgd_iter=2, sgd_minibatch_size=8192, lr=3e-4, seed=4)
+env = PioneerVectorEnv(2048, device="cuda:0", seed=9, engine_config=EngineConfig(max_episode_steps=25))
+tr = PPOTrainer(env, cfg, use_graph=True)
+tr.restore(os.environ["PNR_CK"], restore_env=True)
+it0 = tr.iteration
+rows, graphs = [], []
+for _ in range(3):
+    rows.append(tr.train()); graphs.append(tr._graph is not None)
+w = torch.cat([p.detach().reshape(-1).double().cpu() for p in tr.learner.model.parameters()])
+json.dump({"iteration_at_restore": it0, "graph_after_each_train": graphs, "kl": [r["kl"] for r in rows], "total_loss": [r["total_loss"] for r in rows],
+           "wsum": float(w.sum()), "wabs": float(w.abs().sum())}, open(os.environ["PNR_OUT"], "w"))
+env.close()
+'''
+
+
+def test_restore_with_graph_capture_in_a_fresh_process_warms_up_eagerly_first(tmp_path):
+    """ADVICE r03: restore() sets `iteration` from the checkpoint, and the graph capture used to be gated on it — a fresh
+    process that restored would have captured the hipGraph on its very first collect, with the first launches and scratch
+    allocations inside stream capture.  The gate is the trainer object's own count of eager collects: the first train() after a
+    restore runs eagerly, the second captures, and the run equals the uninterrupted (eager) one bit for bit."""
+    import json, os, subprocess, sys
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    from pioneer_amd.ppo import PPOConfig, PPOTrainer
+    cfg = PPOConfig(rollout_fragment_length=16, num_sgd_iter=2, sgd_minibatch_size=8192, lr=3e-4, seed=4)
+    env = PioneerVectorEnv(2048, device="cuda:0", seed=9, engine_config=EngineConfig(max_episode_steps=25))
+    a = PPOTrainer(env, cfg)
+    for _ in range(2):
+        a.train()
+    path = a.save(str(tmp_path / "ck.pt"))
+    ref = [a.train() for _ in range(3)]
+    w = torch.cat([p.detach().reshape(-1).double().cpu() for p in a.learner.model.parameters()])
+    env.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(RESTORE_CHILD)
+    out = tmp_path / "child.json"
+    res = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PNR_ROOT=root, PNR_CK=path, PNR_OUT=str(out)),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = json.load(open(out))
+    assert r["iteration_at_restore"] == 2
+    import numpy as np
+    assert r["graph_after_each_train"] == [False, True, True]        # eager warm-up by THIS object, then capture + replay
+    # the eager iteration continues the uninterrupted run bit for bit; from the capture on the action noise comes from the graph's
+    # own generator state (re-seeded at capture, PPOTrainer.collect), so later iterations are another — equally valid — sample path
+    assert r["kl"][0] == ref[0]["kl"] and r["total_loss"][0] == ref[0]["total_loss"]
+    assert all(np.isfinite(x) for x in r["kl"] + r["total_loss"]) and np.isfinite(r["wsum"])
+    assert abs(r["wabs"] - float(w.abs().sum())) <= 1e-2 * float(w.abs().sum())

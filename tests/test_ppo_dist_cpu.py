@@ -198,3 +198,32 @@ def test_trial_parallel_runs_each_trial_on_one_rank_and_gathers_the_rows(tmp_pat
         os.environ.pop(k, None)
     L = PPOLearner(PPOConfig(num_sgd_iter=1, sgd_minibatch_size=32, lr=1e-3, seed=3), "cpu")
     assert L.update(make_batch(64, seed=3), torch.Generator().manual_seed(3))["kl"] == r0["rows"][3]["kl"]
+
+
+def _slow_trial_worker(rank, world, port, out_dir):
+    import datetime
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    # the job's own collective timeout is SHORT (here 4 s; 10 minutes on RCCL): rank 0 runs one more trial than rank 1 and that
+    # trial outlasts it, so rank 1 waits in the final gather for longer than the default group would tolerate
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=4))
+
+    def run_one(t):
+        if t == 2:
+            time.sleep(9.0)
+        return {"trial_id": f"{t:05d}", "rank": pdist.world_info()[0], "real_rank": rank}
+
+    rows = pdist.run_trials(3, run_one, trial_parallel=True)
+    torch.save(rows, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_trial_parallel_gather_outlasts_the_jobs_collective_timeout(tmp_path):
+    """with trial_parallel the ranks exchange nothing until the final gather, so an early rank waits there
+    for a whole trial — longer than the default group's collective timeout.  The rows travel through a gloo group with a timeout
+    of days: one rank running one more (slow) trial than the other still ends with every row on every rank."""
+    port = _free_port()
+    mp.spawn(_slow_trial_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "s0.pt", weights_only=False); r1 = torch.load(tmp_path / "s1.pt", weights_only=False)
+    assert r0 == r1 and [r["trial_id"] for r in r0] == ["00000", "00001", "00002"]
+    assert [r["real_rank"] for r in r0] == [0, 1, 0] and all(r["rank"] == 0 for r in r0)
