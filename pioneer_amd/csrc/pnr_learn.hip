@@ -425,6 +425,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
                         (long long)s->w3_partial_floats, (long long)tiles.x * nets * kW3PartFloats);
         F.w3part = s->w3_partials;
         F.h2 = nullptr;
+        F.g_head = nullptr;          // its only reader outside the tile was the weight-gradient kernel's layer-3 role: 4 MB less per update
     }
 #if PNR_MLP_STAMPS
     F.stamps = g_mlp_stamps;

@@ -686,7 +686,7 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
     // head gradients: entries d and 6 + d of the sample's row (lanes 6, 7: the zero padding 12 .. 15), float32 for the
     // weight-gradient kernel, bf16 for this tile's backward products
     const int e0 = d < kMlpAct ? d : 12 + 2 * (d - 6), e1 = d < kMlpAct ? kMlpAct + d : 13 + 2 * (d - 6);
-    if (b < P.B) {
+    if (b < P.B && P.g_head) {          // (null when nothing outside the tile reads it: layer 3's products are made by the tile itself)
         float* gp = P.g_head + ((size_t)net * P.B + b) * kMlpHead;
         gp[e0] = g0; gp[e1] = g1;
     }
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
         if ((lin >> 8) == 1u) {
 #pragma unroll 1
-            for (int i = 0; i < PNR_MLP_DEPHASE; i += 100) __builtin_amdgcn_s_sleep(100);
+            for (int i = 0; i < PNR_MLP_DEPHASE; i += 8) __builtin_amdgcn_s_sleep(8);
         }
     }
 #endif
@@ -1754,9 +1754,406 @@ __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, in
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// r04: the hot roles of the weight-gradient kernel (dW2 halves; dW1 halves) stage their chunks with DIRECT-TO-LDS loads
+// (global_load_lds_dwordx4, "glds": 1 KiB per wave-instruction, no VGPR destination, no ds_write pass) into a THREE-stage ring,
+// one raw barrier per chunk and counted s_waitcnt vmcnt(N): chunk c + 2 is requested at the start of chunk c's products and has two
+// chunks of MFMAs to arrive, where the register-staged form (PNR_WG_GLDS=0, kept for the A/B) had one chunk of prefetch, two
+// barriers and a VGPR -> LDS write pass per chunk: 3 150 cycles per 64-sample chunk for 16 MFMAs per wave (1 024 cycles of matrix
+// pipe per SIMD), the same for every chunk (profiles/r03_i_wgrad_stamps.json) — a workgroup alone on its CU has nothing else to run
+// while it waits (cdna_hip_programming.md section 5, "Pipelining across barriers": the regime where the 3-buffer span pays).
+// A glds writes LDS lane-linearly (wave-uniform base + 16 lane), so the conflict-free image for the transposed reads cannot be
+// made by padding rows: it is an XOR swizzle applied on the SOURCE address and again on the read (16-byte piece j of row r sits
+// at piece j ^ 4 (r & 3): the four rows a ds_read_b64_tr_b16 half-wave touches land in four different 64-byte bank groups).
+// X rows are 288 bytes (32 mod 256): stored as they are, the four rows overlap pairwise in the banks (2-way conflict on the
+// B-operand reads of the dW1 roles, ~2 of 32 cycles per MFMA gap); db1 comes from a fragment of ones in registers instead of a
+// column of ones in the tile.  The products, their k order and the chunk order are those of the register-staged form: same bits.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef PNR_WG_GLDS
+#define PNR_WG_GLDS 1
+#endif
+constexpr int kWgStages = 3;
+constexpr int kWgStage2 = kWgChunk * 512 + kWgChunk * 256;      // dW2 roles: dZ2 [64][256] | H1 half [64][128], bf16: 48 KB
+constexpr int kWgStage1 = kWgChunk * 256 + kWgChunk * 288;      // dW1 roles: dZ1 half [64][128] | X [64][144]: 34 KB
+constexpr int kWgRingBytes = kWgStages * kWgStage2 + 64;        // (+ slack: the last X block reads 32 bytes past its row)
+constexpr int kWgLdsBytesOld = (kWgChunk * kTrH + kWgChunk * kTrH + kWgChunk * kTrG) * 2;
+constexpr int kWgLdsBytes = PNR_WG_GLDS ? (kWgRingBytes > kWgLdsBytesOld ? kWgRingBytes : kWgLdsBytesOld) : kWgLdsBytesOld;
+
+// one direct-to-LDS piece: lane l's 16 bytes at sbase + voff land at LDS byte address lds_dst + 16 l (lds_dst, sbase wave-uniform).
+// M0 carries the LDS base and is compiler-reserved: written and restored in the same statement (cdna_hip_programming.md, inline asm)
+__device__ __forceinline__ void wg_glds16(unsigned voff, const void* sbase, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ const void* wg_uniform_ptr(const void* p)
+{
+    const unsigned long long b = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return (const void*)(((unsigned long long)hi << 32) | lo);
+}
+// LDS byte address of a __shared__ pointer
+__device__ __forceinline__ unsigned wg_lds_addr(const void* p)
+{
+    typedef char __attribute__((address_space(3))) * lds_c;
+    return (unsigned)(unsigned long long)(lds_c)(p);
+}
+// the fragment of wg_frag32 from a SWIZZLED tile (rows of ROWB bytes, 16-byte piece j of row r at piece j ^ 4 (r & 3)); s0 a multiple of 16
+template <int ROWB>
+__device__ __forceinline__ bf16x8 wg_frag32_swz(const char* tile, int s0, int col0, int lane)
+{
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row = s0 + 8 * (G >> 1) + q;                      // row & 3 == q, and so for row + 4
+    const int cb = (col0 + 16 * (G & 1) + 4 * p) * 2;           // byte of the column inside the row
+    const char* a = tile + row * ROWB + (cb ^ (q << 6));
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * ROWB));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// .. and from a LINEAR tile with rows of ROWB bytes
+template <int ROWB>
+__device__ __forceinline__ bf16x8 wg_frag32_lin(const char* tile, int s0, int col0, int lane)
+{
+    const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const char* a = tile + (s0 + 8 * (G >> 1) + q) * ROWB + (col0 + 16 * (G & 1) + 4 * p) * 2;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * ROWB));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// a swizzled tile's piece i (1 KiB of LDS = 1024 / ROWB rows): the source byte offset of lane `lane` relative to the chunk's first row
+// (global rows GROWB bytes apart, the tile's columns starting at byte col_off of a row)
+template <int ROWB>
+__device__ __forceinline__ unsigned wg_piece_src_swz(int i, int lane, int GROWB, int col_off, int& row)
+{
+    constexpr int kLanesPerRow = ROWB / 16;
+    row = i * (1024 / ROWB) + lane / kLanesPerRow;
+    const int jp = lane % kLanesPerRow;
+    return (unsigned)(row * GROWB + col_off + ((jp ^ (4 * (row & 3))) << 4));
+}
+
+// The ring's schedule, shared by both roles.  NP = this wave's glds instructions per chunk.  Per chunk c:
+//   wait until chunk c's pieces of THIS wave have landed (counted: chunk c + 1's may stay in flight) -> barrier (every wave's pieces
+//   landed; every wave is done reading chunk c - 1) -> request chunk c + 2 into the stage chunk c - 1 used -> multiply chunk c.
+// A chunk that is not whole (only the batch's last one can be) is staged by plain loads and ds_write into the same image, zeros
+// for the rows past the end, at the place its glds would have been issued.
+#if PNR_MLP_STAMPS
+// (diagnostic build) phase stamps of the ring, parked in LDS and flushed at the kernel's end: a stamp written to global memory would be
+// one more operation on the VM counter that the ring's counted waits are written against
+#define WG_RING_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0) stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_RING_STAMP(i) do { } while (0)
+#endif
+template <class ISSUE, class SYNC, class MUL, class PRO>
+__device__ __forceinline__ void wg_ring_loop(long long s_begin, long long s_end, int np, ISSUE&& issue, SYNC&& stage_sync, MUL&& multiply,
+                                             PRO&& prologue_work, unsigned long long* stamps = nullptr)
+{
+    const int nch = (int)((s_end - s_begin + kWgChunk - 1) / kWgChunk);
+    const auto whole = [&](int c) { return s_begin + (long long)(c + 1) * kWgChunk <= s_end; };
+    const auto request = [&](int c, int stage) {
+        if (whole(c)) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) issue(c, stage, k);
+        } else stage_sync(c, stage);
+    };
+    if (nch > 0) request(0, 0);
+    if (nch > 1) request(1, 1);
+    // work that does not depend on the chunks (the layer-3 partial sums) runs while the first chunk travels.  Its loads and stores are
+    // further operations on the VM counter: they can only make a counted wait below wait for MORE than the pieces it names
+    prologue_work();
+    int stage = 0;
+    WG_RING_STAMP(1);
+    for (int c = 0; c < nch; ++c) {
+        // outstanding glds of this wave that may stay in flight: those of chunk c + 1 (if it was requested by glds)
+        const int ahead = (c + 1 < nch && whole(c + 1)) ? np : 0;
+        if (c >= 4 && c < 8) WG_RING_STAMP(2 + 4 * (c - 4));          // top of the chunk
+        if (ahead == 0) wg_wait_vm<0>();
+        else if (ahead == 2) wg_wait_vm<2>();
+        else if (ahead == 4) wg_wait_vm<4>();
+        else if (ahead == 5) wg_wait_vm<5>();
+        else wg_wait_vm<6>();
+        if (c >= 4 && c < 8) WG_RING_STAMP(3 + 4 * (c - 4));          // its pieces landed
+        mlp_barrier();
+        if (c >= 4 && c < 8) WG_RING_STAMP(4 + 4 * (c - 4));          // barrier passed
+        const int nstage = stage == 0 ? 2 : stage - 1;                // the stage chunk c - 1 used: every wave is done with it
+        const bool glds_next = c + 2 < nch && whole(c + 2);
+        if (c + 2 < nch && !glds_next) stage_sync(c + 2, nstage);
+        if (c >= 4 && c < 8) WG_RING_STAMP(5 + 4 * (c - 4));
+        // chunk c + 2's pieces are requested from INSIDE the products, a piece or two behind each k-step's MFMAs: issuing the six
+        // of them in one go cost 650 cycles per chunk in which the wave issued no MFMA (profiles/r04_b_wgrad_ring_stamps.json)
+        multiply(stage, [&](int k) { if (glds_next) issue(c + 2, nstage, k); });
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    WG_RING_STAMP(20);
+}
+
+// A wave's 32x32 accumulator block to a row-major float32 matrix through a wave-private LDS tile: 16-byte stores, eight lanes per
+// 128-byte row segment (wg_store_block's one dword per lane cost ~96 cycles of issue per instruction: 6 000 cycles per dW2 wave).
+constexpr int kWgTrS = 36;                                       // floats per row of the transposing tile (144 B: 16-byte aligned)
+__device__ __forceinline__ void wg_store_block_lds(float* scratch, float* __restrict__ m, int ld, int row0, int col0, int ncols, const f32x16& a, int lane)
+{
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) scratch[((i & 3) + 8 * (i >> 2) + 4 * h) * kWgTrS + c] = a[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private tile: the wave's own DS operations complete in order
+    const int r = lane >> 3, q = lane & 7;
+#pragma unroll
+    for (int pss = 0; pss < 4; ++pss) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (r + 8 * pss) * kWgTrS + 4 * q);
+        if (col0 + 4 * q < ncols) {
+            f32x4* dst = reinterpret_cast<f32x4*>(m + (size_t)(row0 + r + 8 * pss) * ld + col0 + 4 * q);
+#if PNR_SLAB_NT
+            __builtin_nontemporal_store(v, dst);
+#else
+            *dst = v;
+#endif
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the reads are done before the next block overwrites the tile
+}
+
+// The fused kernel's per-tile layer-3 products of this slice (dW3 | db2 | db3, kW3PartFloats per tile), added in tile order: part `part`
+// of `parts` takes that share of the elements, a thread ONE quad of them.  Two steps: the (at most 16) tiles' 16-byte pieces are
+// REQUESTED before the ring starts and ADDED after it — one memory round trip (2-4 us under load) for a handful of threads, which as
+// a serial step cost the whole workgroup that time wherever it stood (profiles/r04_b_wgrad_ring_stamps.json: 8 000 cycles in front of
+// the loop, 7 400 behind it); now it travels under the products.
+struct WgW3Sums {
+    static constexpr int kTiles = 16;
+    f32x4 x[kTiles];
+    int q;                    // this thread's quad, or -1
+    long long extra0, t1;     // tiles beyond the first 16 (none at the loop's slice size): added synchronously in finish()
+    const float* pp; size_t stride;
+    __device__ __forceinline__ void request(const MlpWgradParams& P, long long s_begin, long long s_end, int part, int parts, int tid)
+    {
+        const int quads = kW3PartFloats / 4 / parts;              // 273 with four parts: one per thread
+        q = tid < quads ? part * quads + tid : -1;
+        const long long t0 = s_begin / kWgChunk;
+        t1 = (s_end + kWgChunk - 1) / kWgChunk;
+        stride = (size_t)P.n_nets * kW3PartFloats;
+        pp = P.w3part + ((size_t)t0 * P.n_nets + blockIdx.z) * kW3PartFloats + 4 * (q < 0 ? 0 : q);
+        extra0 = t0 + kTiles;
+#pragma unroll
+        for (int j = 0; j < kTiles; ++j) x[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q < 0) return;
+        if (t0 + kTiles <= t1) {                                  // the usual case, one uniform test: sixteen requests back to back (written
+            // with a test per tile, hipcc branched around every load and made the first one wait for its data before the next was issued)
+            const float* a = pp;
+#pragma unroll
+            for (int j = 0; j < kTiles; ++j) { x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a)); a += stride; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kTiles; ++j)
+                if (t0 + j < t1) x[j] = *reinterpret_cast<const f32x4*>(pp + (size_t)j * stride);
+        }
+    }
+    __device__ __forceinline__ void finish(float* slab) const
+    {
+        if (q < 0) return;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        const long long t0 = extra0 - kTiles;
+#pragma unroll
+        for (int j = 0; j < kTiles; ++j) if (t0 + j < t1) sum += x[j];
+        for (long long t = extra0; t < t1; ++t) sum += *reinterpret_cast<const f32x4*>(pp + (size_t)(t - t0) * stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 4 * q + j;
+            slab[e < kMlpHead * kMlpHid ? kGW3 + e : (e < kMlpHead * kMlpHid + kMlpHid ? kGB2 + (e - kMlpHead * kMlpHid) : kGB3 + (e - kMlpHead * kMlpHid - kMlpHid))] = sum[j];
+        }
+    }
+};
+static_assert(kW3PartFloats / 4 / kWgParts <= kWgThreads && kW3PartFloats % (4 * kWgParts) == 0, "one quad of the layer-3 partials per thread and role");
+
+// dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half] of one slice; waves 4 x 2, each 64 (o) x 64 (i)
+__device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ring, int part, size_t nb, long long s_begin, long long s_end,
+                                               float* slab, int tid, unsigned long long* stamps = nullptr)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    const int wo = w >> 1, wi = w & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // this wave's pieces of a chunk: A (dZ2, 32 pieces of two 512-byte rows) w, w + 8, w + 16, w + 24; B (H1 half, 16 pieces of four
+    // 256-byte rows) w, w + 8.  The per-lane source offsets do not depend on the chunk.
+    unsigned offA[4], offB[2];
+    int rowA[4], rowB[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) offA[k] = wg_piece_src_swz<512>(w + 8 * k, lane, kMlpHid * 2, 0, rowA[k]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) offB[k] = wg_piece_src_swz<256>(w + 8 * k, lane, kMlpHid * 2, 256 * part, rowB[k]);
+    const char* gA = reinterpret_cast<const char*>(P.dz2 + nb);
+    const char* gB = reinterpret_cast<const char*>(P.h1 + nb);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(wg_lds_addr(ring));
+    // piece k of this wave's six (0..3: dZ2, 4..5: H1) of chunk c into stage `stage`
+    const auto issue = [&](int c, int stage, int k) {
+        const long long s = s_begin + (long long)c * kWgChunk;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + stage * kWgStage2 + w * 1024);
+        if (k < 4) wg_glds16(offA[k], wg_uniform_ptr(gA + s * (kMlpHid * 2)), dst + k * 8192);
+        else wg_glds16(offB[k - 4], wg_uniform_ptr(gB + s * (kMlpHid * 2)), dst + kWgChunk * 512 + (k - 4) * 8192);
+    };
+    const auto stage_sync = [&](int c, int stage) {
+        const long long s = s_begin + (long long)c * kWgChunk;
+        char* dst = ring + stage * kWgStage2 + w * 1024 + lane * 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (s + rowA[k] < s_end) v = *reinterpret_cast<const uint4*>(gA + s * (kMlpHid * 2) + offA[k]);
+            *reinterpret_cast<uint4*>(dst + k * 8192) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (s + rowB[k] < s_end) v = *reinterpret_cast<const uint4*>(gB + s * (kMlpHid * 2) + offB[k]);
+            *reinterpret_cast<uint4*>(dst + kWgChunk * 512 + k * 8192) = v;
+        }
+    };
+    const auto multiply = [&](int stage, auto&& piece) {
+        const char* ta = ring + stage * kWgStage2;
+        const char* tb = ta + kWgChunk * 512;
+        bf16x8 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) fa[0][a] = wg_frag32_swz<512>(ta, 0, 64 * wo + 32 * a, lane);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[0][b] = wg_frag32_swz<256>(tb, 0, 64 * wi + 32 * b, lane);
+#pragma unroll
+        for (int ks = 0; ks < kWgChunk / 16; ++ks) {
+            if (ks + 1 < kWgChunk / 16) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = wg_frag32_swz<512>(ta, 16 * (ks + 1), 64 * wo + 32 * a, lane);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = wg_frag32_swz<256>(tb, 16 * (ks + 1), 64 * wi + 32 * b, lane);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else piece(ks + 2);      // six pieces over the four k-steps: 2, 2, 1, 1
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    WgW3Sums w3;
+    w3.q = -1;
+    // (requested BEHIND the first two chunks' pieces: in front of them, 28 vector-memory instructions per wave filled the CU's queue
+    // and the pieces' issue waited a memory round trip for room — 8 700 cycles from the kernel's start to the loop against 2 750)
+    wg_ring_loop(s_begin, s_end, 6, issue, stage_sync, multiply, [&] { if (P.w3part) w3.request(P, s_begin, s_end, part, kWgParts, tid); }, stamps);
+    if (P.w3part) w3.finish(slab);
+    mlp_barrier();                                               // every wave is done with the ring: its memory carries the stores' tiles
+    float* scratch = reinterpret_cast<float*>(ring) + w * (32 * kWgTrS);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            wg_store_block_lds(scratch, slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
+}
+
+// dW1[128 half .. +128, :] = dZ1[:, that half]^T . X and db1 of one slice; waves 4 (row blocks) x 2 (column groups: X blocks 0-2 | blocks
+// 3-4 and db1 from a fragment of ones).  Every element's products are accumulated in the order of the register-staged form.
+__device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ring, int half, size_t nb, long long s_begin, long long s_end,
+                                               float* slab, int tid, unsigned long long* stamps = nullptr)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    const int rb = w & 3, cg = w >> 2;
+    f32x16 acc[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    // pieces: A (dZ1 half, 16 pieces of four 256-byte rows) w, w + 8; X (64 rows of 288 bytes = 18 pieces, copied as they lie) w, w + 8
+    // and, for waves 0 and 1, 16 + w
+    unsigned offA[2];
+    int rowA[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) offA[k] = wg_piece_src_swz<256>(w + 8 * k, lane, kMlpHid * 2, 256 * half, rowA[k]);
+    const int nx = w < 2 ? 3 : 2;
+    const char* gA = reinterpret_cast<const char*>(P.dz1 + nb);
+    const char* gX = reinterpret_cast<const char*>(P.xs);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane(wg_lds_addr(ring));
+    // piece k of this wave's (0..1: dZ1 half, 2..4: X; waves 2.. have no piece 4, nobody a piece 5) of chunk c into stage `stage`
+    const auto issue = [&](int c, int stage, int k) {
+        const long long s = s_begin + (long long)c * kWgChunk;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + stage * kWgStage1 + w * 1024);
+        if (k < 2) wg_glds16(offA[k], wg_uniform_ptr(gA + s * (kMlpHid * 2)), dst + k * 8192);
+        else if (k - 2 < nx) wg_glds16((unsigned)((w + 8 * (k - 2)) * 1024 + lane * 16), wg_uniform_ptr(gX + s * (kMlpInPad * 2)), dst + kWgChunk * 256 + (k - 2) * 8192);
+    };
+    const auto stage_sync = [&](int c, int stage) {
+        const long long s = s_begin + (long long)c * kWgChunk;
+        char* dst = ring + stage * kWgStage1 + w * 1024 + lane * 16;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (s + rowA[k] < s_end) v = *reinterpret_cast<const uint4*>(gA + s * (kMlpHid * 2) + offA[k]);
+            *reinterpret_cast<uint4*>(dst + k * 8192) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < nx) {
+                const int o = (w + 8 * k) * 1024 + lane * 16;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (s + o / (kMlpInPad * 2) < s_end) v = *reinterpret_cast<const uint4*>(gX + s * (kMlpInPad * 2) + o);
+                *reinterpret_cast<uint4*>(dst + kWgChunk * 256 + k * 8192) = v;
+            }
+        }
+    };
+    const bf16x8 ones = bf16x8_ones();
+    const auto multiply = [&](int stage, auto&& piece) {
+        const char* ta = ring + stage * kWgStage1;
+        const char* tb = ta + kWgChunk * 256;
+#pragma unroll
+        for (int ks = 0; ks < kWgChunk / 16; ++ks) {
+            const bf16x8 fa = wg_frag32_swz<256>(ta, 16 * ks, 32 * rb, lane);
+            if (cg == 0) {
+                bf16x8 fb[3];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) fb[b] = wg_frag32_lin<kMlpInPad * 2>(tb, 16 * ks, 32 * b, lane);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+            } else {
+                bf16x8 fb[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) fb[b] = wg_frag32_lin<kMlpInPad * 2>(tb, 16 * ks, 32 * (3 + b), lane);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, acc[2], 0, 0, 0);      // every column: db1 of this wave's rows
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else if (ks == 2) piece(4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // (np differs by wave: 5 glds per chunk for waves 0 and 1, 4 for the others — wave-uniform)
+    WgW3Sums w3;
+    wg_ring_loop(s_begin, s_end, 2 + nx, issue, stage_sync, multiply, [&] { w3.request(P, s_begin, s_end, 2 + half, kWgParts, tid); }, stamps);
+    w3.finish(slab);
+    mlp_barrier();
+    float* scratch = reinterpret_cast<float*>(ring) + w * (32 * kWgTrS);
+    const int row0 = 128 * half + 32 * rb;
+    if (cg == 0) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) wg_store_block_lds(scratch, slab + kGW1, kMlpInPad, row0, 32 * b, kMlpInPad, acc[b], lane);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) wg_store_block_lds(scratch, slab + kGW1, kMlpInPad, row0, 32 * (3 + b), kMlpInPad, acc[b], lane);
+        if ((lane & 31) == 0) {
+            const int hh = lane >> 5;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[2][i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradParams P)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[kWgChunk * kTrH + kWgChunk * kTrH + kWgChunk * kTrG];
+    __shared__ __attribute__((aligned(1024))) char lds_raw[kWgLdsBytes];
+    __bf16* lds = reinterpret_cast<__bf16*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int slice = blockIdx.x, part = blockIdx.y, net = blockIdx.z + P.first_net;
     const long long s_begin = (long long)slice * P.slice_rows;
@@ -1765,7 +2162,27 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
     float* slab = P.slabs + ((size_t)slice * kMlpNets + net) * kGradElems;
     const size_t nb = (size_t)net * P.B * kMlpHid;
 
-    if (part < 2) {
+#if PNR_MLP_STAMPS
+    __shared__ unsigned long long wg_stamp_lds[8][kMlpStampSlots];
+    unsigned long long* my_stamps = P.stamps ? wg_stamp_lds[w] : nullptr;
+    if (my_stamps && lane < kMlpStampSlots) my_stamps[lane] = 0ull;
+    const auto flush_stamps = [&]() {
+        if (my_stamps) {
+            if (lane == 0) { my_stamps[22] = __builtin_amdgcn_s_memtime(); my_stamps[25] = __builtin_amdgcn_s_memrealtime(); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < kMlpStampSlots)
+                P.stamps[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + w) * kMlpStampSlots + lane] = my_stamps[lane];
+        }
+    };
+    if (my_stamps && lane == 0) { my_stamps[0] = __builtin_amdgcn_s_memtime(); my_stamps[24] = __builtin_amdgcn_s_memrealtime(); }
+#else
+    unsigned long long* my_stamps = nullptr;
+    const auto flush_stamps = [] {};
+#endif
+    if (PNR_WG_GLDS && part < 2) {
+        wgrad_dw2_glds(P, lds_raw, part, nb, s_begin, s_end, slab, tid, my_stamps);
+        flush_stamps();
+    } else if (part < 2) {
         // dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half]; waves 4 x 2, each 64 (o) x 64 (i)
         __bf16* ta = lds;                        // dZ2 chunk [64][256], stride kTrH
         __bf16* tb = lds + kWgChunk * kTrH;      // H1 chunk [64][128], stride kTrHalf
@@ -1832,70 +2249,74 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
         // (column groups: blocks 0-2 | blocks 3-4 of X's 160 columns).  Every element's products are accumulated in the same order as in the
         // one-role form below: the same bits.
         const int half = part - 2;
-        __bf16* ta = lds;                        // dZ1 chunk, this half's columns: [64][128], stride kTrHalf
-        __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
-        WG_STAMP(0);
-        const int rb = w & 3, cg = w >> 2;       // row block of the half, column group
-        f32x16 acc[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-        WgChunk<128> ca; WgChunk<kMlpInPad> cb;
-        ca.load(P.dz1 + nb + 128 * half, kMlpHid, s_begin, s_end, tid);
-        cb.load(P.xs, kMlpInPad, s_begin, s_end, tid);
-        for (long long s = s_begin; s < s_end; s += kWgChunk) {
-            mlp_barrier();
-            ca.store(ta, kTrHalf, tid); cb.store(tb, kTrX, tid);
-            if (tid < kWgChunk) {                                     // columns 144..159: a one (real rows only), zeros
-                bf16x8 one = {(__bf16)((s + tid < s_end) ? 1.0f : 0.0f), (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad) = one;
-                *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad + 8) = zero;
+        if (PNR_WG_GLDS) {
+            wgrad_dw1_glds(P, lds_raw, half, nb, s_begin, s_end, slab, tid, my_stamps);
+        } else {
+            __bf16* ta = lds;                        // dZ1 chunk, this half's columns: [64][128], stride kTrHalf
+            __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
+            WG_STAMP(0);
+            const int rb = w & 3, cg = w >> 2;       // row block of the half, column group
+            f32x16 acc[3];
+    #pragma unroll
+            for (int b = 0; b < 3; ++b)
+    #pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+            WgChunk<128> ca; WgChunk<kMlpInPad> cb;
+            ca.load(P.dz1 + nb + 128 * half, kMlpHid, s_begin, s_end, tid);
+            cb.load(P.xs, kMlpInPad, s_begin, s_end, tid);
+            for (long long s = s_begin; s < s_end; s += kWgChunk) {
+                mlp_barrier();
+                ca.store(ta, kTrHalf, tid); cb.store(tb, kTrX, tid);
+                if (tid < kWgChunk) {                                     // columns 144..159: a one (real rows only), zeros
+                    bf16x8 one = {(__bf16)((s + tid < s_end) ? 1.0f : 0.0f), (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                    *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad) = one;
+                    *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad + 8) = zero;
+                }
+                mlp_barrier();
+                if (s + kWgChunk < s_end) {
+                    ca.load(P.dz1 + nb + 128 * half, kMlpHid, s + kWgChunk, s_end, tid);
+                    cb.load(P.xs, kMlpInPad, s + kWgChunk, s_end, tid);
+                }
+    #pragma unroll
+                for (int ks = 0; ks < kWgChunk / 16; ++ks) {
+                    const bf16x8 fa = wg_frag32(ta, kTrHalf, 16 * ks, 32 * rb, lane);
+                    if (cg == 0) {
+                        bf16x8 fb[3];
+    #pragma unroll
+                        for (int b = 0; b < 3; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * b, lane);
+    #pragma unroll
+                        for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+                    } else {
+                        bf16x8 fb[2];
+    #pragma unroll
+                        for (int b = 0; b < 2; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * (3 + b), lane);
+    #pragma unroll
+                        for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+                    }
+                }
             }
-            mlp_barrier();
-            if (s + kWgChunk < s_end) {
-                ca.load(P.dz1 + nb + 128 * half, kMlpHid, s + kWgChunk, s_end, tid);
-                cb.load(P.xs, kMlpInPad, s + kWgChunk, s_end, tid);
-            }
-#pragma unroll
-            for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-                const bf16x8 fa = wg_frag32(ta, kTrHalf, 16 * ks, 32 * rb, lane);
+            {
+                const int row0 = 128 * half + 32 * rb;
                 if (cg == 0) {
-                    bf16x8 fb[3];
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * b, lane);
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+    #pragma unroll
+                    for (int b = 0; b < 3; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * b, kMlpInPad, acc[b], lane);
                 } else {
-                    bf16x8 fb[2];
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * (3 + b), lane);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+    #pragma unroll
+                    for (int b = 0; b < 2; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * (3 + b), kMlpInPad, acc[b], lane);
+                    // column 144 of the product = db1: lane c == 16 of column block 4
+                    if ((lane & 31) == 16) {
+                        const int hh = lane >> 5;
+    #pragma unroll
+                        for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[1][i];
+                    }
                 }
             }
         }
-        {
-            const int row0 = 128 * half + 32 * rb;
-            if (cg == 0) {
-#pragma unroll
-                for (int b = 0; b < 3; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * b, kMlpInPad, acc[b], lane);
-            } else {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * (3 + b), kMlpInPad, acc[b], lane);
-                // column 144 of the product = db1: lane c == 16 of column block 4
-                if ((lane & 31) == 16) {
-                    const int hh = lane >> 5;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[1][i];
-                }
-            }
-        }
-        {   // the fused kernel's per-tile layer-3 products of this slice, added in tile order: each of the two roles takes half of the
+        if (!PNR_WG_GLDS) {   // the fused kernel's per-tile layer-3 products of this slice, added in tile order: each of the two roles takes half of the
             // elements, a thread a quad of them — the 16 tiles' 16-byte pieces requested together (one round trip instead of the
-            // 2 x 4 of an element at a time, eight tiles in flight)
-            static_assert(kW3PartFloats % 8 == 0, "halves of whole quads");
+            // 2 x 4 of an element at a time, eight tiles in flight).  (The glds roles each add a QUARTER, while their first chunk travels.)
+            static_assert(kW3PartFloats % 16 == 0, "quarters of whole quads");
             const long long t0 = s_begin / kWgChunk, t1 = (s_end + kWgChunk - 1) / kWgChunk;
             const size_t stride = (size_t)P.n_nets * kW3PartFloats;
             for (int q = half * (kW3PartFloats / 8) + tid; q < (half + 1) * (kW3PartFloats / 8); q += kWgThreads) {
@@ -1917,7 +2338,7 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
                 }
             }
         }
-        WG_STAMP(22);
+        if (PNR_WG_GLDS) flush_stamps(); else { WG_STAMP(22); }
     } else if (part == 2) {
         // dW1 = dZ1^T . X (144 columns) and db1 = dZ1^T . 1 (the tile's column 144 is all ones); wave w: rows 32w..
         __bf16* ta = lds;                        // dZ1 chunk [64][256]
