@@ -37,8 +37,10 @@ extern "C" {
  *   2  pnr_ppo_loss gained `idx` (argument 2) and `means` (before `stream`); pnr_config grew (guarded by struct_size)
  *   3  pnr_mlp_step gained first_net / n_nets (the two nets as two chains) and w3_partials / w3_partial_floats (layer 3's
  *      weight-gradient partials made by the fused kernel); new entry points pnr_ppo_rollout (the sampler's T steps as one
- *      resident launch), pnr_filter_prepare, pnr_mlp_w3_partial_floats */
-#define PNR_ABI_VERSION 3
+ *      resident launch), pnr_filter_prepare, pnr_mlp_w3_partial_floats
+ *   4  float32-accurate operands for the MLP kernels: pnr_mlp_pack / pnr_mlp_forward / pnr_mlp_act / pnr_mlp_gather gained `planes`
+ *      (before `stream`), pnr_mlp_step gained `planes`; pnr_create waits for its zero fill (Conventions) */
+#define PNR_ABI_VERSION 4
 
 #define PNR_DOF 6          /* revolute joints of pioneer_knm_6dof.urdf:209-264 */
 #define PNR_OBS_DIM 137    /* pioneer_knm_env.py:194-211 (26 pieces)         */
@@ -345,10 +347,20 @@ int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, 
 int64_t pnr_mlp_pack_elems(void);
 int64_t pnr_mlp_bias_elems(void);
 int64_t pnr_mlp_slab_floats(int64_t batch);
-int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value, void* wpack, float* bias, void* stream);
+/*
+ * `planes` (ABI 4; 1, 2 or 3) selects the precision of every MFMA operand of the pnr_mlp_* kernels.  1: bf16 operands (8 significant
+ * bits), float32 accumulation — the fast path.  2 / 3: each float32 operand is carried as the sum of 2 / 3 bf16 planes (16 / 24
+ * significant bits; 3 = the accuracy of a float32 GEMM, what the reference's float32 learner computes in,
+ * pioneer_knm_train.py:47) and a product takes the 3 / 6 bf16 MFMAs of the plane pairs, accumulated in float32.  Every bf16 operand
+ * buffer then exists `planes` times, plane-major: wpack [planes][pnr_mlp_pack_elems()], xs / xs_out / xs_in [planes][batch][144],
+ * h1 / h2 / dz1 / dz2 [planes][2][batch][256].  Biases, heads, slabs, Adam state and master weights are float32 either way.
+ * planes > 1: pnr_mlp_forward / pnr_mlp_act save no activations (xs, h1, h2 / xs_out must be NULL: pnr_mlp_backward is bf16-only and
+ * the learner gathers its inputs from the float32 observations), pnr_mlp_gather takes no xs_rows, pnr_mlp_train_step needs w3_partials.
+ */
+int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value, void* wpack, float* bias, int32_t planes, void* stream);
 int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const float* f_loc, const float* f_inv,
                     const float* f_lo, const float* f_hi, const void* wpack, const float* bias, float* head,
-                    void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, void* stream);
+                    void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, int32_t planes, void* stream);
 /*
  * The sampler's per-step launch: both nets forward on `obs` [batch][137] and, in the policy net's last epilogue, the
  * action draw of RLlib's DiagGaussian (what the reference's PPO config samples with): log_std = clamp(raw, -20, 2),
@@ -360,7 +372,7 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
  */
 int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
                 const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
-                float* log_std, float* values, float* actions, float* env_actions, void* xs_out, void* stream);
+                float* log_std, float* values, float* actions, float* env_actions, void* xs_out, int32_t planes, void* stream);
 /*
  * The sampler's closed loop as ONE resident launch: T x (pnr_mlp_act, pnr_step) for every env of handle `h` — per step both nets
  * on the observation in slot t of `obs`, the DiagGaussian draw and clip as in pnr_mlp_act, then BulletEnv.step
@@ -425,6 +437,10 @@ typedef struct pnr_mlp_step {
     int64_t w3_partial_floats; /* weight-gradient products per 64-sample tile there (17 KB) instead of storing H2 (32 KB per tile) for the
                              * weight-gradient kernel, which adds them in tile order: the same sums bit for bit, 30 % fewer bytes in that
                              * kernel.  NULL: H2 is stored to h2 and read back (h2 must be given either way) */
+    int32_t planes;         /* 0 or 1: bf16 operands; 2, 3: split float32 operands (see pnr_mlp_pack): wpack, xs_in / xs, h1, dz1, dz2 hold
+                             * `planes` planes, w3_partials must be given, Adam refreshes every plane of wpack */
+    int64_t xs_in_plane;    /* planes > 1: elements between two planes of xs_in; 0 = batch * 144.  (A minibatch inside an epoch's
+                             * gathered planes [planes][rows][144]: xs_in = plane 0's first row of it, xs_in_plane = rows * 144) */
 } pnr_mlp_step;
 int64_t pnr_mlp_w3_partial_floats(int64_t batch);
 /*
@@ -444,7 +460,7 @@ int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const fl
                    const float* f_hi, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
                    const float* adv, const float* value_target, const float* value_old, void* xs_out, float* actions_out,
                    float* logp_out, float* mean_out, float* log_std_out, float* adv_out, float* value_target_out,
-                   float* value_old_out, const float* record_rows, const void* xs_rows, void* stream);
+                   float* value_old_out, const float* record_rows, const void* xs_rows, int32_t planes, void* stream);
 int64_t pnr_mlp_grad_floats(void);
 int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream);
 int pnr_mlp_adam(const pnr_mlp_step* s, const float* flat_grad, float grad_scale, void* stream);

@@ -114,6 +114,7 @@ class PnrMlpStep(C.Structure):
         ("means", C.c_void_p), ("flat_grad", C.c_void_p), ("xs_in", C.c_void_p),
         ("first_net", C.c_int32), ("n_nets", C.c_int32),
         ("w3_partials", C.c_void_p), ("w3_partial_floats", C.c_int64),
+        ("planes", C.c_int32), ("xs_in_plane", C.c_int64),
     ]
 
 
@@ -140,8 +141,8 @@ SIGNATURES = {
     "pnr_mlp_bias_elems": (C.c_int64, []),
     "pnr_mlp_slab_floats": (C.c_int64, [C.c_int64]),
     "pnr_mlp_w3_partial_floats": (C.c_int64, [C.c_int64]),
-    "pnr_mlp_pack": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP]),
-    "pnr_mlp_forward": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_int32, C.c_int32, _VP]),
+    "pnr_mlp_pack": (C.c_int, [_VP, C.c_int32, C.c_int32, _VP, _VP, C.c_int32, _VP]),
+    "pnr_mlp_forward": (C.c_int, [C.c_int64] + [_VP] * 12 + [C.c_int32, C.c_int32, C.c_int32, _VP]),
     "pnr_ppo_gae_scratch": (C.c_int64, [C.c_int64]),
     "pnr_ppo_gae": (C.c_int, [C.c_int32, C.c_int64] + [_VP] * 8 + [C.c_double, C.c_double] + [_VP] * 6),
     "pnr_filter_moments_scratch": (C.c_int64, [C.c_int64]),
@@ -149,12 +150,12 @@ SIGNATURES = {
     "pnr_filter_merge": (C.c_int, [_VP] * 8),
     "pnr_filter_prepare": (C.c_int, [_VP, _VP, _VP, C.c_double, _VP, _VP, _VP, _VP, _VP]),
     "pnr_permutation": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, _VP, _VP]),
-    "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 17),
+    "pnr_mlp_act": (C.c_int, [C.c_int64] + [_VP] * 16 + [C.c_int32, _VP]),
     "pnr_ppo_rollout": (C.c_int, [_VP, C.c_int32] + [_VP] * 18),
     "pnr_mlp_backward": (C.c_int, [C.c_int64] + [_VP] * 8 + [C.c_int64, _VP, C.c_int32, C.c_int32, C.c_int32, _VP, _VP]),
     "pnr_mlp_grad_floats": (C.c_int64, []),
     "pnr_ppo_pack_record": (C.c_int, [C.c_int64] + [_VP] * 11),
-    "pnr_mlp_gather": (C.c_int, [C.c_int64] + [_VP] * 24),
+    "pnr_mlp_gather": (C.c_int, [C.c_int64] + [_VP] * 23 + [C.c_int32, _VP]),
     "pnr_mlp_train_step": (C.c_int, [C.POINTER(PnrMlpStep), _VP]),
     "pnr_mlp_adam": (C.c_int, [C.POINTER(PnrMlpStep), _VP, C.c_float, _VP]),
     "pnr_num_envs": (C.c_int64, [_VP]),

@@ -93,9 +93,12 @@ int64_t pnr_mlp_slab_floats(int64_t batch)
 int64_t pnr_mlp_pack_elems(void) { return (int64_t)kMlpNets * kPackElems; }
 int64_t pnr_mlp_bias_elems(void) { return (int64_t)kMlpNets * kBiasElems; }
 
-int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value, void* wpack, float* bias, void* stream)
+static inline bool planes_ok(int32_t planes) { return planes >= 1 && planes <= kMlpMaxPlanes; }
+
+int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value, void* wpack, float* bias, int32_t planes, void* stream)
 {
     if (!params || !wpack || !bias) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: null argument");
+    if (!planes_ok(planes)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: planes must be 1, 2 or 3 (got %d)", planes);
     if (n3_policy < 1 || n3_policy > kMlpHead || n3_value < 1 || n3_value > kMlpHead)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_pack: head widths must be in 1..16");
     MlpPackParams P;
@@ -105,7 +108,7 @@ int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value
         P.net[n] = {params[6 * n + 0], params[6 * n + 1], params[6 * n + 2], params[6 * n + 3], params[6 * n + 4], params[6 * n + 5],
                     n == 0 ? n3_policy : n3_value};
     }
-    P.wpack = static_cast<__bf16*>(wpack); P.bias = bias;
+    P.wpack = static_cast<__bf16*>(wpack); P.bias = bias; P.planes = planes;
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((kPackElems + kBiasElems + 255) / 256, kMlpNets), dim3(256), 0, (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
@@ -113,9 +116,12 @@ int pnr_mlp_pack(const float* const* params, int32_t n3_policy, int32_t n3_value
 
 int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const float* f_loc, const float* f_inv,
                     const float* f_lo, const float* f_hi, const void* wpack, const float* bias, float* head,
-                    void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, void* stream)
+                    void* xs, void* h1, void* h2, int32_t first_net, int32_t n_nets, int32_t planes, void* stream)
 {
     if (batch < 1 || !obs || !wpack || !bias || !head) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: null argument or empty batch");
+    if (!planes_ok(planes)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: planes must be 1, 2 or 3 (got %d)", planes);
+    if (planes > 1 && (xs || h1 || h2))
+        return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_forward: split operands (planes %d) save no activations: pnr_mlp_backward is bf16-only", planes);
     if (first_net < 0 || n_nets < 1 || first_net + n_nets > kMlpNets) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: bad net range");
     if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: the four filter vectors come together or not at all");
@@ -125,8 +131,10 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
     P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
     P.xs = static_cast<__bf16*>(xs); P.h1 = static_cast<__bf16*>(h1); P.h2 = static_cast<__bf16*>(h2);
     P.B = batch; P.first_net = first_net; P.n_nets = n_nets;
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets), dim3(kFwdThreads), 0,
-                       (hipStream_t)stream, P);
+    const dim3 grid((unsigned)((batch + kMlpBM - 1) / kMlpBM), n_nets);
+    if (planes == 1) hipLaunchKernelGGL((mlp_forward_kernel<false, 1>), grid, dim3(kFwdThreads), 0, (hipStream_t)stream, P);
+    else if (planes == 2) hipLaunchKernelGGL((mlp_forward_kernel<false, 2>), grid, dim3(kFwdThreads), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((mlp_forward_kernel<false, 3>), grid, dim3(kFwdThreads), 0, (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }
@@ -215,10 +223,13 @@ int pnr_permutation(int64_t n, uint64_t seed, uint64_t stream_id, int64_t* out, 
 
 int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float* f_inv, const float* f_lo, const float* f_hi,
                 const void* wpack, const float* bias, const float* noise, const float* a_max, float* head, float* mean,
-                float* log_std, float* values, float* actions, float* env_actions, void* xs_out, void* stream)
+                float* log_std, float* values, float* actions, float* env_actions, void* xs_out, int32_t planes, void* stream)
 {
     if (batch < 1 || !obs || !wpack || !bias || !noise || !mean || !log_std || !values || !actions)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: null argument or empty batch");
+    if (!planes_ok(planes)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: planes must be 1, 2 or 3 (got %d)", planes);
+    if (planes > 1 && xs_out)
+        return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_act: split operands (planes %d): the learner gathers its inputs from the observations, xs_out must be NULL", planes);
     if ((f_loc || f_inv || f_lo || f_hi) && !(f_loc && f_inv && f_lo && f_hi))
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: the four filter vectors come together or not at all");
     if (a_max && (!env_actions || env_actions == actions))
@@ -230,8 +241,10 @@ int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float
     P.noise = noise; P.a_max = a_max; P.mean = mean; P.log_std = log_std; P.values = values; P.actions = actions;
     P.env_actions = a_max ? env_actions : actions;
     P.xs = static_cast<__bf16*>(xs_out);                     // the nets' input as they saw it, for the learner (or null)
-    hipLaunchKernelGGL(mlp_forward_kernel<false>, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kFwdThreads), 0,
-                       (hipStream_t)stream, P);
+    const dim3 grid((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets);
+    if (planes == 1) hipLaunchKernelGGL((mlp_forward_kernel<false, 1>), grid, dim3(kFwdThreads), 0, (hipStream_t)stream, P);
+    else if (planes == 2) hipLaunchKernelGGL((mlp_forward_kernel<false, 2>), grid, dim3(kFwdThreads), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL((mlp_forward_kernel<false, 3>), grid, dim3(kFwdThreads), 0, (hipStream_t)stream, P);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
 }
@@ -285,7 +298,8 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     MlpWgradParams Wp;
     Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
     Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows; Wp.first_net = 0; Wp.w3part = nullptr; Wp.n_nets = kMlpNets; Wp.stamps = nullptr;
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kWgThreads), 0, st, Wp);
+    Wp.act_plane = 0; Wp.xs_plane = 0;
+    hipLaunchKernelGGL(mlp_wgrad_kernel<1>, dim3((unsigned)slices, kWgParts, kMlpNets), dim3(kWgThreads), 0, st, Wp);
     MlpReduceParams Rp;
     Rp.slabs = slabs; Rp.slices = (int)slices; Rp.accumulate = accumulate; Rp.scale = scale;
     for (int n = 0; n < kMlpNets; ++n) {
@@ -315,6 +329,7 @@ static int mlp_step_check(const pnr_mlp_step* s, const char* who)
         return fail(nullptr, PNR_ERR_INVALID, "%s: head widths must be in 1..16", who);
     if (s->first_net < 0 || s->n_nets < 0 || s->first_net + (s->n_nets ? s->n_nets : kMlpNets) > kMlpNets)
         return fail(nullptr, PNR_ERR_INVALID, "%s: bad net range (first_net %d, n_nets %d)", who, s->first_net, s->n_nets);
+    if (s->planes < 0 || s->planes > kMlpMaxPlanes) return fail(nullptr, PNR_ERR_INVALID, "%s: planes must be 0 .. 3 (got %d)", who, s->planes);
     return PNR_OK;
 }
 
@@ -335,7 +350,7 @@ static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices
     A.n3[0] = s->n3_policy; A.n3[1] = s->n3_value;
     A.m = s->adam_m; A.v = s->adam_v; A.step = s->adam_step;
     A.lr = s->lr; A.beta1 = s->beta1; A.beta2 = s->beta2; A.eps = s->eps;
-    A.wpack = static_cast<__bf16*>(s->wpack); A.bias = s->bias;
+    A.wpack = static_cast<__bf16*>(s->wpack); A.bias = s->bias; A.planes = s->planes > 1 ? s->planes : 1;
     hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, step_nets(s)), dim3(256), 0, st, A);
 }
 
@@ -359,8 +374,11 @@ int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const fl
                    const float* f_hi, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
                    const float* adv, const float* value_target, const float* value_old, void* xs_out, float* actions_out,
                    float* logp_out, float* mean_out, float* log_std_out, float* adv_out, float* value_target_out,
-                   float* value_old_out, const float* record_rows, const void* xs_rows, void* stream)
+                   float* value_old_out, const float* record_rows, const void* xs_rows, int32_t planes, void* stream)
 {
+    if (!planes_ok(planes)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_gather: planes must be 1, 2 or 3 (got %d)", planes);
+    if (planes > 1 && xs_rows)
+        return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_gather: split operands (planes %d) are made from the float32 observations: xs_rows must be NULL", planes);
     const bool soa = actions && logp_old && mean_old && log_std_old && adv && value_target && value_old;
     if (batch < 1 || !(obs || xs_rows) || !(soa || record_rows) || !xs_out ||
         !actions_out || !logp_out || !mean_out || !log_std_out || !adv_out || !value_target_out || !value_old_out)
@@ -372,7 +390,7 @@ int pnr_mlp_gather(int64_t batch, const int64_t* idx, const float* obs, const fl
     G.actions = actions; G.logp = logp_old; G.mean = mean_old; G.log_std = log_std_old; G.adv = adv; G.vtarg = value_target;
     G.values = value_old; G.rec_aos = record_rows; G.xs_src = static_cast<const __bf16*>(xs_rows); G.xs_out = static_cast<__bf16*>(xs_out); G.actions_out = actions_out; G.logp_out = logp_out;
     G.mean_out = mean_out; G.log_std_out = log_std_out; G.adv_out = adv_out; G.vtarg_out = value_target_out; G.values_out = value_old_out;
-    G.B = batch;
+    G.B = batch; G.planes = planes;
     hipLaunchKernelGGL(mlp_gather_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(kMlpThreads), 0, (hipStream_t)stream, G);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;
@@ -396,6 +414,9 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
                     (long long)s->slab_floats, slices * kMlpNets * kGradElems);
     hipStream_t st = (hipStream_t)stream;
     const int nets = step_nets(s);
+    const int planes = s->planes > 1 ? s->planes : 1;
+    if (planes > 1 && (!s->w3_partials || s->idx || (s->obs && !s->xs_in && false)))
+        return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: split operands (planes %d) need w3_partials and contiguous rows (no idx)", planes);
     const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), nets);
     const long long prow = (long long)tiles.x * nets;           // one row of loss sums per workgroup of the fused kernel
     if (s->partial_rows < prow)
@@ -416,9 +437,12 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     F.clip = s->clip_param; F.vf_clip = s->vf_clip_param; F.vf_coeff = s->vf_loss_coeff;
     F.g_head = s->g_head; F.partials = s->partials; F.adam_step = s->adam_step;
     F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
+    F.act_plane = (size_t)kMlpNets * (size_t)B * kMlpHid;            // planes of h1 / dz1 / dz2: [planes][2][B][256]
+    F.xs_plane = s->xs_in_plane > 0 ? (size_t)s->xs_in_plane : (size_t)B * kMlpInPad;
     // layer 3's weight gradients per tile from the fused kernel (then H2 never leaves the CU) when the caller gave the scratch for it;
     // the weight-stationary variant of the fused kernel stores H2 as before (the two forms give the same bits)
-    const bool stationary = F.xs_in && kTrainStationary;
+    const bool stationary = F.xs_in && kTrainStationary && planes == 1;
+    if (planes > 1 && F.xs) return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: split operands (planes %d) read their input planes from xs_in (pnr_mlp_gather)", planes);
     if (s->w3_partials && !stationary) {
         if (s->w3_partial_floats < (long long)tiles.x * nets * kW3PartFloats)
             return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: w3_partials hold %lld floats, the launch needs %lld",
@@ -441,8 +465,12 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
         }
         const unsigned per_net = (unsigned)std::max(1, cus / kMlpNets);
         hipLaunchKernelGGL(mlp_train_kernel, dim3(std::min(tiles.x, per_net), nets), dim3(kFwdThreads), 0, st, F);
+    } else if (planes == 1) {
+        hipLaunchKernelGGL((mlp_forward_kernel<true, 1>), tiles, dim3(kFwdThreads), 0, st, F);
+    } else if (planes == 2) {
+        hipLaunchKernelGGL((mlp_forward_kernel<true, 2>), tiles, dim3(kFwdThreads), 0, st, F);
     } else {
-        hipLaunchKernelGGL(mlp_forward_kernel<true>, tiles, dim3(kFwdThreads), 0, st, F);
+        hipLaunchKernelGGL((mlp_forward_kernel<true, 3>), tiles, dim3(kFwdThreads), 0, st, F);
     }
     if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
         hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
@@ -454,7 +482,12 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
 #if PNR_MLP_STAMPS
     Wp.stamps = g_wg_stamps;
 #endif
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3((unsigned)slices, kWgParts, nets), dim3(kWgThreads), 0, st, Wp);
+    Wp.act_plane = F.act_plane; Wp.xs_plane = F.xs_plane;
+    if (planes > 1 && !PNR_WG_GLDS) return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: this build's weight-gradient kernel is bf16-only");
+    const dim3 wgrid((unsigned)slices, kWgParts, nets);
+    if (planes == 1) hipLaunchKernelGGL(mlp_wgrad_kernel<1>, wgrid, dim3(kWgThreads), 0, st, Wp);
+    else if (planes == 2) hipLaunchKernelGGL(mlp_wgrad_kernel<2>, wgrid, dim3(kWgThreads), 0, st, Wp);
+    else hipLaunchKernelGGL(mlp_wgrad_kernel<3>, wgrid, dim3(kWgThreads), 0, st, Wp);
     if (s->flat_grad)
         hipLaunchKernelGGL(mlp_reduce_flat_kernel, dim3((nets * kGradElems + 255) / 256), dim3(256), 0, st, s->slabs, (int)slices, s->flat_grad,
                            s->first_net * kGradElems, nets * kGradElems);

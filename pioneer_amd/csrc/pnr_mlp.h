@@ -102,6 +102,7 @@ constexpr int kOffW2T = kOffW3 + kMlpHead * kMlpHid;       // [256][256]  W2T[i]
 constexpr int kOffW3T = kOffW2T + kMlpHid * kMlpHid;       // [256][16]   W3T[f][r] = W3[r][f], 8 x 1 blocks
 constexpr int kPackElems = kOffW3T + kMlpHid * kMlpHead;   // 176 128
 constexpr int kBiasElems = 2 * kMlpHid + kMlpHead;         // b1[256] b2[256] b3[16], float32
+constexpr size_t kWPlane = (size_t)kMlpNets * kPackElems;  // elements between two PLANES of the packed weights ([planes][2][kPackElems]; r04, split float32 operands)
 
 // gradient slab of ONE net and ONE batch slice, float32 element offsets (also the layout of the reduced gradient)
 constexpr int kGW1 = 0;                                    // [256][144]
@@ -140,6 +141,7 @@ constexpr int kTrH = 288;         // [64][256] tile for transposed reads (144 dw
 constexpr int kTrX = 160;         // [64][160] (80 dwords = 16 mod 64): 144 inputs, a column of ones, zeros
 constexpr int kTrHalf = 160;      // [64][128] half-width hidden tile (+32 pad)
 constexpr int kTrG = 32;          // [64][16] head-gradient tile (16 dwords)
+constexpr int kTilePlane = PNR_MLP_BM * kXS + PNR_MLP_BM * kHS;   // elements of one LDS plane of the forward / fused kernel (input tile | hidden tile)
 constexpr int kWgChunk = 64;      // samples per weight-gradient chunk
 constexpr int kWgParts = 4;       // weight-gradient workgroup roles (mlp_wgrad_kernel)
 
@@ -150,7 +152,7 @@ struct MlpNetParams {             // float32 master parameters of one net (torch
     int n3;                             // 12 (policy) or 1 (value)
 };
 
-struct MlpPackParams { MlpNetParams net[kMlpNets]; __bf16* wpack; float* bias; };
+struct MlpPackParams { MlpNetParams net[kMlpNets]; __bf16* wpack; float* bias; int planes; };   // wpack: [planes][2][kPackElems]
 
 // One thread per packed element; the transposes and the zero padding happen here, once per update.
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpPackParams P)
@@ -167,7 +169,11 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpPackParams P)
         else if (e < kOffW2T) { const int r = (e - kOffW3) / kMlpHid, f = (e - kOffW3) % kMlpHid; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3 + frag16_off(r, f); }
         else if (e < kOffW3T) { const int i = (e - kOffW2T) / kMlpHid, o = (e - kOffW2T) % kMlpHid; v = N.w2[o * kMlpHid + i]; dst = kOffW2T + frag32_off(i, o, kMlpHid / 16); }
         else { const int f = (e - kOffW3T) / kMlpHead, r = (e - kOffW3T) % kMlpHead; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3T + frag32_off(f, r, 1); }
-        wp[dst] = (__bf16)v;
+        for (int pl = 0; pl < P.planes; ++pl) {          // plane pl carries what planes 0 .. pl - 1 left of the value
+            const __bf16 b = (__bf16)v;
+            wp[pl * kWPlane + dst] = b;
+            v -= (float)b;
+        }
     } else if (e < kPackElems + kBiasElems) {
         const int b = e - kPackElems;
         float v;
@@ -200,6 +206,44 @@ __device__ __forceinline__ f32x2 tanh_fast2(f32x2 x)
     return __builtin_elementwise_fma(r, (f32x2){-2.0f, -2.0f}, (f32x2){1.0f, 1.0f});
 }
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+// ---- r04: float32-accurate operands as SPLIT bf16 planes.  The reference's learner is float32 torch (pioneer_knm_train.py:47
+// 'framework': 'torch', no mixed precision); one bf16 operand carries 8 significant bits.  A float32 value x is written as the sum of
+// NS bf16 numbers, p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1) (each residual is exact in float32): 16 significant bits
+// with two planes, 24 — all of float32 — with three.  A product a . b then takes the bf16 MFMAs of the plane pairs (i, j) with
+// i + j < NS — 3 for NS = 2 (error ~2^-16: 8e-6 relative on the heads), 6 for NS = 3 (1.5e-7, the accuracy of a float32 GEMM) —
+// accumulated in float32 like every product here.  Against the native float32 MFMA (v_mfma_f32_32x32x2_f32: 2 048 MAC in 64
+// cycles per SIMD = 32 MAC/cycle) six bf16 MFMAs per 16 384 MAC (192 cycles = 85 MAC/cycle) are 2.7x the matrix-pipe rate, three
+// are 5.3x (MI355X_MICROARCH.md cycle constants; tools/f32_product_probe.hip measures the three forms on the layer-2 product).
+// Every tensor that is an MFMA operand exists as NS planes of the bf16 layout (packed weights, input rows, the LDS tiles, the saved
+// activations and gradients); biases, heads, the loss, slabs, Adam and the master weights are float32 as before.  NS = 1 is the
+// bf16 path, instruction for instruction what it was.
+template <int NS>
+__device__ __forceinline__ void split_quad(const float (&v)[4], bf16x4_t (&pk)[NS])
+{
+    float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        pk[s] = (bf16x4_t){(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+        if (s + 1 < NS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] -= (float)pk[s][j];
+        }
+    }
+}
+template <int NS>
+__device__ __forceinline__ void split_scalar(float v, __bf16 (&p)[NS])
+{
+    float r = v;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { p[s] = (__bf16)r; r -= (float)p[s]; }
+}
+// the plane pairs of a product in the order they are accumulated: the large term first (it may carry the bias as its C operand)
+template <int NS> struct SplitPairs;
+template <> struct SplitPairs<1> { static constexpr int n = 1; static constexpr int a[1] = {0}, b[1] = {0}; };
+template <> struct SplitPairs<2> { static constexpr int n = 3; static constexpr int a[3] = {0, 0, 1}, b[3] = {0, 1, 0}; };
+template <> struct SplitPairs<3> { static constexpr int n = 6; static constexpr int a[6] = {0, 0, 1, 0, 2, 1}, b[6] = {0, 1, 0, 2, 0, 1}; };
+constexpr int kMlpMaxPlanes = 3;
 // tanh of accumulator quad q (four consecutive features of one sample), rounded to bf16
 template <class ACC>
 __device__ __forceinline__ bf16x4_t tanh_quad(const ACC& acc, int q)
@@ -473,6 +517,8 @@ struct MlpFwdParams {
     __bf16* dz1;               // [2][B][256]
     __bf16* dz2;
     float* w3part;             // [tiles * nets][kW3PartFloats] layer 3's weight-gradient partials per tile (then h2 may be null), or null
+    size_t act_plane;          // NS > 1: elements between two planes of h1 / h2 / dz1 / dz2 ([NS][2][B][256]: 2 B 256)
+    size_t xs_plane;           // NS > 1: elements between two planes of xs_in
     unsigned long long* stamps; // PNR_MLP_STAMPS builds only: [workgroups][4 waves][kMlpStampSlots] cycle stamps, or null
 };
 
@@ -491,22 +537,26 @@ static_assert((kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats + 4 * 8) * 4
 static_assert(kFwdWaves * 32 == kMlpHid, "one 32-row block of the 256 hidden units per wave");
 
 // the one-row-block product: acc[cb] += W[32 rows of this wave][K] . tile[BM samples][K]^T (see MlpGemm for the two steps)
-template <int K, int STRIDE>
+template <int K, int STRIDE, int NS = 1>
 struct MlpGemm1 {
     static constexpr int KS = K / 16;
     static constexpr int D = PNR_MLP_RING;
-    bf16x8 a[D];
+    bf16x8 a[D][NS];
     const __bf16* wa;
-    // w_block: this wave's row block in the fragment-native packing: k-step ks at ks * 512
+    // w_block: this wave's row block in the fragment-native packing: k-step ks at ks * 512 (plane s: + s * kWPlane)
     __device__ __forceinline__ void prefetch(const __bf16* __restrict__ w_block, int lane)
     {
         wa = w_block + lane * 8;
 #pragma unroll
         for (int p = 0; p < D - 1; ++p)
-            if (p < KS) a[p] = ld_global_bf16x8(wa + 512 * p);
+            if (p < KS) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[p][s] = ld_global_bf16x8(wa + s * kWPlane + 512 * p);
+            }
     }
     // init: what every column block's accumulators start from (the bias rows of this wave, the same for every sample), read as
     // the FIRST MFMA's C operand — 16 copies per column block and product less than accumulators initialised beforehand; or null
+    // tile: plane 0 of the LDS tile (plane s: + s * kTilePlane)
     template <class F>
     __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[kMlpCB], int lane, F&& after_loads, const f32x16* init = nullptr)
     {
@@ -514,7 +564,10 @@ struct MlpGemm1 {
         const __bf16* tb = tile + r * STRIDE + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + D - 1 < KS) a[(ks + D - 1) % D] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
+            if (ks + D - 1 < KS) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[(ks + D - 1) % D][s] = ld_global_bf16x8(wa + s * kWPlane + 512 * (ks + D - 1));
+            }
             if (ks == (KS > D ? KS - D : 0)) {
                 __builtin_amdgcn_sched_barrier(0);
                 after_loads();
@@ -522,12 +575,17 @@ struct MlpGemm1 {
             }
             // (reading the sample fragments one k-step ahead of their MFMAs — 16 more registers — changed nothing in the fused
             // kernel and cost the sampler's forward 9 us of 14: r03, dropped)
-            bf16x8 b[kMlpCB];
+            bf16x8 b[NS][kMlpCB];
 #pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D], b[cb], (ks == 0 && init) ? *init : acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < kMlpCB; ++cb) b[s][cb] = *reinterpret_cast<const bf16x8*>(tb + s * kTilePlane + cb * 32 * STRIDE + 16 * ks);
+#pragma unroll
+            for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
+#pragma unroll
+                for (int cb = 0; cb < kMlpCB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb],
+                                                                      (ks == 0 && pi == 0 && init) ? *init : acc[cb], 0, 0, 0);
         }
     }
 };
@@ -588,34 +646,48 @@ __device__ __forceinline__ bf16x8 bf16x8_ones()
     return o;
 }
 // dW3 (this wave's feature columns 32 w ..) and db3 (wave 0) of one 64-sample tile: G tile [64][16] bf16, H2 tile [64][256] bf16
+// (NS planes each: gplane / hplane elements apart)
+template <int NS = 1>
 __device__ __forceinline__ void mlp_tile_w3_products(const __bf16* gtile, int gstride, const __bf16* htile, int hstride, int lane, int w,
-                                                     f32x4 (&aw3)[2], f32x4& ab3)
+                                                     f32x4 (&aw3)[2], f32x4& ab3, int gplane = 0, int hplane = 0)
 {
     const bf16x8 ones = bf16x8_ones();
     aw3[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw3[1] = aw3[0]; ab3 = aw3[0];
 #pragma unroll
     for (int ks = 0; ks < kMlpBM / 32; ++ks) {
-        const bf16x8 fg = wg_frag16(gtile, gstride, 32 * ks, 0, lane);            // A: rows = head entries
-        if (w == 0) ab3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, ones, ab3, 0, 0, 0);
+        bf16x8 fg[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fg[s] = wg_frag16(gtile + s * gplane, gstride, 32 * ks, 0, lane);            // A: rows = head entries
+        if (w == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) ab3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[s], ones, ab3, 0, 0, 0);
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const bf16x8 fh = wg_frag16(htile, hstride, 32 * ks, 32 * w + 16 * b, lane);
-            aw3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg, fh, aw3[b], 0, 0, 0);
+            bf16x8 fh[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) fh[s] = wg_frag16(htile + s * hplane, hstride, 32 * ks, 32 * w + 16 * b, lane);
+#pragma unroll
+            for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
+                aw3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[SplitPairs<NS>::a[pi]], fh[SplitPairs<NS>::b[pi]], aw3[b], 0, 0, 0);
         }
     }
 }
 // db2 (this wave's feature columns) of one tile: every row of 1^T . dZ2
-__device__ __forceinline__ void mlp_tile_b2_products(const __bf16* ztile, int zstride, int lane, int w, f32x4 (&ab2)[2])
+template <int NS = 1>
+__device__ __forceinline__ void mlp_tile_b2_products(const __bf16* ztile, int zstride, int lane, int w, f32x4 (&ab2)[2], int zplane = 0)
 {
     const bf16x8 ones = bf16x8_ones();
     ab2[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab2[1] = ab2[0];
 #pragma unroll
     for (int ks = 0; ks < kMlpBM / 32; ++ks)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const bf16x8 fz = wg_frag16(ztile, zstride, 32 * ks, 32 * w + 16 * b, lane);
-            ab2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fz, ab2[b], 0, 0, 0);
-        }
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bf16x8 fz = wg_frag16(ztile + s * zplane, zstride, 32 * ks, 32 * w + 16 * b, lane);
+                ab2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fz, ab2[b], 0, 0, 0);
+            }
 }
 
 // The tile's loss on all 512 threads of the fused kernels: eight lanes per sample, lane d < 6 = action dimension d of the policy head
@@ -623,6 +695,7 @@ __device__ __forceinline__ void mlp_tile_b2_products(const __bf16* ztile, int zs
 // (ppo_value_sample).  hd: the tile's head rows [64][16] float32, gt: its head gradients [64][kGS] bf16 (written here, with the
 // float32 copy to g_head), rl: the parked record (rec_early) — all LDS; wsum [8 waves][4]: the waves' partial loss sums.
 // As one thread per sample on wave 0 the other seven waves waited 4 300 cycles of a tile's 38 000 for it (profiles/r03_d_mlp_stamps.json).
+template <int NS = 1>
 __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, long long row0, int tid, const float* hd, __bf16* gt, const float* rl,
                                               float* wsum, bool rec_early)
 {
@@ -690,8 +763,15 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
         float* gp = P.g_head + ((size_t)net * P.B + b) * kMlpHead;
         gp[e0] = g0; gp[e1] = g1;
     }
-    gt[sl * kGS + e0] = (__bf16)g0;
-    gt[sl * kGS + e1] = (__bf16)g1;
+    if constexpr (NS == 1) {
+        gt[sl * kGS + e0] = (__bf16)g0;
+        gt[sl * kGS + e1] = (__bf16)g1;
+    } else {                              // the gradient rows as NS planes (plane s of the tile: + s * kTilePlane)
+        __bf16 p0[NS], p1[NS];
+        split_scalar<NS>(g0, p0); split_scalar<NS>(g1, p1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { gt[s * kTilePlane + sl * kGS + e0] = p0[s]; gt[s * kTilePlane + sl * kGS + e1] = p1[s]; }
+    }
     // the tile's sums: lane 0 of every group, then across the wave's eight samples; the waves' partial sums meet in LDS
     float sums[4] = {d == 0 ? s_surr : 0.f, d == 0 ? s_vf : 0.f, d == 0 ? s_kl : 0.f, d == 0 ? s_ent : 0.f};
 #pragma unroll
@@ -709,10 +789,13 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
 // pass — the activations are written once (for the weight-gradient kernel) and never read back; H1 also stays in the
 // registers of the lanes that made it, for the dZ1 epilogue.  One 256-column LDS tile serves H1, H2, dZ2 (in place over H2)
 // and dZ1, the dead input tile holds the head rows, their gradients and the tile's record: 53 KB.
-template <bool FUSED>
-__global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
+// NS: bf16 planes per operand (1: the bf16 path; 2, 3: split float32 operands, one workgroup per CU — the LDS tile exists NS times,
+// plane s at + s * kTilePlane; the packed weights at + s * kWPlane; the saved tiles at plane stride P.act_plane)
+template <bool FUSED, int NS = 1>
+__global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[kMlpBM * kXS + kMlpBM * kHS];
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane];
+    static_assert(NS >= 1 && NS <= kMlpMaxPlanes && NS * kTilePlane * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
     MLP_STAMP_DECL;
     __bf16* xt = lds;
     __bf16* ht = lds + kMlpBM * kXS;
@@ -747,7 +830,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
     f32x4 bq1[4];
     bias_load(bias, bq1);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm1<kMlpInPad, kXS> g1;
+    MlpGemm1<kMlpInPad, kXS, NS> g1;
     g1.prefetch(wp + kOffW1 + w * (kMlpInPad / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
 #if PNR_MLP_DEPHASE
@@ -772,26 +855,32 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy,
             // every load of the thread in flight before the first LDS write
             constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFwdThreads - 1) / kFwdThreads;
-            uint4 v[kIt];
+            uint4 v[NS][kIt];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+            const __bf16* xin = P.xs_in + (size_t)s * P.xs_plane;               // plane s of the pre-gathered rows
             if (row0 + kMlpBM <= P.B) {            // a whole tile: 18 KB contiguous — thread offset + constant per piece, one uniform test
-                const __bf16* base = P.xs_in + row0 * kMlpInPad + tid * 8;
+                const __bf16* base = xin + row0 * kMlpInPad + tid * 8;
 #pragma unroll
                 for (int i = 0; i < kIt; ++i) {
-                    v[i] = make_uint4(0u, 0u, 0u, 0u);
-                    if (i < kCh / kFwdThreads || tid + kFwdThreads * i < kCh) v[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * kFwdThreads * 8);
+                    v[s][i] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < kCh / kFwdThreads || tid + kFwdThreads * i < kCh) v[s][i] = *reinterpret_cast<const uint4*>(base + (size_t)i * kFwdThreads * 8);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < kIt; ++i) {
                     const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                    v[i] = make_uint4(0u, 0u, 0u, 0u);
-                    if (ch < kCh && row0 + row < P.B) v[i] = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
+                    v[s][i] = make_uint4(0u, 0u, 0u, 0u);
+                    if (ch < kCh && row0 + row < P.B) v[s][i] = *reinterpret_cast<const uint4*>(xin + (row0 + row) * kMlpInPad + cc * 8);
                 }
             }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int i = 0; i < kIt; ++i) {
                 const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                if (ch < kCh) *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = v[i];
+                if (ch < kCh) *reinterpret_cast<uint4*>(xt + s * kTilePlane + row * kXS + cc * 8) = v[s][i];
             }
         } else {
         if (P.f_loc) {
@@ -839,12 +928,15 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
                 if (P.f_loc) y = fminf(fmaxf((y - fv[col]) * fv[kMlpInPad + col], fv[2 * kMlpInPad + col]), fv[3 * kMlpInPad + col]);
                 x[j] = (live && col < kMlpIn) ? y : 0.f;
             }
-            // 18 bf16 = 36 bytes per thread, 4-byte aligned in the tile: nine dword stores
+            // 18 bf16 = 36 bytes per thread, 4-byte aligned in the tile: nine dword stores (per plane: the residual goes on)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int j = 0; j < CPT; j += 2) {
                 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
                 bf16x2 pk = {(__bf16)x[j], (__bf16)x[j + 1]};
-                *reinterpret_cast<bf16x2*>(xt + row * kXS + CPT * part + j) = pk;
+                *reinterpret_cast<bf16x2*>(xt + s * kTilePlane + row * kXS + CPT * part + j) = pk;
+                if (s + 1 < NS) { x[j] -= (float)pk[0]; x[j + 1] -= (float)pk[1]; }
             }
         }
         }
@@ -865,12 +957,14 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
     // FUSED: layer 1's activations additionally STAY in this lane's registers (32 bf16 = 16 registers: exactly the values the
     // dZ1 epilogue multiplies its own accumulators with), instead of coming back from L2 behind a vmcnt(0), two barriers and an
     // LDS round trip (3 500 of a tile's 44 000 cycles in the phase stamps)
-    bf16x4 h1keep[FUSED ? kMlpCB * 4 : 1];
+    bf16x4 h1keep[(FUSED && NS == 1) ? kMlpCB * 4 : 1];
+    f32x4 h1keep_f[(FUSED && NS > 1) ? kMlpCB * 4 : 1];        // NS > 1: the float32 values themselves (what the planes add up to)
     const auto epilogue = [&](bool keep) {
 #pragma unroll
         for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                if constexpr (NS == 1) {
                 bf16x4 pk;
                 if (PNR_MLP_DIAG & 1) {
 #pragma unroll
@@ -880,7 +974,22 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
                 }
                 *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk;
                 if constexpr (FUSED) { if (keep) h1keep[4 * cb + q] = pk; }
+                } else {
+                    const f32x2 lo = tanh_fast2((f32x2){acc[cb][4 * q], acc[cb][4 * q + 1]}), hi = tanh_fast2((f32x2){acc[cb][4 * q + 2], acc[cb][4 * q + 3]});
+                    const float t[4] = {lo[0], lo[1], hi[0], hi[1]};
+                    bf16x4_t pk[NS];
+                    split_quad<NS>(t, pk);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * kTilePlane + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
+                    if constexpr (FUSED) { if (keep) h1keep_f[4 * cb + q] = (f32x4){t[0], t[1], t[2], t[3]}; }
+                }
             }
+    };
+    // a [BM][256] tile's NS planes to global rows (plane s of a saved tensor: + s * P.act_plane elements)
+    const auto store_planes = [&](__bf16* dst) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            mlp_store_htile_nt<kFwdThreads>(ht + s * kTilePlane, dst + (size_t)s * P.act_plane + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
     };
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
@@ -896,7 +1005,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
     f32x4 bq2[4];
     bias_load(bias + kMlpHid, bq2);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm1<kMlpHid, kHS> g2;
+    MlpGemm1<kMlpHid, kHS, NS> g2;
     g2.prefetch(wp + kOffW2 + w * (kMlpHid / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
     mlp_barrier();
@@ -917,7 +1026,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
                 rect.load(src, net, row0, P.B, tid);
             }
         }
-        if (P.h1 && !(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        if (P.h1 && !(PNR_MLP_DIAG & 64)) store_planes(P.h1);
     }, &b16_2);
     if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
         if (rec_early) rect.park(reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
@@ -937,13 +1046,19 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         const int r16 = lane & 15, g = lane >> 4;
         f32x4 a3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);    // rows 4g .. 4g+3: the accumulators' start
         const __bf16* w3 = wp + kOffW3 + lane * 8;                    // fragment-native: block ks at ks * 512
-        bf16x8 w3f[kMlpHid / 32];
+        bf16x8 w3f[kMlpHid / 32][NS];
 #pragma unroll
-        for (int ks = 0; ks < kMlpHid / 32; ++ks) w3f[ks] = ld_global_bf16x8(w3 + 512 * ks);
+        for (int ks = 0; ks < kMlpHid / 32; ++ks)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) w3f[ks][s] = ld_global_bf16x8(w3 + s * kWPlane + 512 * ks);
 #pragma unroll
         for (int ks = 0; ks < kMlpHid / 32; ++ks) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (16 * w + r16) * kHS + 32 * ks + 8 * g);
-            a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks], b, a3, 0, 0, 0);
+            bf16x8 b[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const bf16x8*>(ht + s * kTilePlane + (16 * w + r16) * kHS + 32 * ks + 8 * g);
+#pragma unroll
+            for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
+                a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]], a3, 0, 0, 0);
         }
         {
             const long long b = row0 + 16 * w + r16;                  // column = sample, rows 4g .. 4g+3 = head entries
@@ -994,7 +1109,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
     MLP_STAMP(11);                        // head product + its stores
 
     if constexpr (!FUSED) {
-        if (P.h2 && !(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        if (P.h2 && !(PNR_MLP_DIAG & 64)) store_planes(P.h2);
     }
     if constexpr (FUSED) {
         float* hd = reinterpret_cast<float*>(xt);                         // [64][16] float32 head rows (written above)
@@ -1002,13 +1117,15 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         const float* rl = reinterpret_cast<const float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2;   // the parked record
         float* wsum = reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats; // [8 waves][4] loss sums
         // W3^T's fragment for the first backward product: requested before the H2 store and the loss
-        const bf16x8 w3t = ld_global_bf16x8(wp + kOffW3T + w * 512 + lane * 8);
+        bf16x8 w3t[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) w3t[s] = ld_global_bf16x8(wp + s * kWPlane + kOffW3T + w * 512 + lane * 8);
         __builtin_amdgcn_sched_barrier(0);
-        if (P.h2 && !(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);      // (null: layer 3's gradients are made here, below)
+        if (P.h2 && !(PNR_MLP_DIAG & 64)) store_planes(P.h2);      // (null: layer 3's gradients are made here, below)
         mlp_barrier();
         MLP_STAMP(12);                    // barrier before the loss
         // ---- the tile's loss on all 512 threads (mlp_tile_loss)
-        mlp_tile_loss(P, net, row0, tid, hd, gt, rl, wsum, rec_early);
+        mlp_tile_loss<NS>(P, net, row0, tid, hd, gt, rl, wsum, rec_early);
         MLP_STAMP(13);                    // loss done
         mlp_barrier();
         MLP_STAMP(14);                    // barrier after the loss
@@ -1022,14 +1139,35 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         }
 
         // acc * (1 - h^2) with h read from the tile at this lane's own quads and the product written over it
+        // acc * (1 - h^2) of quad q with h the float32 values hf, as NS planes into the tile at this lane's quads
+        const auto dtanh_split = [&](int cb, int q, const f32x4& hf) {
+            float d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = acc[cb][4 * q + j] * __builtin_fmaf(-hf[j], hf[j], 1.0f);
+            bf16x4_t pk[NS];
+            split_quad<NS>(d, pk);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * kTilePlane + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
+        };
         const auto bwd_epilogue = [&]() {
 #pragma unroll
             for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     __bf16* at = ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h;
+                    if constexpr (NS == 1) {
                     const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at);
                     *reinterpret_cast<bf16x4*>(at) = dtanh_quad(acc[cb], q, hv);
+                    } else {
+                        f32x4 hf = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = NS - 1; s >= 0; --s) {                       // the planes add up to the float32 activation exactly
+                            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at + s * kTilePlane);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) hf[j] += (float)hv[j];
+                        }
+                        dtanh_split(cb, q, hf);
+                    }
                 }
         };
         const auto zero_acc = [&]() {
@@ -1043,7 +1181,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         float* w3p = P.w3part ? P.w3part + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * kW3PartFloats : nullptr;
         if (w3p) {
             f32x4 aw3[2], ab3;
-            mlp_tile_w3_products(gt, kGS, ht, kHS, lane, w, aw3, ab3);
+            mlp_tile_w3_products<NS>(gt, kGS, ht, kHS, lane, w, aw3, ab3, kTilePlane, kTilePlane);
             const int c16 = lane & 15, g = lane >> 4;              // C: col = lane & 15, rows 4g .. 4g+3
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -1057,24 +1195,28 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
         zero_acc();
         {
-            bf16x8 b[kMlpCB];
+            bf16x8 b[NS][kMlpCB];
 #pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t, b[cb], acc[cb], 0, 0, 0);
+                for (int cb = 0; cb < kMlpCB; ++cb) b[s][cb] = *reinterpret_cast<const bf16x8*>(gt + s * kTilePlane + (32 * cb + c) * kGS + 8 * h);
+#pragma unroll
+            for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
+#pragma unroll
+                for (int cb = 0; cb < kMlpCB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb], acc[cb], 0, 0, 0);
         }
         bwd_epilogue();
         if (w3p) {                                                 // db2 = 1^T . dZ2 of this wave's columns, now that they hold dZ2
             f32x4 ab2[2];
-            mlp_tile_b2_products(ht, kHS, lane, w, ab2);
+            mlp_tile_b2_products<NS>(ht, kHS, lane, w, ab2, kTilePlane);
             if ((lane >> 4) == 0) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * w + 16 * b + (lane & 15)] = ab2[b][0];
             }
         }
         MLP_STAMP(15);                    // dH2 product + its epilogue
-        MlpGemm1<kMlpHid, kHS> g4;                // W2^T's first fragments ahead of the barrier
+        MlpGemm1<kMlpHid, kHS, NS> g4;            // W2^T's first fragments ahead of the barrier
         g4.prefetch(wp + kOffW2T + w * (kMlpHid / 16) * 512, lane);
         __builtin_amdgcn_sched_barrier(0);
         mlp_barrier();
@@ -1083,7 +1225,7 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         // ---- dH1^T = W2^T . dZ2^T (the dZ2 tile leaves from inside the product), then H1 into the tile and dZ1 in place over it
         zero_acc();
         g4.run(ht, acc, lane, [&] {
-            if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+            if (!(PNR_MLP_DIAG & 64)) store_planes(P.dz2);
         });
         MLP_STAMP(17);                    // dZ2 store + W2^T product issued
         MLP_STAMP(18);
@@ -1095,11 +1237,12 @@ __global__ __launch_bounds__(kFwdThreads, FUSED ? 4 : 2) void mlp_forward_kernel
         for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = dtanh_quad(acc[cb], q, h1keep[4 * cb + q]);
+                if constexpr (NS == 1) *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = dtanh_quad(acc[cb], q, h1keep[4 * cb + q]);
+                else dtanh_split(cb, q, h1keep_f[4 * cb + q]);
             }
         MLP_STAMP(21);
         mlp_barrier();
-        if (!(PNR_MLP_DIAG & 64)) mlp_store_htile_nt<kFwdThreads>(ht, P.dz1 + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+        if (!(PNR_MLP_DIAG & 64)) store_planes(P.dz1);
         MLP_STAMP(22);                    // end
         MLP_STAMP_FLUSH;
     }
@@ -1453,7 +1596,8 @@ struct MlpGatherParams {
     const float* adv; const float* vtarg; const float* values;
     const float* rec_aos;      // [rows][24] the same record as ONE 96-byte row per sample (record_pack_kernel), or null: the seven arrays
     const __bf16* xs_src;      // [rows][144] the nets' inputs as the sampler saw them (pnr_mlp_act's xs_out), or null: made from obs
-    __bf16* xs_out;            // [B][144]
+    __bf16* xs_out;            // [planes][B][144]
+    int planes;                // 1, or 2 / 3 split planes of the filtered float32 input (then xs_src must be null)
     float* actions_out; float* logp_out; float* mean_out; float* log_std_out; float* adv_out; float* vtarg_out; float* values_out;
     long long B;
 };
@@ -1523,6 +1667,11 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGather
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = (__bf16)((col + k < kMlpIn) ? x[k] : 0.f);
         *reinterpret_cast<bf16x4*>(P.xs_out + b * kMlpInPad + col) = pk;
+        for (int pl = 1; pl < P.planes; ++pl) {          // the residual planes of the split float32 input
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x[k] = (col + k < kMlpIn) ? x[k] - (float)pk[k] : 0.f; pk[k] = (__bf16)x[k]; }
+            *reinterpret_cast<bf16x4*>(P.xs_out + ((size_t)pl * P.B + b) * kMlpInPad + col) = pk;
+        }
     }
     }
     if (part < 3) {
@@ -1658,6 +1807,8 @@ struct MlpWgradParams {
     const float* w3part;       // [tiles * n_nets][kW3PartFloats] the fused kernel's per-tile layer-3 partials (then h2 is not read), or null
     int n_nets;                // nets of the launch that wrote w3part (its row index is tile * n_nets + blockIdx.z)
     unsigned long long* stamps; // PNR_MLP_STAMPS builds only (tools/wgrad_stamps.py): [nets][roles][slices][8 waves][kMlpStampSlots], or null
+    size_t act_plane;          // NS > 1: elements between two planes of h1 / dz1 / dz2
+    size_t xs_plane;           // .. and of xs
 };
 #if PNR_MLP_STAMPS
 #define WG_STAMP(i) do { if (P.stamps && lane == 0) { unsigned long long* sp_ = P.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + w) * kMlpStampSlots; \
@@ -1773,10 +1924,22 @@ __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, in
 #ifndef PNR_WG_GLDS
 #define PNR_WG_GLDS 1
 #endif
-constexpr int kWgStages = 3;
-constexpr int kWgStage2 = kWgChunk * 512 + kWgChunk * 256;      // dW2 roles: dZ2 [64][256] | H1 half [64][128], bf16: 48 KB
-constexpr int kWgStage1 = kWgChunk * 256 + kWgChunk * 288;      // dW1 roles: dZ1 half [64][128] | X [64][144]: 34 KB
-constexpr int kWgRingBytes = kWgStages * kWgStage2 + 64;        // (+ slack: the last X block reads 32 bytes past its row)
+// the ring's geometry by the number of operand planes (NS > 1: float32-accurate split operands): chunks of 64 samples and three
+// stages for bf16; 32-sample chunks for split operands (a stage holds every plane's tiles), three stages with two planes, two with three
+template <int NS> struct WgGeom {
+    static constexpr int CH = NS == 1 ? 64 : 32;                        // samples per chunk
+    static constexpr int KS = CH / 16;                                  // k-steps per chunk
+    static constexpr int STAGES = NS <= 2 ? 3 : 2;
+    static constexpr int kPlane2 = CH * 512 + CH * 256;                 // dW2 roles, one plane: dZ2 [CH][256] | H1 half [CH][128], bf16
+    static constexpr int kPlane1 = CH * 256 + CH * 288;                 // dW1 roles, one plane: dZ1 half [CH][128] | X [CH][144]
+    static constexpr int kStage2 = NS * kPlane2, kStage1 = NS * kPlane1;
+    static constexpr int kRing = STAGES * kStage2 + 64;                 // (+ slack: the last X block reads 32 bytes past its row)
+    static constexpr int nA2 = CH / 16, nB2 = CH / 32;                  // a wave's pieces per plane and chunk: dZ2, H1 half
+    static constexpr int nA1 = CH / 32, kXPieces = CH * 288 / 1024;     // dZ1 half; X pieces of the whole workgroup (18 or 9)
+};
+constexpr int kWgRingBytes = WgGeom<1>::kRing > WgGeom<2>::kRing ? (WgGeom<1>::kRing > WgGeom<3>::kRing ? WgGeom<1>::kRing : WgGeom<3>::kRing)
+                                                                 : (WgGeom<2>::kRing > WgGeom<3>::kRing ? WgGeom<2>::kRing : WgGeom<3>::kRing);
+static_assert(kWgRingBytes <= 150 * 1024, "the ring fits one CU beside the stamps");
 constexpr int kWgLdsBytesOld = (kWgChunk * kTrH + kWgChunk * kTrH + kWgChunk * kTrG) * 2;
 constexpr int kWgLdsBytes = PNR_WG_GLDS ? (kWgRingBytes > kWgLdsBytesOld ? kWgRingBytes : kWgLdsBytesOld) : kWgLdsBytesOld;
 
@@ -1848,45 +2011,47 @@ __device__ __forceinline__ unsigned wg_piece_src_swz(int i, int lane, int GROWB,
 #else
 #define WG_RING_STAMP(i) do { } while (0)
 #endif
-template <class ISSUE, class SYNC, class MUL, class PRO>
+template <int CH, int STAGES, int MAXP, class ISSUE, class SYNC, class MUL, class PRO>
 __device__ __forceinline__ void wg_ring_loop(long long s_begin, long long s_end, int np, ISSUE&& issue, SYNC&& stage_sync, MUL&& multiply,
                                              PRO&& prologue_work, unsigned long long* stamps = nullptr)
 {
-    const int nch = (int)((s_end - s_begin + kWgChunk - 1) / kWgChunk);
-    const auto whole = [&](int c) { return s_begin + (long long)(c + 1) * kWgChunk <= s_end; };
+    constexpr int D = STAGES - 1;                                     // chunks requested ahead of the one being multiplied
+    const int nch = (int)((s_end - s_begin + CH - 1) / CH);
+    const auto whole = [&](int c) { return s_begin + (long long)(c + 1) * CH <= s_end; };
     const auto request = [&](int c, int stage) {
         if (whole(c)) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) issue(c, stage, k);
+            for (int k = 0; k < MAXP; ++k) issue(c, stage, k);
         } else stage_sync(c, stage);
     };
-    if (nch > 0) request(0, 0);
-    if (nch > 1) request(1, 1);
-    // work that does not depend on the chunks (the layer-3 partial sums) runs while the first chunk travels.  Its loads and stores are
-    // further operations on the VM counter: they can only make a counted wait below wait for MORE than the pieces it names
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < nch) request(c, c);
+    // work that does not depend on the chunks (the layer-3 partial sums' requests) goes behind the first chunks' pieces.  Its loads and
+    // stores are further operations on the VM counter: they can only make a counted wait below wait for MORE than the pieces it names
     prologue_work();
     int stage = 0;
     WG_RING_STAMP(1);
     for (int c = 0; c < nch; ++c) {
-        // outstanding glds of this wave that may stay in flight: those of chunk c + 1 (if it was requested by glds)
-        const int ahead = (c + 1 < nch && whole(c + 1)) ? np : 0;
+        // glds of this wave that may stay in flight: those of the chunks c + 1 .. c + D - 1 (requested by glds; none with two stages)
+        const int ahead = (D > 1 && c + 1 < nch && whole(c + 1)) ? np : 0;
         if (c >= 4 && c < 8) WG_RING_STAMP(2 + 4 * (c - 4));          // top of the chunk
         if (ahead == 0) wg_wait_vm<0>();
-        else if (ahead == 2) wg_wait_vm<2>();
         else if (ahead == 4) wg_wait_vm<4>();
         else if (ahead == 5) wg_wait_vm<5>();
-        else wg_wait_vm<6>();
+        else if (ahead == 6) wg_wait_vm<6>();
+        else wg_wait_vm<0>();
         if (c >= 4 && c < 8) WG_RING_STAMP(3 + 4 * (c - 4));          // its pieces landed
         mlp_barrier();
         if (c >= 4 && c < 8) WG_RING_STAMP(4 + 4 * (c - 4));          // barrier passed
-        const int nstage = stage == 0 ? 2 : stage - 1;                // the stage chunk c - 1 used: every wave is done with it
-        const bool glds_next = c + 2 < nch && whole(c + 2);
-        if (c + 2 < nch && !glds_next) stage_sync(c + 2, nstage);
+        const int nstage = stage == 0 ? STAGES - 1 : stage - 1;       // the stage chunk c - 1 used: every wave is done with it
+        const bool glds_next = c + D < nch && whole(c + D);
+        if (c + D < nch && !glds_next) stage_sync(c + D, nstage);
         if (c >= 4 && c < 8) WG_RING_STAMP(5 + 4 * (c - 4));
-        // chunk c + 2's pieces are requested from INSIDE the products, a piece or two behind each k-step's MFMAs: issuing the six
-        // of them in one go cost 650 cycles per chunk in which the wave issued no MFMA (profiles/r04_b_wgrad_ring_stamps.json)
-        multiply(stage, [&](int k) { if (glds_next) issue(c + 2, nstage, k); });
-        stage = stage == 2 ? 0 : stage + 1;
+        // chunk c + D's pieces are requested from INSIDE the products, a few behind each k-step's MFMAs: issuing the six
+        // of them in one go cost 650 cycles per chunk in which the wave issued no MFMA (profiles/r04_a_wgrad_ring_stamps_issue_in_one_go.json)
+        multiply(stage, [&](int k) { if (glds_next) issue(c + D, nstage, k); });
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
     WG_RING_STAMP(20);
 }
@@ -1968,9 +2133,12 @@ struct WgW3Sums {
 static_assert(kW3PartFloats / 4 / kWgParts <= kWgThreads && kW3PartFloats % (4 * kWgParts) == 0, "one quad of the layer-3 partials per thread and role");
 
 // dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half] of one slice; waves 4 x 2, each 64 (o) x 64 (i)
+template <int NS>
 __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ring, int part, size_t nb, long long s_begin, long long s_end,
                                                float* slab, int tid, unsigned long long* stamps = nullptr)
 {
+    typedef WgGeom<NS> G;
+    constexpr int CH = G::CH, NPP = G::nA2 + G::nB2, MAXP = NS * NPP;   // pieces per plane / per chunk of one wave
     const int lane = tid & 63, w = tid >> 6;
     const int wo = w >> 1, wi = w & 1;
     f32x16 acc[2][2];
@@ -1980,71 +2148,103 @@ __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ri
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    // this wave's pieces of a chunk: A (dZ2, 32 pieces of two 512-byte rows) w, w + 8, w + 16, w + 24; B (H1 half, 16 pieces of four
-    // 256-byte rows) w, w + 8.  The per-lane source offsets do not depend on the chunk.
-    unsigned offA[4], offB[2];
-    int rowA[4], rowB[2];
+    // this wave's pieces of a chunk and plane: A (dZ2, pieces of two 512-byte rows) w, w + 8, ..; B (H1 half, pieces of four 256-byte
+    // rows) w, ..  The per-lane source offsets depend on neither the chunk nor the plane.
+    unsigned offA[G::nA2], offB[G::nB2];
+    int rowA[G::nA2], rowB[G::nB2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) offA[k] = wg_piece_src_swz<512>(w + 8 * k, lane, kMlpHid * 2, 0, rowA[k]);
+    for (int k = 0; k < G::nA2; ++k) offA[k] = wg_piece_src_swz<512>(w + 8 * k, lane, kMlpHid * 2, 0, rowA[k]);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) offB[k] = wg_piece_src_swz<256>(w + 8 * k, lane, kMlpHid * 2, 256 * part, rowB[k]);
+    for (int k = 0; k < G::nB2; ++k) offB[k] = wg_piece_src_swz<256>(w + 8 * k, lane, kMlpHid * 2, 256 * part, rowB[k]);
     const char* gA = reinterpret_cast<const char*>(P.dz2 + nb);
     const char* gB = reinterpret_cast<const char*>(P.h1 + nb);
+    const size_t plane_b = P.act_plane * 2;                          // bytes between two planes of a saved tensor
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane(wg_lds_addr(ring));
-    // piece k of this wave's six (0..3: dZ2, 4..5: H1) of chunk c into stage `stage`
+    // piece k of this wave's MAXP of chunk c into stage `stage`: plane k / NPP, then A pieces, then B pieces
     const auto issue = [&](int c, int stage, int k) {
-        const long long s = s_begin + (long long)c * kWgChunk;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + stage * kWgStage2 + w * 1024);
-        if (k < 4) wg_glds16(offA[k], wg_uniform_ptr(gA + s * (kMlpHid * 2)), dst + k * 8192);
-        else wg_glds16(offB[k - 4], wg_uniform_ptr(gB + s * (kMlpHid * 2)), dst + kWgChunk * 512 + (k - 4) * 8192);
+        const long long s = s_begin + (long long)c * CH;
+        const int pl = k / NPP, r = k % NPP;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + stage * G::kStage2 + pl * G::kPlane2 + w * 1024);
+        if (r < G::nA2) wg_glds16(offA[r], wg_uniform_ptr(gA + pl * plane_b + s * (kMlpHid * 2)), dst + r * 8192);
+        else wg_glds16(offB[r - G::nA2], wg_uniform_ptr(gB + pl * plane_b + s * (kMlpHid * 2)), dst + CH * 512 + (r - G::nA2) * 8192);
     };
     const auto stage_sync = [&](int c, int stage) {
-        const long long s = s_begin + (long long)c * kWgChunk;
-        char* dst = ring + stage * kWgStage2 + w * 1024 + lane * 16;
+        const long long s = s_begin + (long long)c * CH;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (s + rowA[k] < s_end) v = *reinterpret_cast<const uint4*>(gA + s * (kMlpHid * 2) + offA[k]);
-            *reinterpret_cast<uint4*>(dst + k * 8192) = v;
-        }
+        for (int pl = 0; pl < NS; ++pl) {
+            char* dst = ring + stage * G::kStage2 + pl * G::kPlane2 + w * 1024 + lane * 16;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (s + rowB[k] < s_end) v = *reinterpret_cast<const uint4*>(gB + s * (kMlpHid * 2) + offB[k]);
-            *reinterpret_cast<uint4*>(dst + kWgChunk * 512 + k * 8192) = v;
+            for (int k = 0; k < G::nA2; ++k) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (s + rowA[k] < s_end) v = *reinterpret_cast<const uint4*>(gA + pl * plane_b + s * (kMlpHid * 2) + offA[k]);
+                *reinterpret_cast<uint4*>(dst + k * 8192) = v;
+            }
+#pragma unroll
+            for (int k = 0; k < G::nB2; ++k) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (s + rowB[k] < s_end) v = *reinterpret_cast<const uint4*>(gB + pl * plane_b + s * (kMlpHid * 2) + offB[k]);
+                *reinterpret_cast<uint4*>(dst + CH * 512 + k * 8192) = v;
+            }
         }
     };
     const auto multiply = [&](int stage, auto&& piece) {
-        const char* ta = ring + stage * kWgStage2;
-        const char* tb = ta + kWgChunk * 512;
-        bf16x8 fa[2][2], fb[2][2];
+        const char* ta = ring + stage * G::kStage2;
+        const char* tb = ta + CH * 512;
+        if constexpr (NS == 1) {
+            bf16x8 fa[2][2], fb[2][2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) fa[0][a] = wg_frag32_swz<512>(ta, 0, 64 * wo + 32 * a, lane);
+            for (int a = 0; a < 2; ++a) fa[0][a] = wg_frag32_swz<512>(ta, 0, 64 * wo + 32 * a, lane);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) fb[0][b] = wg_frag32_swz<256>(tb, 0, 64 * wi + 32 * b, lane);
+            for (int b = 0; b < 2; ++b) fb[0][b] = wg_frag32_swz<256>(tb, 0, 64 * wi + 32 * b, lane);
 #pragma unroll
-        for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-            if (ks + 1 < kWgChunk / 16) {
+            for (int ks = 0; ks < G::KS; ++ks) {
+                if (ks + 1 < G::KS) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = wg_frag32_swz<512>(ta, 16 * (ks + 1), 64 * wo + 32 * a, lane);
+                    for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = wg_frag32_swz<512>(ta, 16 * (ks + 1), 64 * wo + 32 * a, lane);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = wg_frag32_swz<256>(tb, 16 * (ks + 1), 64 * wi + 32 * b, lane);
+                    for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = wg_frag32_swz<256>(tb, 16 * (ks + 1), 64 * wi + 32 * b, lane);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = ks; k < MAXP; k += G::KS) piece(k);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int ks = 0; ks < G::KS; ++ks) {
+                bf16x8 fa[NS][2], fb[NS][2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else piece(ks + 2);      // six pieces over the four k-steps: 2, 2, 1, 1
-            __builtin_amdgcn_sched_barrier(0);
+                for (int pl = 0; pl < NS; ++pl) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) fa[pl][a] = wg_frag32_swz<512>(ta + pl * G::kPlane2, 16 * ks, 64 * wo + 32 * a, lane);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) fb[pl][b] = wg_frag32_swz<256>(tb + pl * G::kPlane2, 16 * ks, 64 * wi + 32 * b, lane);
+                }
+#pragma unroll
+                for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SplitPairs<NS>::a[pi]][a], fb[SplitPairs<NS>::b[pi]][b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = ks; k < MAXP; k += G::KS) piece(k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     WgW3Sums w3;
     w3.q = -1;
-    // (requested BEHIND the first two chunks' pieces: in front of them, 28 vector-memory instructions per wave filled the CU's queue
-    // and the pieces' issue waited a memory round trip for room — 8 700 cycles from the kernel's start to the loop against 2 750)
-    wg_ring_loop(s_begin, s_end, 6, issue, stage_sync, multiply, [&] { if (P.w3part) w3.request(P, s_begin, s_end, part, kWgParts, tid); }, stamps);
+    // (requested BEHIND the first chunks' pieces: in front of them, 28 vector-memory instructions per wave filled the CU's queue
+    // and the pieces' issue waited a memory round trip for room)
+    wg_ring_loop<CH, G::STAGES, MAXP>(s_begin, s_end, MAXP, issue, stage_sync, multiply,
+                                      [&] { if (P.w3part) w3.request(P, s_begin, s_end, part, kWgParts, tid); }, stamps);
     if (P.w3part) w3.finish(slab);
     mlp_barrier();                                               // every wave is done with the ring: its memory carries the stores' tiles
     float* scratch = reinterpret_cast<float*>(ring) + w * (32 * kWgTrS);
@@ -2057,9 +2257,12 @@ __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ri
 
 // dW1[128 half .. +128, :] = dZ1[:, that half]^T . X and db1 of one slice; waves 4 (row blocks) x 2 (column groups: X blocks 0-2 | blocks
 // 3-4 and db1 from a fragment of ones).  Every element's products are accumulated in the order of the register-staged form.
+template <int NS>
 __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ring, int half, size_t nb, long long s_begin, long long s_end,
                                                float* slab, int tid, unsigned long long* stamps = nullptr)
 {
+    typedef WgGeom<NS> G;
+    constexpr int CH = G::CH, NXMAX = (G::kXPieces + 7) / 8, NPP = G::nA1 + NXMAX, MAXP = NS * NPP;
     const int lane = tid & 63, w = tid >> 6;
     const int rb = w & 3, cg = w >> 2;
     f32x16 acc[3];
@@ -2067,71 +2270,90 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
     for (int b = 0; b < 3; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-    // pieces: A (dZ1 half, 16 pieces of four 256-byte rows) w, w + 8; X (64 rows of 288 bytes = 18 pieces, copied as they lie) w, w + 8
-    // and, for waves 0 and 1, 16 + w
-    unsigned offA[2];
-    int rowA[2];
+    // pieces per plane: A (dZ1 half, pieces of four 256-byte rows) w, ..; X (CH rows of 288 bytes, copied as they lie) w, w + 8, ..
+    // below kXPieces (some waves have one piece less)
+    unsigned offA[G::nA1];
+    int rowA[G::nA1];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) offA[k] = wg_piece_src_swz<256>(w + 8 * k, lane, kMlpHid * 2, 256 * half, rowA[k]);
-    const int nx = w < 2 ? 3 : 2;
+    for (int k = 0; k < G::nA1; ++k) offA[k] = wg_piece_src_swz<256>(w + 8 * k, lane, kMlpHid * 2, 256 * half, rowA[k]);
+    const int nx = (G::kXPieces - w + 7) / 8;
     const char* gA = reinterpret_cast<const char*>(P.dz1 + nb);
     const char* gX = reinterpret_cast<const char*>(P.xs);
+    const size_t plane_b = P.act_plane * 2, xplane_b = P.xs_plane * 2;
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane(wg_lds_addr(ring));
-    // piece k of this wave's (0..1: dZ1 half, 2..4: X; waves 2.. have no piece 4, nobody a piece 5) of chunk c into stage `stage`
     const auto issue = [&](int c, int stage, int k) {
-        const long long s = s_begin + (long long)c * kWgChunk;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + stage * kWgStage1 + w * 1024);
-        if (k < 2) wg_glds16(offA[k], wg_uniform_ptr(gA + s * (kMlpHid * 2)), dst + k * 8192);
-        else if (k - 2 < nx) wg_glds16((unsigned)((w + 8 * (k - 2)) * 1024 + lane * 16), wg_uniform_ptr(gX + s * (kMlpInPad * 2)), dst + kWgChunk * 256 + (k - 2) * 8192);
+        const long long s = s_begin + (long long)c * CH;
+        const int pl = k / NPP, r = k % NPP;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + stage * G::kStage1 + pl * G::kPlane1 + w * 1024);
+        if (r < G::nA1) wg_glds16(offA[r], wg_uniform_ptr(gA + pl * plane_b + s * (kMlpHid * 2)), dst + r * 8192);
+        else if (r - G::nA1 < nx)
+            wg_glds16((unsigned)((w + 8 * (r - G::nA1)) * 1024 + lane * 16), wg_uniform_ptr(gX + pl * xplane_b + s * (kMlpInPad * 2)), dst + CH * 256 + (r - G::nA1) * 8192);
     };
     const auto stage_sync = [&](int c, int stage) {
-        const long long s = s_begin + (long long)c * kWgChunk;
-        char* dst = ring + stage * kWgStage1 + w * 1024 + lane * 16;
+        const long long s = s_begin + (long long)c * CH;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (s + rowA[k] < s_end) v = *reinterpret_cast<const uint4*>(gA + s * (kMlpHid * 2) + offA[k]);
-            *reinterpret_cast<uint4*>(dst + k * 8192) = v;
-        }
+        for (int pl = 0; pl < NS; ++pl) {
+            char* dst = ring + stage * G::kStage1 + pl * G::kPlane1 + w * 1024 + lane * 16;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k < nx) {
-                const int o = (w + 8 * k) * 1024 + lane * 16;
+            for (int k = 0; k < G::nA1; ++k) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (s + o / (kMlpInPad * 2) < s_end) v = *reinterpret_cast<const uint4*>(gX + s * (kMlpInPad * 2) + o);
-                *reinterpret_cast<uint4*>(dst + kWgChunk * 256 + k * 8192) = v;
+                if (s + rowA[k] < s_end) v = *reinterpret_cast<const uint4*>(gA + pl * plane_b + s * (kMlpHid * 2) + offA[k]);
+                *reinterpret_cast<uint4*>(dst + k * 8192) = v;
+            }
+#pragma unroll
+            for (int k = 0; k < NXMAX; ++k) {
+                if (k < nx) {
+                    const int o = (w + 8 * k) * 1024 + lane * 16;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (s + o / (kMlpInPad * 2) < s_end) v = *reinterpret_cast<const uint4*>(gX + pl * xplane_b + s * (kMlpInPad * 2) + o);
+                    *reinterpret_cast<uint4*>(dst + CH * 256 + k * 8192) = v;
+                }
             }
         }
     };
     const bf16x8 ones = bf16x8_ones();
     const auto multiply = [&](int stage, auto&& piece) {
-        const char* ta = ring + stage * kWgStage1;
-        const char* tb = ta + kWgChunk * 256;
+        const char* ta = ring + stage * G::kStage1;
+        const char* tb = ta + CH * 256;
 #pragma unroll
-        for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-            const bf16x8 fa = wg_frag32_swz<256>(ta, 16 * ks, 32 * rb, lane);
+        for (int ks = 0; ks < G::KS; ++ks) {
+            bf16x8 fa[NS];
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) fa[pl] = wg_frag32_swz<256>(ta + pl * G::kPlane1, 16 * ks, 32 * rb, lane);
             if (cg == 0) {
-                bf16x8 fb[3];
+                bf16x8 fb[NS][3];
 #pragma unroll
-                for (int b = 0; b < 3; ++b) fb[b] = wg_frag32_lin<kMlpInPad * 2>(tb, 16 * ks, 32 * b, lane);
+                for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
+                    for (int b = 0; b < 3; ++b) fb[pl][b] = wg_frag32_lin<kMlpInPad * 2>(tb + pl * G::kPlane1, 16 * ks, 32 * b, lane);
+#pragma unroll
+                for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SplitPairs<NS>::a[pi]], fb[SplitPairs<NS>::b[pi]][b], acc[b], 0, 0, 0);
             } else {
-                bf16x8 fb[2];
+                bf16x8 fb[NS][2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) fb[b] = wg_frag32_lin<kMlpInPad * 2>(tb, 16 * ks, 32 * (3 + b), lane);
+                for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, ones, acc[2], 0, 0, 0);      // every column: db1 of this wave's rows
+                    for (int b = 0; b < 2; ++b) fb[pl][b] = wg_frag32_lin<kMlpInPad * 2>(tb + pl * G::kPlane1, 16 * ks, 32 * (3 + b), lane);
+#pragma unroll
+                for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SplitPairs<NS>::a[pi]], fb[SplitPairs<NS>::b[pi]][b], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int pl = 0; pl < NS; ++pl)
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pl], ones, acc[2], 0, 0, 0);      // every column: db1 of this wave's rows
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (ks < 2) { piece(2 * ks); piece(2 * ks + 1); } else if (ks == 2) piece(4);
+#pragma unroll
+            for (int k = ks; k < MAXP; k += G::KS) piece(k);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // (np differs by wave: 5 glds per chunk for waves 0 and 1, 4 for the others — wave-uniform)
     WgW3Sums w3;
-    wg_ring_loop(s_begin, s_end, 2 + nx, issue, stage_sync, multiply, [&] { w3.request(P, s_begin, s_end, 2 + half, kWgParts, tid); }, stamps);
+    // (np differs by wave — some have one X piece less per plane — wave-uniform)
+    wg_ring_loop<CH, G::STAGES, MAXP>(s_begin, s_end, NS * (G::nA1 + nx), issue, stage_sync, multiply,
+                                      [&] { w3.request(P, s_begin, s_end, 2 + half, kWgParts, tid); }, stamps);
     w3.finish(slab);
     mlp_barrier();
     float* scratch = reinterpret_cast<float*>(ring) + w * (32 * kWgTrS);
@@ -2150,6 +2372,7 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
     }
 }
 
+template <int NS = 1>
 __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradParams P)
 {
     __shared__ __attribute__((aligned(1024))) char lds_raw[kWgLdsBytes];
@@ -2180,7 +2403,7 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
     const auto flush_stamps = [] {};
 #endif
     if (PNR_WG_GLDS && part < 2) {
-        wgrad_dw2_glds(P, lds_raw, part, nb, s_begin, s_end, slab, tid, my_stamps);
+        wgrad_dw2_glds<NS>(P, lds_raw, part, nb, s_begin, s_end, slab, tid, my_stamps);
         flush_stamps();
     } else if (part < 2) {
         // dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half]; waves 4 x 2, each 64 (o) x 64 (i)
@@ -2250,7 +2473,7 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
         // one-role form below: the same bits.
         const int half = part - 2;
         if (PNR_WG_GLDS) {
-            wgrad_dw1_glds(P, lds_raw, half, nb, s_begin, s_end, slab, tid, my_stamps);
+            wgrad_dw1_glds<NS>(P, lds_raw, half, nb, s_begin, s_end, slab, tid, my_stamps);
         } else {
             __bf16* ta = lds;                        // dZ1 chunk, this half's columns: [64][128], stride kTrHalf
             __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
@@ -2520,6 +2743,7 @@ struct MlpAdamParams {
     float* means;              // [8]
     const float* kl_coeff; const float* ent_coeff; float vf_coeff;
     int first_net;             // blockIdx.y + first_net = net
+    int planes;                // bf16 planes of the packed weights that are refreshed (1: bf16 operands; 2, 3: split float32)
 };
 
 __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
@@ -2581,8 +2805,18 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
         P.m[si] = m; P.v[si] = v; *dst = pv;
     }
     __bf16* wp = P.wpack + (size_t)net * kPackElems;
-    if (wp0 >= 0) wp[wp0] = (__bf16)pv;
-    if (wp1 >= 0) wp[wp1] = (__bf16)pv;
+    if (P.planes <= 1) {
+        if (wp0 >= 0) wp[wp0] = (__bf16)pv;
+        if (wp1 >= 0) wp[wp1] = (__bf16)pv;
+    } else {
+        float r = pv;
+        for (int pl = 0; pl < P.planes; ++pl) {
+            const __bf16 b = (__bf16)r;
+            if (wp0 >= 0) wp[pl * kWPlane + wp0] = b;
+            if (wp1 >= 0) wp[pl * kWPlane + wp1] = b;
+            r -= (float)b;
+        }
+    }
     if (bp >= 0) P.bias[net * kBiasElems + bp] = pv;
 }
 

@@ -1,5 +1,8 @@
 """The PPO driver's two MLPs on the hand-written bf16 MFMA kernels of csrc/pnr_mlp.h (C ABI: pnr_mlp_*).
 
+``planes`` selects the operands' precision (include/pioneer_amd.h, pnr_mlp_pack): 1 = bf16 (the fast path), 2 / 3 = every float32
+operand as the sum of 2 / 3 bf16 planes (3: the accuracy of a float32 GEMM — what the reference's torch learner computes in).
+
 ``HipMLP`` owns the packed bf16 weights and the activation / gradient workspaces for one ``ActorCritic`` and exposes
 
 * ``forward_nograd``  the sampling path: heads of a batch of RAW observations, the MeanStdFilter applied on load;
@@ -28,9 +31,15 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+PLANES = {True: 1, "bf16": 1, "bf16x2": 2, "f32": 3}      # PPOConfig.hip_kernels -> bf16 planes per operand
+
+
 class HipMLP:
-    def __init__(self, model: nn.Module, max_batch: int, device):
+    def __init__(self, model: nn.Module, max_batch: int, device, planes: int = 1):
         self.lib = _lib.load_library()
+        self.planes = int(planes)
+        if self.planes not in (1, 2, 3):
+            raise AssertionError(f"planes must be 1, 2 or 3, got {planes}")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise AssertionError("HipMLP needs a HIP device")
@@ -46,7 +55,7 @@ class HipMLP:
         self.params = [t for lins in (pol, val) for l in lins for t in (l.weight, l.bias)]     # 12, net-major
         assert all(p.dtype == torch.float32 and p.is_contiguous() and p.device == self.device for p in self.params)
         bf, f32 = dict(dtype=torch.bfloat16, device=self.device), dict(dtype=torch.float32, device=self.device)
-        self.wpack = torch.empty(int(self.lib.pnr_mlp_pack_elems()), **bf)
+        self.wpack = torch.empty(self.planes * int(self.lib.pnr_mlp_pack_elems()), **bf)
         self.bias = torch.empty(int(self.lib.pnr_mlp_bias_elems()), **f32)
         B = self.max_batch
         self._train_ws = None
@@ -64,10 +73,12 @@ class HipMLP:
         if self._train_ws is None:
             B = self.max_batch
             bf, f32 = dict(dtype=torch.bfloat16, device=self.device), dict(dtype=torch.float32, device=self.device)
+            P = self.planes
             self._train_ws = {
                 "xs": torch.empty((B, IN_PAD), **bf),
-                "h1": torch.empty((2, B, HID), **bf), "h2": torch.empty((2, B, HID), **bf),
-                "dz1": torch.empty((2, B, HID), **bf), "dz2": torch.empty((2, B, HID), **bf),
+                # (planes > 1: H2 is never stored — the fused kernel makes layer 3's products itself — so one plane of it is enough)
+                "h1": torch.empty((P, 2, B, HID), **bf), "h2": torch.empty((2, B, HID), **bf),
+                "dz1": torch.empty((P, 2, B, HID), **bf), "dz2": torch.empty((P, 2, B, HID), **bf),
                 "slabs": torch.empty(int(self.lib.pnr_mlp_slab_floats(B)), **f32),
                 "head": torch.empty(2 * B * HEAD, **f32), "g": torch.empty(2 * B * HEAD, **f32),
                 "partials": torch.empty((2 * ((B + 63) // 64), 8), **f32),      # one row per (64-sample tile, net)
@@ -78,15 +89,17 @@ class HipMLP:
     def pack(self) -> None:
         """bf16 copies of the current master weights (padded, plus the transposes the backward pass reads)."""
         _lib.check(self.lib.pnr_mlp_pack(self._ptrs(self.params), self.n3[0], self.n3[1], _p(self.wpack), _p(self.bias),
-                                         self._stream()))
+                                         self.planes, self._stream()))
 
     def _launch_forward(self, B, obs, idx, filt, head, save):
+        if save and self.planes != 1:
+            raise AssertionError("the autograd binding (saved activations + pnr_mlp_backward) is bf16-only: use train_step for planes > 1")
         ws = self._workspace() if save else None
         f = filt if filt is not None else (None, None, None, None)
         self._batch_of_ws(B)       # the kernels index the saved activations as [2][B][256] with the CURRENT batch size
         _lib.check(self.lib.pnr_mlp_forward(B, _p(obs), _p(idx), _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(self.wpack), _p(self.bias),
                                             _p(head), _p(ws["xs"]) if ws else None, _p(ws["h1"]) if ws else None,
-                                            _p(ws["h2"]) if ws else None, 0, 2, self._stream()))
+                                            _p(ws["h2"]) if ws else None, 0, 2, self.planes, self._stream()))
 
     def _batch_of_ws(self, B):
         if B > self.max_batch:
@@ -130,10 +143,10 @@ class HipMLP:
             if x is not None:
                 assert x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == shape and x.device == self.device, name
         assert (a_max is None) or (env_actions is not None and env_actions.data_ptr() != actions.data_ptr())
-        assert xs_out is None or (xs_out.dtype == torch.bfloat16 and xs_out.is_contiguous() and tuple(xs_out.shape) == (B, 144))
+        assert xs_out is None or (self.planes == 1 and xs_out.dtype == torch.bfloat16 and xs_out.is_contiguous() and tuple(xs_out.shape) == (B, 144))
         _lib.check(self.lib.pnr_mlp_act(B, _p(obs), _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(self.wpack), _p(self.bias), _p(noise),
                                         _p(a_max), _p(head), _p(mean), _p(log_std), _p(values), _p(actions), _p(env_actions),
-                                        _p(xs_out), self._stream()))
+                                        _p(xs_out), self.planes, self._stream()))
 
     @torch.no_grad()
     def rollout(self, env, filt, noise: torch.Tensor, a_max: Optional[torch.Tensor], *, obs: torch.Tensor, mean: torch.Tensor,
@@ -143,6 +156,7 @@ class HipMLP:
         [T + 1, N, 137], the draw and clip of ``act``, and the step of ``env`` (a kinematic-mode PioneerVectorEnv with env-major
         layouts) with that action — reward / done / truncated [T, N], the next observation into slot t + 1.  Equals T x (act,
         env.vector_step) bit for bit; the env's state advances as if they had been called."""
+        assert self.planes == 1, "the resident rollout kernel keeps bf16 weights in registers: planes > 1 samples with act() + vector_step()"
         T, N = int(noise.shape[0]), int(env.num_envs)
         f = filt if filt is not None else (None, None, None, None)
         for name, x, shape in (("noise", noise, (T, N, 6)), ("mean", mean, (T, N, 6)), ("log_std", log_std, (T, N, 6)), ("values", values, (T, N)),
@@ -226,6 +240,7 @@ class HipMLP:
         The buffers live in this object (one set per ``slot``: the learner gathers epoch e + 1 into the other set while epoch e's
         updates read this one) and are overwritten by the next call with the same slot."""
         if xs_rows is not None:       # the sampler's saved net inputs (act(xs_out=...)): copied, nothing is filtered
+            assert self.planes == 1, "planes > 1: the input planes are made from the float32 observations"
             assert xs_rows.dtype == torch.bfloat16 and xs_rows.is_contiguous() and xs_rows.shape[1] == 144 and xs_rows.device == self.device
             assert idx.dtype == torch.int64 and idx.is_contiguous()
             obs_p, R, filt = None, int(xs_rows.shape[0]), None
@@ -237,9 +252,11 @@ class HipMLP:
         if sets is None:
             sets = self._gathered = {}
         g = sets.get(slot)
-        if g is None or g["xs"].shape[0] < n:
+        if g is None or g["xs"].shape[-2] != n:
             f32 = dict(dtype=torch.float32, device=self.device)
-            g = {"xs": torch.empty((n, 144), dtype=torch.bfloat16, device=self.device)}
+            # planes > 1: [planes, n, 144] — a minibatch is the slice [:, s:s + mbs] (train_step(xs_in=...) takes the strided view's rows
+            # through a per-minibatch plane-major copy, see train_step)
+            g = {"xs": torch.empty((n, 144) if self.planes == 1 else (self.planes, n, 144), dtype=torch.bfloat16, device=self.device)}
             for k in self.REC_KEYS:
                 g[k] = torch.empty((n, 6) if k in ("actions", "mean", "log_std") else (n,), **f32)
             sets[slot] = g
@@ -253,8 +270,8 @@ class HipMLP:
                 assert v.dtype == torch.float32 and v.is_contiguous() and v.device == self.device and v.shape[0] == R, k
             src = [_p(rec[k]) for k in self.REC_KEYS]
         _lib.check(self.lib.pnr_mlp_gather(n, _p(idx), obs_p, _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), *src, _p(g["xs"]),
-                                           *[_p(g[k]) for k in self.REC_KEYS], _p(rec_rows), _p(xs_rows), self._stream()))
-        return {k: v[:n] for k, v in g.items()}
+                                           *[_p(g[k]) for k in self.REC_KEYS], _p(rec_rows), _p(xs_rows), self.planes, self._stream()))
+        return {k: (v[:n] if (k != "xs" or self.planes == 1) else v) for k, v in g.items()}
 
     def train_step(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float, means_out: torch.Tensor,
                    lr: float, betas=(0.9, 0.999), eps: float = 1e-8, flat_grad: Optional[torch.Tensor] = None,
@@ -266,9 +283,14 @@ class HipMLP:
         behind this object's back (construction, restore)."""
         if xs_in is not None:
             # the epoch's pre-gathered rows (gather_epoch): inputs and record are read row by row, nothing is filtered
-            assert xs_in.dtype == torch.bfloat16 and xs_in.is_contiguous() and xs_in.shape[1] == 144 and xs_in.device == self.device
+            assert xs_in.dtype == torch.bfloat16 and xs_in.shape[-1] == 144 and xs_in.device == self.device
             assert obs is None and idx is None and filt is None
-            B = R = int(xs_in.shape[0])
+            if self.planes == 1:
+                assert xs_in.dim() == 2 and xs_in.is_contiguous()
+            else:
+                # [planes, B, 144], possibly a slice [:, s:s + B] of an epoch's gathered planes: rows contiguous, planes stride(0) apart
+                assert xs_in.dim() == 3 and xs_in.shape[0] == self.planes and xs_in.stride(2) == 1 and xs_in.stride(1) == 144
+            B = R = int(xs_in.shape[-2])
         else:
             self._check_inputs(obs, idx, filt, self.device)
             B = int(idx.numel()) if idx is not None else int(obs.shape[0])
@@ -304,8 +326,12 @@ class HipMLP:
         w3 = ws["w3part"]
         if nets is not None and tuple(nets) == (1, 1):
             w3 = w3[w3.numel() // 2:]
-        if self.w3_partials:                   # (False: H2 is stored and read back by the weight-gradient kernel — the A/B; same bits)
+        if self.w3_partials or self.planes > 1:  # (False: H2 is stored and read back by the weight-gradient kernel — the A/B; same bits)
             s.w3_partials, s.w3_partial_floats = w3.data_ptr(), w3.numel()
+        s.planes = self.planes
+        if self.planes > 1:
+            assert xs_in is not None, "planes > 1: train_step takes the pre-gathered input planes (gather_epoch)"
+            s.xs_in_plane = int(xs_in.stride(0))
         s.means = means_out.data_ptr()
         if flat_grad is not None:
             assert flat_grad.dtype == torch.float32 and flat_grad.is_contiguous() and flat_grad.numel() == int(self.lib.pnr_mlp_grad_floats())
@@ -316,6 +342,7 @@ class HipMLP:
         """Adam on the all-reduced bucket ``flat_grad`` ([pnr_mlp_grad_floats()], always the WHOLE bucket: ``nets`` selects the half
         that is applied)."""
         s = self._step_args(lr, betas, eps, nets)
+        s.planes = self.planes
         _lib.check(self.lib.pnr_mlp_adam(C.byref(s), _p(flat_grad), C.c_float(grad_scale), self._stream()))
 
     def policy_loss(self, obs, idx, filt, rec, kl_c, ent_c, clip: float, vf_clip: float, vf_coeff: float) -> torch.Tensor:

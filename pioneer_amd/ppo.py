@@ -56,8 +56,10 @@ class PPOConfig:
     filter_clip: float = 10.0
     seed: int = 0
     # engine option (no reference counterpart): on a HIP device, run the reference-shaped nets, the loss, Adam, GAE and the
-    # shuffle on the hand-written kernels (bf16 MFMA operands); False = the float32 torch formulation
-    hip_kernels: bool = True
+    # shuffle on the hand-written kernels.  True / "bf16": bf16 MFMA operands (the fast path); "f32": every operand as three bf16
+    # planes = float32-accurate products on the same kernels (the reference's learner is float32 torch, pioneer_knm_train.py:47),
+    # "bf16x2": two planes (16 significant bits); False = the float32 torch formulation
+    hip_kernels: object = True
 
     @classmethod
     def from_dict(cls, d: Dict) -> "PPOConfig":
@@ -67,7 +69,19 @@ class PPOConfig:
             d.setdefault("hip_kernels", bool(d.pop("amp_bf16")))
         return cls(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k in cls.__dataclass_fields__})
 
+    def mlp_planes(self) -> int:
+        """bf16 planes per MFMA operand of the hand-written kernels (pioneer_amd.mlp.PLANES)."""
+        from .mlp import PLANES
+        if self.hip_kernels not in PLANES:
+            raise AssertionError(f"hip_kernels must be one of True, 'bf16', 'bf16x2', 'f32' or False, got {self.hip_kernels!r}")
+        return PLANES[self.hip_kernels]
+
+    def mlp_dtype(self) -> str:
+        return {1: "bf16", 2: "bf16x2 (two bf16 planes per float32 operand)", 3: "f32 (three bf16 planes per operand: float32-accurate products)"}[self.mlp_planes()]
+
     def wants_hip(self, device) -> bool:
+        if self.hip_kernels:
+            self.mlp_planes()          # a misspelt precision fails here, not as a silent torch run
         return (bool(self.hip_kernels) and torch.device(device).type == "cuda" and self.obs_dim == 137 and self.act_dim == 6
                 and tuple(self.fcnet_hiddens) == (256, 256) and not self.grad_clip)
 
@@ -384,7 +398,7 @@ class PPOLearner:
         if self._mlp is None or self._mlp.max_batch < batch:
             from .mlp import HipMLP
             old = self._mlp
-            self._mlp = HipMLP(self.model, batch, self.device)
+            self._mlp = HipMLP(self.model, batch, self.device, planes=self.cfg.mlp_planes())
             if old is not None:                                   # keep the optimiser state across a workspace resize
                 for a, b in zip(self._mlp.adam_state(), old.adam_state()):
                     a.copy_(b)
@@ -434,6 +448,7 @@ class PPOLearner:
             self._epochs += 1
             return mlp.gather_epoch(rec["obs"], perm, filt, None, rec_rows=rows, xs_rows=rec.get("xs"), slot=e % 2)
 
+        xs_rows = (lambda g_, s_: g_["xs"][s_:s_ + mbs]) if mlp.planes == 1 else (lambda g_, s_: g_["xs"][:, s_:s_ + mbs])
         nxt, nxt_ready = gather(0), None
         for e in range(cfg.num_sgd_iter):
             g = nxt
@@ -466,7 +481,7 @@ class PPOLearner:
                         with torch.cuda.stream(st):
                             mlp.train_step(None, None, None, {k_: g[k_][s:s + mbs] for k_ in mlp.REC_KEYS}, self._kl_c, self._ent_c,
                                            cfg.clip_param, cfg.vf_clip_param, cfg.vf_loss_coeff, self._means2[net, k], cfg.lr,
-                                           flat_grad=self._flat_grad, xs_in=g["xs"][s:s + mbs], nets=(net, 1))
+                                           flat_grad=self._flat_grad, xs_in=xs_rows(g, s), nets=(net, 1))
                             pdist.allreduce_sum_(self._flat_grad[net * ge:(net + 1) * ge])
                             mlp.adam(self._flat_grad, 1.0 / world, cfg.lr, nets=(net, 1))
                     k += 1
@@ -478,7 +493,7 @@ class PPOLearner:
             for s in range(0, B - mbs + 1, mbs):
                 mlp.train_step(None, None, None, {k_: g[k_][s:s + mbs] for k_ in mlp.REC_KEYS}, self._kl_c, self._ent_c, cfg.clip_param,
                                cfg.vf_clip_param, cfg.vf_loss_coeff, self._means[k], cfg.lr,
-                               flat_grad=self._flat_grad if multi else None, xs_in=g["xs"][s:s + mbs])
+                               flat_grad=self._flat_grad if multi else None, xs_in=xs_rows(g, s))
                 if multi:
                     pdist.allreduce_sum_(self._flat_grad)          # the one 0.86 MB bucket
                     mlp.adam(self._flat_grad, 1.0 / world, cfg.lr)
@@ -522,7 +537,8 @@ class PPOTrainer:
         # kinematic mode with env-major layouts: the sampler's T steps are one resident launch (dynamics mode keeps the per-step
         # pnr_mlp_act + pnr_step pair); False forces the per-step form (the A/B and the equality test)
         ec = env.engine_config
-        self.resident_rollout = self.hip and ec.mode == "kinematic" and ec.obs_layout == "env_major" and ec.action_layout == "env_major"
+        self.resident_rollout = self.hip and ec.mode == "kinematic" and ec.obs_layout == "env_major" and ec.action_layout == "env_major" \
+            and self.cfg.mlp_planes() == 1          # (the resident kernel keeps bf16 weights in registers; split operands sample per step)
         self._graph = None
         self._eager_collects = 0        # eager (uncaptured) collects done by this trainer object: gates the graph capture
         T, N, D, A = self.cfg.rollout_fragment_length, env.num_envs, self.cfg.obs_dim, self.cfg.act_dim
@@ -545,11 +561,12 @@ class PPOTrainer:
         }
         if self.hip:
             from .mlp import HipMLP
-            self.sample_mlp = HipMLP(self.learner.model, N, self.device)   # packed weights for the rollout's T forwards
+            self.sample_mlp = HipMLP(self.learner.model, N, self.device, planes=self.cfg.mlp_planes())   # packed weights for the rollout's T forwards
             self._last_heads = torch.empty((2, N, 16), **f32)
             self._last_v = torch.empty((N,), **f32)
             # the nets' inputs as the sampler saw them (filtered, bf16): what the learner trains on, 288 bytes per sample
-            self.buf["xs"] = torch.empty((T, N, 144), dtype=torch.bfloat16, device=self.device)
+            if self.cfg.mlp_planes() == 1:
+                self.buf["xs"] = torch.empty((T, N, 144), dtype=torch.bfloat16, device=self.device)
             self._adv_stats = torch.zeros(3, dtype=torch.float64, device=self.device)     # sum, sum of squares, count (pnr_ppo_gae)
         else:
             self.buf["obs"] = torch.empty((T, N, D), **f32)            # filtered, what the nets saw
@@ -587,10 +604,11 @@ class PPOTrainer:
                 mlp.rollout(self.env, filt, noise, self.a_max if clip else None, obs=self.raw_in, mean=buf["mean"], log_std=buf["log_std"],
                             values=buf["values"], actions=buf["actions"], reward=buf["reward"], done=buf["done"], truncated=buf["trunc"],
                             xs_out=buf["xs"])
+            xs = buf.get("xs")                              # (split operands: the learner re-makes its input planes from the observations)
             for t in range(0 if not self.resident_rollout else T, T):
                 mlp.act(self.raw_in[t], filt, noise[t], self.a_max if clip else None, mean=buf["mean"][t], log_std=buf["log_std"][t],
                         values=buf["values"][t], actions=buf["actions"][t], env_actions=self._env_act if clip else None,
-                        xs_out=buf["xs"][t])
+                        xs_out=xs[t] if xs is not None else None)
                 self._step_env(t, self._env_act if clip else buf["actions"][t])
             last = mlp.forward_nograd(self.raw_in[T], None, filt, out=self._last_heads)
             self._last_v.copy_(last[1, :, 0])           # bootstrap value of the state after the last step
@@ -645,7 +663,8 @@ class PPOTrainer:
         if self.hip:
             batch.update(obs=flat(self.raw_in[:T]), filt=self._filt())      # raw: the kernels filter on load
             batch["adv_stats"] = self._adv_stats
-            batch["xs"] = flat(buf["xs"])
+            if "xs" in buf:
+                batch["xs"] = flat(buf["xs"])
         else:
             batch["obs"] = flat(buf["obs"])
         return batch

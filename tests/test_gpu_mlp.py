@@ -323,3 +323,115 @@ def test_weight_stationary_training_kernel_is_bit_identical(tmp_path):
                         "pre_gathered or graph_replay", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "4 passed" in r.stdout, r.stdout[-1000:]
+
+
+# ---- float32-accurate operands (r04): every MFMA operand as 2 / 3 bf16 planes (include/pioneer_amd.h, pnr_mlp_pack) -----------------
+# The reference's learner is float32 torch (pioneer_knm_train.py:47): tolerances against plain float32 torch autograd, written here:
+#   planes = 3 ("f32"):    heads relative L2 <= 1e-5 (measured ~3e-7), gradients <= 1e-4 (measured ~1e-6)
+#   planes = 2 ("bf16x2"): heads <= 2e-5 (16 significant bits: ~8e-6), gradients <= 2e-4
+SPLIT_TOL = {3: (1e-5, 1e-4), 2: (2e-5, 2e-4)}
+
+
+def _f32_reference(model, x):
+    with torch.no_grad():
+        return model.policy(x), model.value(x)
+
+
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("B,rows,with_filter", [(4099, 9000, True), (32768, None, False), (1, None, True)])
+def test_split_operand_forward_matches_float32_torch(planes, B, rows, with_filter):
+    from pioneer_amd.mlp import HipMLP
+    model, _, obs, idx, filt = make(B, seed=31, rows=rows, with_filter=with_filter)
+    mlp = HipMLP(model, B, obs.device, planes=planes)
+    mlp.pack()
+    head = mlp.forward_nograd(obs, idx, filt)
+    x = net_input(obs, idx, filt)
+    ref_p, ref_v = _f32_reference(model, x)
+    ref64_p, ref64_v = model.double().policy(x.double()), model.double().value(x.double())
+    model.float()
+    tol = SPLIT_TOL[planes][0]
+    if B == 1:      # one value-head number (here -0.008, a sum of terms ~0.1): relative error of a single cancelling scalar says nothing
+        assert float((head[1, :, :1].double() - ref64_v).abs().max()) <= tol * 0.5
+    else:
+        assert rel(head[1, :, :1], ref64_v) <= tol, rel(head[1, :, :1], ref64_v)
+    assert rel(head[0, :, :12], ref64_p) <= tol, rel(head[0, :, :12], ref64_p)
+    if planes == 3:       # as close to the float64 truth as torch's own float32 forward is (both ~1e-7): float32-equivalent
+        assert rel(head[0, :, :12], ref64_p) <= max(4.0 * rel(ref_p, ref64_p), 1e-6)
+    # the bf16 path on the same inputs, for scale
+    mlp1 = HipMLP(model, B, obs.device); mlp1.pack()
+    assert rel(mlp1.forward_nograd(obs, idx, filt)[0, :, :12], ref64_p) > 50 * rel(head[0, :, :12], ref64_p)
+
+
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("B", [8192, 4099])
+def test_split_operand_train_step_matches_float32_autograd_and_adam(planes, B):
+    """pnr_mlp_train_step with split operands on pre-gathered input planes: (a) its gradient (the flat bucket) against float32 torch
+    autograd of the PPO loss (PPOLearner.loss: the torch formulation), parameter by parameter; (b) the loss means; (c) the update
+    against torch.optim.Adam on the autograd gradients; (d) the fused reduce + Adam form against the flat-bucket form, bit for bit;
+    (e) every plane of the repacked weights against a fresh pack."""
+    import copy
+    from pioneer_amd.mlp import HipMLP
+    from pioneer_amd.ppo import PPOConfig, PPOLearner
+    R, lr = 12000, 1e-3
+    model, _, obs, _, filt = make(B, seed=23, rows=R, with_filter=True)
+    dev = obs.device
+    rec = _record(R, dev)
+    klc = torch.tensor(0.2, device=dev); entc = torch.tensor(0.01, device=dev)
+    mlp = HipMLP(model, B, dev, planes=planes)
+    model_f = copy.deepcopy(model); mlp_f = HipMLP(model_f, B, dev, planes=planes)
+    # the torch formulation on a copy of the weights
+    cfg = PPOConfig(lr=lr, hip_kernels=False, kl_coeff=0.2, vf_clip_param=10.0, clip_param=0.3, vf_loss_coeff=1.0)
+    L = PPOLearner(cfg, dev)
+    L.model.load_state_dict(model.state_dict())
+    L.kl_coeff = 0.2
+    params_l = [p for net in (L.model.policy, L.model.value) for l in net if isinstance(l, torch.nn.Linear) for p in (l.weight, l.bias)]
+    model_t = copy.deepcopy(model)                               # torch.optim.Adam fed with the kernels' gradients
+    params_t = [p for net in (model_t.policy, model_t.value) for l in net if isinstance(l, torch.nn.Linear) for p in (l.weight, l.bias)]
+    opt = torch.optim.Adam(params_t, lr=lr)
+    means = torch.zeros(4, 8, device=dev); means_f = torch.zeros(4, 8, device=dev)
+    flat = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), device=dev)
+    mlp.pack(); mlp_f.pack()
+    g = torch.Generator(device=dev).manual_seed(2)
+    gtol = SPLIT_TOL[planes][1]
+    for it in range(4):
+        perm = torch.randperm(R, generator=g, device=dev).contiguous()
+        ga = mlp.gather_epoch(obs, perm, filt, rec)
+        gb = mlp_f.gather_epoch(obs, perm, filt, rec)
+        s0 = 64 * 7                                               # a minibatch inside the epoch's rows: plane stride R * 144
+        mb = {k: ga[k][s0:s0 + B] for k in mlp.REC_KEYS}
+        mlp.train_step(None, None, None, mb, klc, entc, 0.3, 10.0, 1.0, means[it], lr, xs_in=ga["xs"][:, s0:s0 + B])
+        mlp_f.train_step(None, None, None, {k: gb[k][s0:s0 + B] for k in mlp.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means_f[it], lr,
+                         flat_grad=flat, xs_in=gb["xs"][:, s0:s0 + B])
+        # float32 autograd on the same minibatch
+        rows_ = perm[s0:s0 + B]
+        x = net_input(obs, rows_, filt)
+        L._ent_c.fill_(0.01); L._kl_c.fill_(0.2)
+        batch = {"obs": x, "actions": rec["actions"][rows_], "mean": rec["mean"][rows_], "log_std": rec["log_std"][rows_],
+                 "logp": rec["logp"][rows_], "adv": rec["adv"][rows_], "vtarg": rec["vtarg"][rows_], "values": rec["values"][rows_]}
+        for prm in params_l:
+            prm.grad = None
+        loss, info = L.loss(batch)
+        loss.backward()
+        for gk, prm, nm in zip(_unpack_flat(flat), params_l, NAMES):
+            assert rel(gk, prm.grad) <= gtol, (it, nm, rel(gk, prm.grad))
+        assert abs(float(means[it, 4]) - float(loss)) <= 2e-5 * max(1.0, abs(float(loss))), (float(means[it, 4]), float(loss))
+        for prm, gk in zip(params_t, _unpack_flat(flat)):
+            prm.grad = gk.clone()
+        opt.step()
+        mlp_f.adam(flat, 1.0, lr)
+        assert torch.equal(means[it], means_f[it])
+        for a, b in zip(mlp_f.params, params_t):                  # same gradients: the two Adams agree to rounding
+            assert float((a - b).abs().max()) <= 2e-3 * lr, (it, float((a - b).abs().max()))
+        with torch.no_grad():                                     # the autograd reference follows the kernels' weights
+            for a, b in zip(params_l, mlp_f.params):
+                a.copy_(b)
+    for a, c in zip(mlp.params, mlp_f.params):
+        assert torch.equal(a, c)                                  # fused reduce + Adam == flat-bucket form
+    w_now = mlp.wpack.clone(); b_now = mlp.bias.clone()
+    mlp.pack()
+    assert torch.equal(w_now, mlp.wpack) and torch.equal(b_now, mlp.bias)         # every plane of the refreshed weights is exact
+    # the planes add up to the float32 master weights (planes = 3: exactly; 2: to 2^-16)
+    n = int(mlp.lib.pnr_mlp_pack_elems())
+    tot = mlp.wpack.view(planes, n).float().sum(0)
+    one = HipMLP(model, B, dev); one.pack()
+    assert float((tot - one.wpack.float()).abs().max()) <= 2.0 ** -8 * float(one.wpack.float().abs().max())
