@@ -42,6 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+LEARNER_TRAFFIC = "learner_pmc_traffic.json"      # profiles/: FETCH/WRITE bytes of the learner kernels per update (tools/learner_traffic.py)
 BYTES_PER_ENV_STEP = 750   # 24 action + 92 state in + 80 state out + 548 obs + 6 reward/flags
 STEP_IO_BYTES = 24 + 548 + 6   # per env-step regardless of fusion
 STATE_BYTES = 92 + 80          # per env per LAUNCH (a fused rollout keeps state in registers)
@@ -92,6 +93,8 @@ def parse_args(argv=None):
     ap.add_argument("--ppo-minibatch", type=int, default=32768, help="GLOBAL sgd_minibatch_size of the ppo_loop leg (SURVEY 8(d) config 3)")
     ap.add_argument("--ppo-large-minibatch", type=int, default=131072,
                     help="also report the loop with this global minibatch size as \"ppo_loop_large_minibatch\" (0 = skip)")
+    ap.add_argument("--ppo-f32", type=int, default=1,
+                    help="also report the PPO loop with float32-accurate kernels (PPOConfig(hip_kernels='f32')) as \"ppo_loop_f32\"")
     ap.add_argument("--ppo-timeout", type=float, default=300.0)
     return ap.parse_args(argv)
 
@@ -591,7 +594,7 @@ def run_rank(args):
                         f"{args.weak_envs} envs PER GPU on {world} ranks (weak scaling; not the metric's configuration)")
         weak["total_envs"] = args.weak_envs * world
 
-    def ppo_leg(iters, global_mbs):
+    def ppo_leg(iters, global_mbs, precision=True):
         """BASELINE config[2] at N=1 (16 384 envs, full rollout + learn loop) and config[3] at N>1
         (65 536 envs in total sharded over the ranks, gradients all-reduced over RCCL/xGMI)."""
         from pioneer_amd.ppo import PPOConfig, PPOTrainer
@@ -600,7 +603,7 @@ def run_rank(args):
         penv = PioneerVectorEnv(cnt, device=dev, seed=0, env_id_offset=start,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=args.mode))
         mbs = max(1, min(global_mbs // world, 32 * cnt))      # this rank's share of every global minibatch
-        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs)
+        pcfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=mbs, hip_kernels=precision)
         tr = PPOTrainer(penv, pcfg, use_graph=True)
         tr.train(); tr.train()                       # warm-up: eager iteration, then the graph-captured one
         barrier()
@@ -620,9 +623,44 @@ def run_rank(args):
         del tr
         torch.cuda.empty_cache()
         steps = iters * 32 * total
-        return {"value": steps / tp, "unit": "env-steps/s", "total_envs": total, "envs_per_gpu": cnt, "rollout_T": 32,
+        # ---- roofline of the learner (the kernels behind pnr_mlp_train_step): useful flops against the dense bf16 MFMA peak and the
+        # bytes the three kernels move (FETCH_SIZE x 2 + WRITE_SIZE per update from a committed rocprofv3 --pmc pass over
+        # tools/mlp_step_bench.py, quoted only while the learner sources are the ones that pass ran on) against the HBM peak
+        updates = iters * 4 * ((32 * cnt) // mbs)
+        learn_s = sum(r["learn_time_s"] for r in rs)
+        us_per_update = learn_s / max(1, updates) * 1e6
+        planes = pcfg.mlp_planes() if hip_learner else 0
+        mac_per_sample_net = 106496 + 69632 + 110592           # forward, backward-data, weight gradients (csrc/pnr_mlp.h)
+        flops = 2.0 * mac_per_sample_net * mbs * 2             # per update on this rank, both nets: the model's flops ..
+        mfma_flops = flops * {0: 0, 1: 1, 2: 3, 3: 6}[planes]  # .. and what the matrix cores execute for them (plane pairs)
+        roof = {"bound": "hbm + latency (arithmetic intensity ~110 flop/B against a ridge of ~310)", "us_per_update": us_per_update,
+                "minibatch_per_rank": mbs, "flops_per_update": flops, "mfma_flops_per_update": mfma_flops,
+                "achieved_TFLOPs": flops / (us_per_update * 1e-6) / 1e12, "mfma_peak_TFLOPs": 2500.0,
+                "mfma_frac": mfma_flops / (us_per_update * 1e-6) / 2.5e15,
+                "timing": "learn_time_s of the timed iterations / updates (includes the epoch's gather and the record packing)"}
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", LEARNER_TRAFFIC)))
+            have, want = doc.get("learner_sha16"), _lib.source_fingerprint(_lib.LEARNER_KERNEL_SOURCES)
+            key = f"planes{planes}"
+            if have != want:
+                roof["bytes_per_update"] = None
+                roof["bytes_source"] = f"stale: the learner kernels changed since the counter pass (profiles/{LEARNER_TRAFFIC}: {have}, this build: {want})"
+            elif key not in doc or int(doc[key]["batch"]) != int(mbs):
+                roof["bytes_per_update"] = None
+                roof["bytes_source"] = f"profiles/{LEARNER_TRAFFIC} has no pass for {key} at {mbs} samples"
+            else:
+                b = float(doc[key]["bytes_per_update"])
+                roof.update({"bytes_per_update": b, "hbm_GBps": b / (us_per_update * 1e-6) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBPS,
+                             "hbm_frac": b / (us_per_update * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                             "bytes_by_kernel": {k: v["bytes"] for k, v in doc[key]["kernels"].items()},
+                             "bytes_source": f"profiles/{LEARNER_TRAFFIC} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on these sources, {want}; "
+                                             "FETCH_SIZE doubled, Infinity-Cache hits counted; looked up, NOT measured in this run)"})
+        except Exception as exc:
+            roof["bytes_per_update"] = None
+            roof["bytes_source"] = f"profiles/{LEARNER_TRAFFIC}: {type(exc).__name__}"
+        return {"value": steps / tp, "roofline": roof if hip_learner else None, "unit": "env-steps/s", "total_envs": total, "envs_per_gpu": cnt, "rollout_T": 32,
                 "num_sgd_iter": 4, "sgd_minibatch_size": mbs * world, "sgd_minibatch_size_per_rank": mbs,
-                "sgd_updates_per_iter": 4 * ((32 * cnt) // mbs), "mlp_dtype": "bf16",
+                "sgd_updates_per_iter": 4 * ((32 * cnt) // mbs), "mlp_dtype": pcfg.mlp_dtype(),
                 "hip_graph": graphed, "iters": iters, "losses_finite": finite,
                 "grad_allreduce": ({"backend": backend, "world_size": world,
                                     "bytes": 4 * (int(_lib.load_library().pnr_mlp_grad_floats()) if hip_learner else 205581),
@@ -632,7 +670,7 @@ def run_rank(args):
                 "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                 "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
 
-    def emit(ppo_loop, ppo_large):
+    def emit(ppo_loop, ppo_large, ppo_f32=None):
         if rank != 0:
             return
         launches = K // T
@@ -686,13 +724,15 @@ def run_rank(args):
             out["weak_scaling"] = weak
         if ppo_loop:
             out["ppo_loop"] = ppo_loop
+        if ppo_f32:
+            out["ppo_loop_f32"] = ppo_f32
         if ppo_large:
             out["ppo_loop_large_minibatch"] = ppo_large
         if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    ppo_loop = ppo_large = None
+    ppo_loop = ppo_large = ppo_f32 = None
     rc = 0
     if args.ppo_iters < 0:
         args.ppo_iters = 10 if args.mode == "kinematic" else 0      # ~90 ms of timed work per PPO leg
@@ -717,22 +757,29 @@ def run_rank(args):
         wd.start()
         try:
             ppo_loop = ppo_leg(args.ppo_iters, args.ppo_minibatch)
+            if args.ppo_f32:
+                # the same loop with float32-accurate products on the same kernels (three bf16 planes per operand): the reference's
+                # learner is float32 torch (pioneer_knm_train.py:47), so THIS is the reference-precision figure; `ppo_loop` is the
+                # bf16-operand extra
+                ppo_f32 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "f32")
             if args.ppo_large_minibatch > 0 and args.ppo_large_minibatch != args.ppo_minibatch:
                 ppo_large = ppo_leg(args.ppo_iters, args.ppo_large_minibatch)
         except Exception as exc:
             err = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             if ppo_loop is None:
                 ppo_loop = err
+            elif args.ppo_f32 and ppo_f32 is None:
+                ppo_f32 = err
             else:
                 ppo_large = err
             rc = 5
         with lock:
             state["done"] = True
         wd.cancel()
-        for leg in (ppo_loop, ppo_large):
+        for leg in (ppo_loop, ppo_large, ppo_f32):
             if leg and leg.get("losses_finite") is False:
                 rc = 5
-    emit(ppo_loop, ppo_large)
+    emit(ppo_loop, ppo_large, ppo_f32)
 
     if world > 1:
         dist.barrier()

@@ -629,3 +629,34 @@ def test_restore_with_graph_capture_in_a_fresh_process_warms_up_eagerly_first(tm
     assert r["kl"][0] == ref[0]["kl"] and r["total_loss"][0] == ref[0]["total_loss"]
     assert all(np.isfinite(x) for x in r["kl"] + r["total_loss"]) and np.isfinite(r["wsum"])
     assert abs(r["wabs"] - float(w.abs().sum())) <= 1e-2 * float(w.abs().sum())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+def test_hip_trainer_with_float32_accurate_kernels(precision):
+    """PPOConfig(hip_kernels="f32"): the whole loop on the hand-written kernels with every MFMA operand as three bf16 planes (the
+    reference's learner is float32 torch, pioneer_knm_train.py:47).  The sampler runs per step (pnr_mlp_act + pnr_step: the resident
+    rollout kernel is bf16-only), the learner gathers its input planes from the float32 observations.  (a) The first rollout — same
+    initial weights, same noise stream — equals the float32 torch formulation's to float32 rounding; (b) the run learns, graph-captured."""
+    import dataclasses
+    from pioneer_amd import PioneerVectorEnv, EngineConfig
+    from pioneer_amd.ppo import PPOConfig, PPOTrainer
+    cfg = PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=16384, lr=3e-4, entropy_coeff_start=1e-3, seed=1,
+                    hip_kernels=precision)
+    mk = lambda: PioneerVectorEnv(4096, device="cuda:0", seed=1, engine_config=EngineConfig(max_episode_steps=100))   # noqa: E731
+    tr = PPOTrainer(mk(), cfg, use_graph=True)
+    assert tr.learner.hip and not tr.resident_rollout and tr.sample_mlp.planes == cfg.mlp_planes() == {"f32": 3, "bf16x2": 2}[precision]
+    ref = PPOTrainer(mk(), dataclasses.replace(cfg, hip_kernels=False))
+    assert not ref.learner.hip
+    tr._collect_impl(); ref._collect_impl()
+    torch.cuda.synchronize()
+    tol = 2e-5 if precision == "f32" else 2e-4
+    for k in ("mean", "log_std", "values"):
+        a, b = tr.buf[k][0].double(), ref.buf[k][0].double()          # step 0: the same observations through both forwards
+        assert float((a - b).norm() / b.norm()) <= tol, (k, float((a - b).norm() / b.norm()))
+    rows = [tr.train() for _ in range(12)]
+    assert tr._graph is not None
+    ret = [r["episode_reward_mean"] for r in rows if math.isfinite(r["episode_reward_mean"])]     # (episodes end every 100 steps = ~3 iterations)
+    assert len(ret) >= 3 and ret[-1] > ret[0] + 1.0, ret
+    assert all(math.isfinite(r[k]) for r in rows for k in ("kl", "total_loss", "vf_loss", "entropy"))
+    assert float(tr.learner.hip_mlp(1).adam_state()[2]) == 12 * 4 * (32 * 4096 // 16384)
+    tr.env.close(); ref.env.close()

@@ -18,7 +18,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = ActorCritic(PPOConfig()).to(dev)
-mlp = HipMLP(model, B, dev)
+PLANES = int(os.environ.get("PLANES", "1"))      # 1: bf16 operands; 2, 3: split float32 operands
+mlp = HipMLP(model, B, dev, planes=PLANES)
 mlp.w3_partials = os.environ.get("W3PART", "1") == "1"      # 0: H2 stored and read back (the A/B)
 mlp.pack()
 R = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
@@ -30,6 +31,7 @@ rec = {"actions": act, "mean": mean, "log_std": ls, "logp": gaussian_logp(act, m
 perm = torch.randperm(rows, device=dev)
 rec_rows = mlp.pack_record(rec)
 g = mlp.gather_epoch(obs, perm, filt, None, rec_rows=rec_rows)
+XS = (lambda s: g["xs"][s:s + B]) if PLANES == 1 else (lambda s: g["xs"][:, s:s + B])
 klc = torch.tensor(0.2, device=dev)
 entc = torch.tensor(0.01, device=dev)
 means = torch.zeros(8, device=dev)
@@ -46,9 +48,9 @@ def step(i):
         for net, st in enumerate(streams):
             with torch.cuda.stream(st):
                 mlp.train_step(None, None, None, {k: g[k][s:s + B] for k in mlp.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means2[net], 2e-5,
-                               xs_in=g["xs"][s:s + B], nets=(net, 1))
+                               xs_in=XS(s), nets=(net, 1))
         return
-    mlp.train_step(None, None, None, {k: g[k][s:s + B] for k in mlp.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means, 2e-5, xs_in=g["xs"][s:s + B])
+    mlp.train_step(None, None, None, {k: g[k][s:s + B] for k in mlp.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means, 2e-5, xs_in=XS(s))
 
 
 if CHAINS:
@@ -73,14 +75,14 @@ us = e0.elapsed_time(e1) / N * 1e3
 
 # the sampler's step at 16 384 samples
 S = 16384
-smp = HipMLP(model, S, dev)
+smp = HipMLP(model, S, dev, planes=PLANES)
 smp.pack()
 so = R(S, 137)
 noise = R(S, 6)
 a_max = torch.ones(6, device=dev)
 out = {k: torch.empty(S, 6, device=dev) for k in ("mean", "log_std", "actions", "env")}
 vals = torch.empty(S, device=dev)
-xs = torch.empty(S, 144, dtype=torch.bfloat16, device=dev)
+xs = torch.empty(S, 144, dtype=torch.bfloat16, device=dev) if PLANES == 1 else None
 act_call = lambda: smp.act(so, filt, noise, a_max, mean=out["mean"], log_std=out["log_std"], values=vals, actions=out["actions"],  # noqa: E731
                            env_actions=out["env"], xs_out=xs)
 for _ in range(20):
@@ -91,6 +93,6 @@ for _ in range(N):
     act_call()
 e1.record()
 torch.cuda.synchronize()
-print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "chains": CHAINS, "w3_partials": mlp.w3_partials, "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
+print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "planes": PLANES, "chains": CHAINS, "w3_partials": mlp.w3_partials, "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
                   "param_sums": [round(float(p_.double().sum()), 6) for p_ in mlp.params[:2]] + [round(float(p_.double().sum()), 6) for p_ in mlp.params[6:8]],
                   "means_finite": bool(torch.isfinite(means[:5]).all()), "means": [round(float(x), 5) for x in means[:5]]}))

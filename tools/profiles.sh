@@ -50,13 +50,18 @@ if has ppo; then
   python3 $R/tools/rocpd_pmc.py $db $O/prof_${TAG}_learner_pmc_sq.json > /dev/null
 fi
 if has learner; then
-  STEP="$R/tools/mlp_step_bench.py 32768 100"
-  db=$(prof lstat --kernel-trace -d /tmp/p_lstat -o t -- python3 $STEP)
-  python3 $R/tools/rocpd_stats.py $db --top 8 --csv $O/prof_${TAG}_learner_kernel_stats.csv > $O/prof_${TAG}_learner_kernel_stats.txt
-  db=$(prof lfetch --kernel-trace --pmc FETCH_SIZE -d /tmp/p_lfetch -o t -- python3 $STEP)
-  python3 $R/tools/rocpd_pmc.py $db $O/prof_${TAG}_learner_pmc_fetch.json > /dev/null
-  db=$(prof lwrite --kernel-trace --pmc WRITE_SIZE -d /tmp/p_lwrite -o t -- python3 $STEP)
-  python3 $R/tools/rocpd_pmc.py $db $O/prof_${TAG}_learner_pmc_write.json > /dev/null
-  python3 $R/tools/learner_traffic.py $O/prof_${TAG}_learner_pmc_fetch.json $O/prof_${TAG}_learner_pmc_write.json $O/prof_${TAG}_learner_pmc_traffic.json "$RND $TAG" > $O/prof_${TAG}_learner_pmc_traffic.txt
+  cp $R/profiles/learner_pmc_traffic.json $O/prof_${TAG}_learner_pmc_traffic.json 2>/dev/null || true
+  for P in 1 3; do
+    export PLANES=$P
+    STEP="$R/tools/mlp_step_bench.py 32768 100"
+    db=$(prof lstat$P --kernel-trace -d /tmp/p_lstat$P -o t -- python3 $STEP)
+    python3 $R/tools/rocpd_stats.py $db --top 8 --csv $O/prof_${TAG}_learner_planes${P}_kernel_stats.csv > $O/prof_${TAG}_learner_planes${P}_kernel_stats.txt
+    db=$(prof lfetch$P --kernel-trace --pmc FETCH_SIZE -d /tmp/p_lfetch$P -o t -- python3 $STEP)
+    python3 $R/tools/rocpd_pmc.py $db $O/prof_${TAG}_learner_planes${P}_pmc_fetch.json > /dev/null
+    db=$(prof lwrite$P --kernel-trace --pmc WRITE_SIZE -d /tmp/p_lwrite$P -o t -- python3 $STEP)
+    python3 $R/tools/rocpd_pmc.py $db $O/prof_${TAG}_learner_planes${P}_pmc_write.json > /dev/null
+    python3 $R/tools/learner_traffic.py $O/prof_${TAG}_learner_planes${P}_pmc_fetch.json $O/prof_${TAG}_learner_planes${P}_pmc_write.json $O/prof_${TAG}_learner_pmc_traffic.json "$RND $TAG" 32768 $P > $O/prof_${TAG}_learner_planes${P}_pmc_traffic.txt
+  done
+  unset PLANES
 fi
 echo profiles done
