@@ -757,7 +757,7 @@ def run_rank(args):
         wd.start()
         try:
             ppo_loop = ppo_leg(args.ppo_iters, args.ppo_minibatch)
-            if args.ppo_f32:
+            if args.ppo_f32 and world == 1:       # (N = 1 only: the reference-precision figure of config[2]; the N > 1 leg stays the one form rehearsed there)
                 # the same loop with float32-accurate products on the same kernels (three bf16 planes per operand): the reference's
                 # learner is float32 torch (pioneer_knm_train.py:47), so THIS is the reference-precision figure; `ppo_loop` is the
                 # bf16-operand extra
