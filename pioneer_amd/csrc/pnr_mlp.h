@@ -57,6 +57,10 @@ static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implem
 #ifndef PNR_MLP_DIAG
 #define PNR_MLP_DIAG 0
 #endif
+#ifndef PNR_MLP_W3_LDS
+#define PNR_MLP_W3_LDS 0          // 1: the fused kernel (bf16 operands) keeps W3 in LDS for its head product.  A/B r04: 51.2 vs 50.6 us, train_step 84.1 vs 84.2 — no gain
+                                  // (the co-resident workgroup fills the head phase's L2 round trip anyway), so the fragments keep coming from L2 and LDS stays 53 KB
+#endif
 #ifndef PNR_MLP_DEPHASE
 #define PNR_MLP_DEPHASE 0         // > 0: the fused kernel's second workgroup per CU starts this many x 64 cycles late (A/B r04)
 #endif
@@ -794,11 +798,16 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
 template <bool FUSED, int NS = 1>
 __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane];
+    // NS == 1: W3 (8 KB, fragment-native as packed) lives in LDS for the head product — fetched from L2 where it is used, its eight
+    // fragments' round trip stood in the middle of the tile's chain (head phase 2 070 cycles for 128 cycles of MFMA on four of the
+    // eight waves, the others waiting at the next barrier: profiles/r03_j_mlp_stamps.json).  (NS = 3 has no LDS left for it.)
+    constexpr bool kW3Lds = PNR_MLP_W3_LDS && NS == 1 && FUSED;      // (the plain forward keeps three workgroups per CU: 53 KB each)
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0)];
     static_assert(NS >= 1 && NS <= kMlpMaxPlanes && NS * kTilePlane * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
     MLP_STAMP_DECL;
     __bf16* xt = lds;
     __bf16* ht = lds + kMlpBM * kXS;
+    __bf16* w3l = lds + NS * kTilePlane;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int net = blockIdx.y + P.first_net;
     const long long row0 = (long long)blockIdx.x * kMlpBM;
@@ -851,6 +860,9 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 
     // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero)
     {
+        static_assert(kMlpHead * kMlpHid / 8 == kFwdThreads, "W3: one 16-byte piece per thread");
+        uint4 w3v = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (kW3Lds) w3v = *reinterpret_cast<const uint4*>(wp + kOffW3 + 8 * tid);    // travels with the tile's rows
         float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
         if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy,
             // every load of the thread in flight before the first LDS write
@@ -940,6 +952,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             }
         }
         }
+        if constexpr (kW3Lds) *reinterpret_cast<uint4*>(w3l + 8 * tid) = w3v;
         mlp_barrier();
         if (P.xs && net == 0) {                                   // the input is the same for both nets: saved once
             for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kFwdThreads) {
@@ -1050,7 +1063,10 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
         for (int ks = 0; ks < kMlpHid / 32; ++ks)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) w3f[ks][s] = ld_global_bf16x8(w3 + s * kWPlane + 512 * ks);
+            for (int s = 0; s < NS; ++s) {
+                if constexpr (kW3Lds) w3f[ks][s] = *reinterpret_cast<const bf16x8*>(w3l + 512 * ks + lane * 8);
+                else w3f[ks][s] = ld_global_bf16x8(w3 + s * kWPlane + 512 * ks);
+            }
 #pragma unroll
         for (int ks = 0; ks < kMlpHid / 32; ++ks) {
             bf16x8 b[NS];
