@@ -276,12 +276,15 @@ __device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParam
     }
 
     // -- observe() ----------------------------------------------------------------
+    // (timing-only ablations of a -DPNR_DIAG_BUILD=1 variant, PNR_DIAG bits as in step_kernel: 2 no obs flush, 4 no obs emit; in the
+    // product library `diag` is the literal 0)
+    const int diag = PNR_DIAG_BUILD ? P.diag : 0;
     if (tile_in_use) wave_lds_sync();       // previous flush done before the tile is rewritten
     if (OBS_EM) {
         SinkLdsTile sink{tile + el * kObsDim, kJpl * p, p};
-        emit_obs<false>(K, o, q, p, sink);
+        if (!(diag & 4)) emit_obs<false>(K, o, q, p, sink);
         wave_lds_sync();
-        flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
+        if (!(diag & 2)) flush_tile(tile, P.obs + tile0 * kObsDim, nvalid, lane);
     } else {
         SinkLdsFeatureTile sink{tile + el, kJpl * p, p};
         emit_obs<false>(K, o, q, p, sink);
