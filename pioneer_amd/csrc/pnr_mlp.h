@@ -28,6 +28,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // The TU is compiled -ffp-contract=off for the bit-exact env integrator; nothing here needs that: the epilogues
 // (bias + tanh, (1 - h^2) dz, the filter, Adam) are a quarter of the fused kernel's issue slots and fuse into FMAs.
@@ -50,7 +51,7 @@ constexpr int kMlpCB = kMlpBM / 32;  // 32-sample column blocks per tile
 static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implemented");
 // PNR_MLP_DIAG: timing-only ablations of the forward kernel (results are wrong when set; tools/mlp_ablation.py): 1 no tanh,
 // 2 no observation loads, 4 / 8 no layer-2 / layer-1 product, 16 no head, 32 no forward epilogues, 64 no tile stores (h1, h2,
-// dz2, dz1), 128 no H1 reload, 256 no loss (record loads and arithmetic)
+// dz2, dz1), 128 no H1 reload, 256 no loss (record loads and arithmetic), 512 half the products' sample-fragment LDS reads
 #ifndef PNR_MLP_RING
 #define PNR_MLP_RING 5            // depth of the weight-fragment prefetch ring (A/B: tools/mlp_variant_ab.py)
 #endif
@@ -583,13 +584,71 @@ struct MlpGemm1 {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
-                for (int cb = 0; cb < kMlpCB; ++cb) b[s][cb] = *reinterpret_cast<const bf16x8*>(tb + s * kTilePlane + cb * 32 * STRIDE + 16 * ks);
+                for (int cb = 0; cb < kMlpCB; ++cb) {
+                    // (PNR_MLP_DIAG & 512, timing only: ONE sample-fragment read per k-step serves both column blocks — what a
+                    // 4 row-groups x 2 sample-halves wave layout would save in LDS reads, without its doubled weight stream)
+                    if ((PNR_MLP_DIAG & 512) && cb > 0) b[s][cb] = b[s][0];
+                    else b[s][cb] = *reinterpret_cast<const bf16x8*>(tb + s * kTilePlane + cb * 32 * STRIDE + 16 * ks);
+                }
 #pragma unroll
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
 #pragma unroll
                 for (int cb = 0; cb < kMlpCB; ++cb)
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb],
                                                                       (ks == 0 && pi == 0 && init) ? *init : acc[cb], 0, 0, 0);
+        }
+    }
+};
+
+// The product of the 4 (row groups) x 2 (sample halves) wave layout: acc[j] += W[row block rb0 + j][K] . tile[32 samples of column
+// block cbk][K]^T, j = 0, 1.  ONE sample-fragment read per k-step serves both MFMAs (the 8 x 1 layout of MlpGemm1 reads two for its
+// two), at the price of every weight fragment being requested by two waves.  Timing-only ablation of the 8 x 1 layout with one read
+// serving both of its MFMAs: fused kernel 49.0 -> 42.1 us (profiles/r04_e_fused_timing_only_ablations_kernel_stats.txt).
+#ifndef PNR_MLP_WAVE_LAYOUT
+#define PNR_MLP_WAVE_LAYOUT 0     // bf16 fused kernel: 0 = 8 row blocks x whole tile (r03); 1 = 4 row groups x 2 sample halves — built, bit-identical, SLOWER (r04 A/B:
+                                  // fused kernel 57.5 vs 52.1 us, train_step 92.3 vs 85.7): the doubled weight stream costs more than the halved LDS reads save
+#endif
+#ifndef PNR_MLP_RING2
+#define PNR_MLP_RING2 4           // prefetch ring depth of the 4 x 2 layout (two fragments per k-step: 8 registers per slot)
+#endif
+template <int K, int STRIDE>
+struct MlpGemm2R {
+    static constexpr int KS = K / 16;
+    static constexpr int D = PNR_MLP_RING2;
+    bf16x8 a[D][2];
+    const __bf16* wa;
+    // w_blocks: the first of this wave's two row blocks in the fragment-native packing: block (rb, ks) at (rb KS + ks) * 512
+    __device__ __forceinline__ void prefetch(const __bf16* __restrict__ w_blocks, int lane)
+    {
+        wa = w_blocks + lane * 8;
+#pragma unroll
+        for (int p = 0; p < D - 1; ++p)
+            if (p < KS) {
+                a[p][0] = ld_global_bf16x8(wa + 512 * p);
+                a[p][1] = ld_global_bf16x8(wa + 512 * (KS + p));
+            }
+    }
+    // init: [2] what the two accumulators start from (this wave's bias rows), as the first MFMAs' C operands; or null
+    template <class F>
+    __device__ __forceinline__ void run(const __bf16* tile, int cbk, f32x16 (&acc)[2], int lane, F&& after_loads, const f32x16* init = nullptr)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const __bf16* tb = tile + (32 * cbk + r) * STRIDE + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + D - 1 < KS) {
+                a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
+                a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 512 * (KS + ks + D - 1));
+            }
+            if (ks == (KS > D ? KS - D : 0)) {
+                __builtin_amdgcn_sched_barrier(0);
+                after_loads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(tb + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][j], b, (ks == 0 && init) ? init[j] : acc[j], 0, 0, 0);
         }
     }
 };
@@ -814,33 +873,42 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     const __bf16* wp = P.wpack + (size_t)net * kPackElems;
     const float* bias = P.bias + net * kBiasElems;
     const int c = lane & 31, h = lane >> 5;
+    // ---- which blocks of a layer's [256 rows][64 samples] output this wave's two accumulators hold.  8 x 1 layout (r03): row block w,
+    // column blocks 0 and 1.  4 x 2 layout (r04, bf16 operands): row blocks 2 (w >> 1) and + 1, column block w & 1.
+    constexpr bool L42 = PNR_MLP_WAVE_LAYOUT == 1 && NS == 1 && kMlpCB == 2 && FUSED;     // (the plain forward keeps its 78 registers: three workgroups per CU)
+    constexpr int NRB = L42 ? 2 : 1;                              // row blocks (and bias sets) of a wave
+    const int rowblk0 = L42 ? 2 * (w >> 1) : w, colblk0 = L42 ? (w & 1) : 0;
+    const auto rowblk = [&](int j) { return L42 ? rowblk0 + j : rowblk0; };
+    const auto colblk = [&](int j) { return L42 ? colblk0 : j; };
     // a wave's four 16-byte bias pieces (rows 32 w + 8 k + 4 h ..): requested in FRONT of the product's weight-fragment prefetch,
     // so that they are the older operations (vector-memory results return in order: asked for behind the fragments, as the
     // accumulators' initial values, each bias load made the compiler wait for vmcnt(0), draining the prefetch ring inside the product)
-    const auto bias_load = [&](const float* b, f32x4 (&q)[4]) {
+    const auto bias_load = [&](const float* b, f32x4 (&q)[NRB][4]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = *reinterpret_cast<const f32x4*>(b + 32 * w + 8 * k + 4 * h);
+        for (int r = 0; r < NRB; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[r][k] = *reinterpret_cast<const f32x4*>(b + 32 * rowblk(r) + 8 * k + 4 * h);
     };
     // .. as ONE 16-register value: the first MFMA of each column block reads it as its C operand (MlpGemm1::run's `init`)
-    const auto bias16 = [&](const f32x4 (&q)[4]) {
+    const auto bias16 = [&](const f32x4 (&q)[NRB][4], int r) {
         f32x16 b;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[4 * k + j] = q[k][j];
+            for (int j = 0; j < 4; ++j) b[4 * k + j] = q[r][k][j];
         return b;
     };
-    const auto bias_init = [&](f32x16 (&acc)[kMlpCB], const f32x16& b) {       // (timing-only builds that skip a product)
+    const auto bias_init = [&](f32x16 (&acc)[kMlpCB], const f32x16 (&b)[NRB]) {       // (timing-only builds that skip a product)
 #pragma unroll
-        for (int cb = 0; cb < kMlpCB; ++cb) acc[cb] = b;
+        for (int cb = 0; cb < kMlpCB; ++cb) acc[cb] = b[L42 ? cb : 0];
     };
     // layer 1's bias and first weight fragments do not depend on the tile: requested before anything else
     MLP_STAMP(0);
-    f32x4 bq1[4];
+    f32x4 bq1[NRB][4];
     bias_load(bias, bq1);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm1<kMlpInPad, kXS, NS> g1;
-    g1.prefetch(wp + kOffW1 + w * (kMlpInPad / 16) * 512, lane);
+    typename std::conditional<L42, MlpGemm2R<kMlpInPad, kXS>, MlpGemm1<kMlpInPad, kXS, NS>>::type g1;
+    g1.prefetch(wp + kOffW1 + rowblk0 * (kMlpInPad / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
 #if PNR_MLP_DEPHASE
     if constexpr (FUSED) {
@@ -985,7 +1053,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                 } else {
                     pk = tanh_quad(acc[cb], q);
                 }
-                *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk;
+                *reinterpret_cast<bf16x4*>(ht + (32 * colblk(cb) + c) * kHS + 32 * rowblk(cb) + 8 * q + 4 * h) = pk;
                 if constexpr (FUSED) { if (keep) h1keep[4 * cb + q] = pk; }
                 } else {
                     const f32x2 lo = tanh_fast2((f32x2){acc[cb][4 * q], acc[cb][4 * q + 1]}), hi = tanh_fast2((f32x2){acc[cb][4 * q + 2], acc[cb][4 * q + 3]});
@@ -1007,19 +1075,22 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
     {
-        const f32x16 b16 = bias16(bq1);
-        if (!(PNR_MLP_DIAG & 8)) g1.run(xt, acc, lane, [] {}, &b16);
-        else bias_init(acc, b16);
+        f32x16 b16[NRB];
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) b16[r] = bias16(bq1, r);
+        if (PNR_MLP_DIAG & 8) bias_init(acc, b16);
+        else if constexpr (L42) g1.run(xt, colblk0, acc, lane, [] {}, b16);
+        else g1.run(xt, acc, lane, [] {}, &b16[0]);
     }
     MLP_STAMP(2);                         // layer-1 product issued
     if (!(PNR_MLP_DIAG & 32)) epilogue(true);
     MLP_STAMP(3);                         // layer-1 epilogue
     // layer 2's bias and first weight fragments are requested ahead of the barrier (and of the tile store behind it)
-    f32x4 bq2[4];
+    f32x4 bq2[NRB][4];
     bias_load(bias + kMlpHid, bq2);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm1<kMlpHid, kHS, NS> g2;
-    g2.prefetch(wp + kOffW2 + w * (kMlpHid / 16) * 512, lane);
+    typename std::conditional<L42, MlpGemm2R<kMlpHid, kHS>, MlpGemm1<kMlpHid, kHS, NS>>::type g2;
+    g2.prefetch(wp + kOffW2 + rowblk0 * (kMlpHid / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
     mlp_barrier();
     MLP_STAMP(4);                         // barrier after the layer-1 epilogue
@@ -1027,11 +1098,13 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 
     // ---- layer 2: H2^T = tanh(W2 . H1^T + b2); the tile is overwritten once every wave has read it.  The H1 tile leaves for
     // HBM from INSIDE the product, behind its last weight-fragment load, and the tile's record is requested there too
-    const f32x16 b16_2 = bias16(bq2);
+    f32x16 b16_2[NRB];
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) b16_2[r] = bias16(bq2, r);
     if (PNR_MLP_DIAG & 4) bias_init(acc, b16_2);
     MlpRecordTile<kFwdThreads> rect;
     const bool rec_early = FUSED && !P.idx && !(PNR_MLP_DIAG & 256);
-    if (!(PNR_MLP_DIAG & 4)) g2.run(ht, acc, lane, [&] {
+    const auto l2_hook = [&] {
         if constexpr (FUSED) {
             if (rec_early) {
                 // policy: actions, mean, log_std, adv, logp; value: -, -, -, vtarg, values
@@ -1040,7 +1113,11 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             }
         }
         if (P.h1 && !(PNR_MLP_DIAG & 64)) store_planes(P.h1);
-    }, &b16_2);
+    };
+    if (!(PNR_MLP_DIAG & 4)) {
+        if constexpr (L42) g2.run(ht, colblk0, acc, lane, l2_hook, b16_2);
+        else g2.run(ht, acc, lane, l2_hook, &b16_2[0]);
+    }
     if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
         if (rec_early) rect.park(reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
     }
@@ -1133,9 +1210,10 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         const float* rl = reinterpret_cast<const float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2;   // the parked record
         float* wsum = reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats; // [8 waves][4] loss sums
         // W3^T's fragment for the first backward product: requested before the H2 store and the loss
-        bf16x8 w3t[NS];
+        bf16x8 w3t[NS * NRB];                                            // [plane] (8 x 1) or [row block] (4 x 2, one plane)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) w3t[s] = ld_global_bf16x8(wp + s * kWPlane + kOffW3T + w * 512 + lane * 8);
+        for (int s = 0; s < NS * NRB; ++s)
+            w3t[s] = ld_global_bf16x8(wp + (L42 ? 0 : s) * kWPlane + kOffW3T + (L42 ? rowblk(s) : w) * 512 + lane * 8);
         __builtin_amdgcn_sched_barrier(0);
         if (P.h2 && !(PNR_MLP_DIAG & 64)) store_planes(P.h2);      // (null: layer 3's gradients are made here, below)
         mlp_barrier();
@@ -1170,7 +1248,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    __bf16* at = ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h;
+                    __bf16* at = ht + (32 * colblk(cb) + c) * kHS + 32 * rowblk(cb) + 8 * q + 4 * h;
                     if constexpr (NS == 1) {
                     const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at);
                     *reinterpret_cast<bf16x4*>(at) = dtanh_quad(acc[cb], q, hv);
@@ -1208,9 +1286,17 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                 for (int j = 0; j < 4; ++j) w3p[kMlpHead * kMlpHid + kMlpHid + 4 * g + j] = ab3[j];     // every column of G^T . 1 is db3
             }
         }
+        // (4 x 2 layout: a wave's feature columns 32 w .. are overwritten by itself AND by its partner of the other sample half:
+        // both have read them above before either writes)
+        if constexpr (L42) { if (w3p) mlp_barrier(); }
         // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
         zero_acc();
         {
+            if constexpr (L42) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(gt + (32 * colblk0 + c) * kGS + 8 * h);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[j], b, acc[j], 0, 0, 0);
+            } else {
             bf16x8 b[NS][kMlpCB];
 #pragma unroll
             for (int s = 0; s < NS; ++s)
@@ -1221,28 +1307,33 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
                 for (int cb = 0; cb < kMlpCB; ++cb)
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb], acc[cb], 0, 0, 0);
-        }
-        bwd_epilogue();
-        if (w3p) {                                                 // db2 = 1^T . dZ2 of this wave's columns, now that they hold dZ2
-            f32x4 ab2[2];
-            mlp_tile_b2_products<NS>(ht, kHS, lane, w, ab2, kTilePlane);
-            if ((lane >> 4) == 0) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * w + 16 * b + (lane & 15)] = ab2[b][0];
             }
         }
+        bwd_epilogue();
+        const auto b2_products = [&] {                             // db2 = 1^T . dZ2 of this wave's columns 32 w .., now that they hold dZ2
+            if (w3p) {
+                f32x4 ab2[2];
+                mlp_tile_b2_products<NS>(ht, kHS, lane, w, ab2, kTilePlane);
+                if ((lane >> 4) == 0) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * w + 16 * b + (lane & 15)] = ab2[b][0];
+                }
+            }
+        };
+        if constexpr (!L42) b2_products();                          // (8 x 1: only this wave wrote these columns)
         MLP_STAMP(15);                    // dH2 product + its epilogue
-        MlpGemm1<kMlpHid, kHS, NS> g4;            // W2^T's first fragments ahead of the barrier
-        g4.prefetch(wp + kOffW2T + w * (kMlpHid / 16) * 512, lane);
+        typename std::conditional<L42, MlpGemm2R<kMlpHid, kHS>, MlpGemm1<kMlpHid, kHS, NS>>::type g4;    // W2^T's first fragments ahead of the barrier
+        g4.prefetch(wp + kOffW2T + rowblk0 * (kMlpHid / 16) * 512, lane);
         __builtin_amdgcn_sched_barrier(0);
         mlp_barrier();
+        if constexpr (L42) b2_products();                           // (4 x 2: the partner's half of the columns is in place now)
         MLP_STAMP(16);                    // barrier after it
 
         // ---- dH1^T = W2^T . dZ2^T (the dZ2 tile leaves from inside the product), then H1 into the tile and dZ1 in place over it
         zero_acc();
-        g4.run(ht, acc, lane, [&] {
-            if (!(PNR_MLP_DIAG & 64)) store_planes(P.dz2);
-        });
+        const auto dz2_hook = [&] { if (!(PNR_MLP_DIAG & 64)) store_planes(P.dz2); };
+        if constexpr (L42) g4.run(ht, colblk0, acc, lane, dz2_hook);
+        else g4.run(ht, acc, lane, dz2_hook);
         MLP_STAMP(17);                    // dZ2 store + W2^T product issued
         MLP_STAMP(18);
         mlp_barrier();                         // every read of dZ2 (the product and the store inside it) is done: the tile is free
@@ -1253,7 +1344,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if constexpr (NS == 1) *reinterpret_cast<bf16x4*>(ht + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = dtanh_quad(acc[cb], q, h1keep[4 * cb + q]);
+                if constexpr (NS == 1) *reinterpret_cast<bf16x4*>(ht + (32 * colblk(cb) + c) * kHS + 32 * rowblk(cb) + 8 * q + 4 * h) = dtanh_quad(acc[cb], q, h1keep[4 * cb + q]);
                 else dtanh_split(cb, q, h1keep_f[4 * cb + q]);
             }
         MLP_STAMP(21);
