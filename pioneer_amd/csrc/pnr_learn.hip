@@ -415,8 +415,8 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     hipStream_t st = (hipStream_t)stream;
     const int nets = step_nets(s);
     const int planes = s->planes > 1 ? s->planes : 1;
-    if (planes > 1 && (!s->w3_partials || s->idx || (s->obs && !s->xs_in && false)))
-        return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: split operands (planes %d) need w3_partials and contiguous rows (no idx)", planes);
+    if (planes > 1 && (!s->w3_partials || !s->xs_in))
+        return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: split operands (planes %d) need w3_partials and the pre-gathered input planes (xs_in, pnr_mlp_gather)", planes);
     const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), nets);
     const long long prow = (long long)tiles.x * nets;           // one row of loss sums per workgroup of the fused kernel
     if (s->partial_rows < prow)
@@ -442,7 +442,6 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     // layer 3's weight gradients per tile from the fused kernel (then H2 never leaves the CU) when the caller gave the scratch for it;
     // the weight-stationary variant of the fused kernel stores H2 as before (the two forms give the same bits)
     const bool stationary = F.xs_in && kTrainStationary && planes == 1;
-    if (planes > 1 && F.xs) return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: split operands (planes %d) read their input planes from xs_in (pnr_mlp_gather)", planes);
     if (s->w3_partials && !stationary) {
         if (s->w3_partial_floats < (long long)tiles.x * nets * kW3PartFloats)
             return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: w3_partials hold %lld floats, the launch needs %lld",
