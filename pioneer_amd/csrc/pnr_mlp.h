@@ -2134,9 +2134,12 @@ __device__ __forceinline__ void wg_ring_loop(long long s_begin, long long s_end,
 #pragma unroll
     for (int c = 0; c < D; ++c)
         if (c < nch) request(c, c);
-    // work that does not depend on the chunks (the layer-3 partial sums' requests) goes behind the first chunks' pieces.  Its loads and
-    // stores are further operations on the VM counter: they can only make a counted wait below wait for MORE than the pieces it names
-    prologue_work();
+    // `late_work` (the requests of the layer-3 partial sums: sixteen 16-byte loads of a few threads, consumed after the accumulators'
+    // stores) is issued at the top of the LAST chunk's products.  In front of the loop — even behind the first chunks' pieces — its 16
+    // vector-memory instructions per wave queued up with the 12 pieces and the loop started 5 500 cycles later (8 250 against 2 750
+    // cycles from the kernel's start, profiles/r04_b_wgrad_ring_stamps.json); no counted wait follows the last chunk's, so nothing
+    // waits for these loads but their use.
+    bool late_done = false;
     int stage = 0;
     WG_RING_STAMP(1);
     for (int c = 0; c < nch; ++c) {
@@ -2155,11 +2158,13 @@ __device__ __forceinline__ void wg_ring_loop(long long s_begin, long long s_end,
         const bool glds_next = c + D < nch && whole(c + D);
         if (c + D < nch && !glds_next) stage_sync(c + D, nstage);
         if (c >= 4 && c < 8) WG_RING_STAMP(5 + 4 * (c - 4));
+        if (c == nch - 1) { prologue_work(); late_done = true; }
         // chunk c + D's pieces are requested from INSIDE the products, a few behind each k-step's MFMAs: issuing the six
         // of them in one go cost 650 cycles per chunk in which the wave issued no MFMA (profiles/r04_a_wgrad_ring_stamps_issue_in_one_go.json)
         multiply(stage, [&](int k) { if (glds_next) issue(c + D, nstage, k); });
         stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
+    if (!late_done) prologue_work();
     WG_RING_STAMP(20);
 }
 
@@ -2348,11 +2353,8 @@ __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ri
     };
     WgW3Sums w3;
     w3.q = -1;
-    // (requested BEHIND the first chunks' pieces: in front of them, 28 vector-memory instructions per wave filled the CU's queue
-    // and the pieces' issue waited a memory round trip for room)
     wg_ring_loop<CH, G::STAGES, MAXP>(s_begin, s_end, MAXP, issue, stage_sync, multiply,
                                       [&] { if (P.w3part) w3.request(P, s_begin, s_end, part, kWgParts, tid); }, stamps);
-    if (P.w3part) w3.finish(slab);
     mlp_barrier();                                               // every wave is done with the ring: its memory carries the stores' tiles
     float* scratch = reinterpret_cast<float*>(ring) + w * (32 * kWgTrS);
 #pragma unroll
@@ -2360,6 +2362,7 @@ __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ri
 #pragma unroll
         for (int b = 0; b < 2; ++b)
             wg_store_block_lds(scratch, slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
+    if (P.w3part) w3.finish(slab);                               // (behind the accumulators' stores: its loads have had that long to arrive)
 }
 
 // dW1[128 half .. +128, :] = dZ1[:, that half]^T . X and db1 of one slice; waves 4 (row blocks) x 2 (column groups: X blocks 0-2 | blocks
@@ -2461,7 +2464,6 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
     // (np differs by wave — some have one X piece less per plane — wave-uniform)
     wg_ring_loop<CH, G::STAGES, MAXP>(s_begin, s_end, NS * (G::nA1 + nx), issue, stage_sync, multiply,
                                       [&] { w3.request(P, s_begin, s_end, 2 + half, kWgParts, tid); }, stamps);
-    w3.finish(slab);
     mlp_barrier();
     float* scratch = reinterpret_cast<float*>(ring) + w * (32 * kWgTrS);
     const int row0 = 128 * half + 32 * rb;
@@ -2477,6 +2479,7 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
             for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[2][i];
         }
     }
+    w3.finish(slab);
 }
 
 template <int NS = 1>
