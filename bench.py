@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MIN_SERIES_S = 0.06        # the timed K-step block is repeated back to back until the series is at least this long ...
 MIN_REPEATS = 5            # ... and at least this often; `ms_per_step` = series wall time / (repeats x K)
 MAX_REPEATS = 20000
-DYN_COUNTERS = "r04_d_dyn_sq_counters.json"      # tools/dyn_counters_summary.py (VALU instructions per launch of the dynamics kernel)
+DYN_COUNTERS = "r04_f_dyn_sq_counters.json"      # tools/dyn_counters_summary.py (VALU instructions per launch of the dynamics kernel)
 
 
 def parse_args(argv=None):

@@ -6,7 +6,7 @@ Keeps the reference CLI's surface (cli.py:12-40 there: sub-command ``pioneer-tra
 ``--no-monitor``, and ``tensorboard -e EXPERIMENT``, cli.py:43-55; ``tracking.training_root`` and a ``logging`` dictConfig read
 from ``config.yaml`` next to this file, as the reference's config.yaml:1-24) on top of ``pioneer_amd.launch.train``, plus
 ``pioneer-eval`` (the role of the reference's temp/pioneer_eval.py: restore a checkpoint, roll out, record) and the engine's own
-switches (``--restore CHECKPOINT``, ``--trial-parallel``, ``--mode``).  For several GPUs run it under
+switches (``--restore CHECKPOINT``, ``--trial-parallel``, ``--mode``, ``--precision``).  For several GPUs run it under
 ``python -m torch.distributed.run --nproc-per-node N cli.py pioneer-train-kinem ...`` (``--trial-parallel``: one trial per GPU
 at a time, the reference's own parallelism; default: every trial data-parallel over the GPUs).
 """
@@ -49,6 +49,10 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("--iterations", type=int, default=1000)
     tr.add_argument("--envs-per-worker", type=int, default=4096)
     tr.add_argument("--mode", choices=["kinematic", "dynamic"], default="kinematic")
+    tr.add_argument("--precision", choices=["bf16", "bf16x2", "f32", "torch"], default="bf16",
+                    help="the learner's arithmetic: bf16 MFMA operands (default), float32-accurate products on the same kernels "
+                         "('f32': three bf16 planes per operand; 'bf16x2': two), or the float32 torch formulation — the reference's "
+                         "learner is float32 torch (pioneer_knm_train.py:47)")
     tr.add_argument("--restore", default=None, metavar="CHECKPOINT", help="start every trial from this PPOTrainer.save() file")
     tr.add_argument("--trial-parallel", action="store_true",
                     help="several GPUs: rank r runs trials r, r + world, ... on its own (no traffic between the GPUs)")
@@ -107,7 +111,8 @@ def main(argv=None) -> int:
     rows = train(results_dir=out_dir, checkpoint_freq=args.checkpoint_freq, num_samples=args.num_samples,
                  num_workers=args.num_workers, monitor=not args.no_monitor,
                  training_iterations=args.iterations, envs_per_worker=args.envs_per_worker, mode=args.mode,
-                 restore=args.restore, trial_parallel=args.trial_parallel)
+                 restore=args.restore, trial_parallel=args.trial_parallel,
+                 hip_kernels=False if args.precision == "torch" else args.precision)
     if int(os.environ.get("RANK", "0")) == 0:
         print("Results:\n\n" + dump(rows, RESULT_COLUMNS) + "\n")
     return 0

@@ -43,14 +43,17 @@ def train(results_dir: str,
           monitor_steps: int = 500,
           engine_config: Optional[EngineConfig] = None,
           trial_parallel: bool = False,
-          restore: Optional[str] = None):
+          restore: Optional[str] = None,
+          hip_kernels: object = None):
     """Returns a pandas DataFrame (one row per trial, Tune-style) if pandas is importable, else the row list.
 
     Several GPUs (torch.distributed.run): by default every trial is data-parallel over the ranks (env shards, gradients
     all-reduced).  ``trial_parallel=True`` is the reference's own parallelism instead — Tune runs its ``num_samples`` trials
     independently (pioneer_knm_train.py:43-44; cli.py:15 defaults to 128 of them): rank r trains trials r, r + world, ... on
     its own GPU with ``num_workers x envs_per_worker`` envs each and NO traffic between the GPUs until the result rows are
-    gathered at the end.  ``restore``: a PPOTrainer.save() checkpoint every trial starts from (Tune's restore=...)."""
+    gathered at the end.  ``restore``: a PPOTrainer.save() checkpoint every trial starts from (Tune's restore=...).
+    ``hip_kernels``: the learner's arithmetic when no ``ppo_config`` is given — True / "bf16" (default), "f32" / "bf16x2" (float32-
+    accurate split operands on the same kernels) or False (the float32 torch formulation); PPOConfig.hip_kernels."""
     # the engine's own options: as given, or — dynamics mode — the inertia-scaled motor (omega = 20 rad/s, zeta = 1 on every
     # joint: with plain torque gains PPO does not learn the task, DESIGN.md section 6); TimeLimit(500) and auto-reset as
     # the reference's prepare_env wraps it (pioneer_knm_train.py:27)
@@ -86,7 +89,8 @@ def train(results_dir: str,
         # = 125 iterations there (pioneer_knm_train.py:37-40, :62); left at 1 M timesteps it would be over after
         # 8 of these 131 072-sample iterations (2 at 16 384 envs).
         cfg = ppo_config or PPOConfig(num_sgd_iter=4, sgd_minibatch_size=max(1, 32768 // world),   # 32 768 samples per GLOBAL minibatch
-                                      entropy_decay_steps=125 * 32 * total_envs)
+                                      entropy_decay_steps=125 * 32 * total_envs,
+                                      **({} if hip_kernels is None else {"hip_kernels": hip_kernels}))
         ent_rng = np.random.RandomState(cfg.seed + 7919 * trial)
         cfg = PPOConfig(**{**cfg.__dict__, "entropy_coeff_start": sample_entropy_start(ent_rng),
                            "seed": cfg.seed + trial})

@@ -21,6 +21,9 @@ def test_parser_keeps_the_reference_options():
     assert e.checkpoint == "ck.pt" and e.gif == "o.gif" and e.episodes == 3
     a = ap.parse_args(["pioneer-train-kinem", "-e", "x", "--restore", "ck.pt", "--trial-parallel"])
     assert a.restore == "ck.pt" and a.trial_parallel
+    assert a.precision == "bf16" and ap.parse_args(["pioneer-train-kinem", "-e", "x", "--precision", "f32"]).precision == "f32"
+    with pytest.raises(SystemExit):
+        ap.parse_args(["pioneer-train-kinem", "-e", "x", "--precision", "fp8"])
     t = ap.parse_args(["tensorboard", "-e", "exp1"])                # the reference's second sub-command (cli.py:43-55)
     assert t.command == "tensorboard" and t.experiment == "exp1" and t.port == 6006
 
@@ -83,6 +86,15 @@ def test_train_then_eval_through_the_cli(tmp_path, monkeypatch, capsys):
     import json
     row = json.loads((tmp_path / "resumed" / "PPO_Pioneer-v1_00000" / "result.json").read_text().strip().splitlines()[-1])
     assert row["training_iteration"] == 3 and row["timesteps_total"] == 3 * 32 * 256
+    # --precision f32: the same run with float32-accurate kernels (params.json records it); a bf16 checkpoint restores into it
+    # (same master weights and Adam state: the operand precision is not part of a checkpoint)
+    rc = cli.main(["pioneer-train-kinem", "-e", "f32run", "-c", "0", "-n", "1", "--no-monitor", "--iterations", "2",
+                   "--envs-per-worker", "256", "--precision", "f32"])
+    assert rc == 0
+    params = json.loads((tmp_path / "f32run" / "PPO_Pioneer-v1_00000" / "params.json").read_text())
+    assert params["hip_kernels"] == "f32"
+    row = json.loads((tmp_path / "f32run" / "PPO_Pioneer-v1_00000" / "result.json").read_text().strip().splitlines()[-1])
+    assert row["training_iteration"] == 2 and all(row[k] == row[k] for k in ("kl", "total_loss"))
 
 
 @pytest.mark.gpu
