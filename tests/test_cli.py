@@ -89,12 +89,12 @@ def test_train_then_eval_through_the_cli(tmp_path, monkeypatch, capsys):
     # --precision f32: the same run with float32-accurate kernels (params.json records it); a bf16 checkpoint restores into it
     # (same master weights and Adam state: the operand precision is not part of a checkpoint)
     rc = cli.main(["pioneer-train-kinem", "-e", "f32run", "-c", "0", "-n", "1", "--no-monitor", "--iterations", "2",
-                   "--envs-per-worker", "256", "--precision", "f32"])
+                   "--envs-per-worker", "256", "--precision", "f32", "--restore", str(tdir / "checkpoint_final.pt")])
     assert rc == 0
     params = json.loads((tmp_path / "f32run" / "PPO_Pioneer-v1_00000" / "params.json").read_text())
     assert params["hip_kernels"] == "f32"
     row = json.loads((tmp_path / "f32run" / "PPO_Pioneer-v1_00000" / "result.json").read_text().strip().splitlines()[-1])
-    assert row["training_iteration"] == 2 and all(row[k] == row[k] for k in ("kl", "total_loss"))
+    assert row["training_iteration"] == 4 and all(row[k] == row[k] for k in ("kl", "total_loss"))      # 2 restored + 2
 
 
 @pytest.mark.gpu
