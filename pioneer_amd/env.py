@@ -62,6 +62,7 @@ class PioneerKinematicEnv(compat.GymEnv):
             engine = EngineConfig(max_episode_steps=0, auto_reset=False, mode=mode)
         self.np_random = None                                              # :45
         self.seed()                                                        # :46
+        self._base_engine = engine                                         # what reset() returns to (scene bodies of the constructor kept)
         self._vec = PioneerVectorEnv(1, device=device, seed=self._seed_value,
                                      pioneer_config=self.config,
                                      simulation_config=self.simulation_config, engine_config=engine)
@@ -71,10 +72,26 @@ class PioneerKinematicEnv(compat.GymEnv):
         self.dt = self._vec.dt                                             # :60
         self.eps = self._vec.eps                                           # :61
 
+        from .scene import Scene, World
+        self.scene = Scene(self)                                           # bullet_env.py:86-88: the objects the demo drives
+        self.world = World(self)
         self._obs = self.reset_world()                                     # :69 (+ reset_simulator in BulletEnv.__init__)
         self.action_space = compat.to_gym_space(Box(-self.a_max, self.a_max, dtype=np.float32))  # :72
         self.observation_space = compat.to_gym_space(self.observation_to_space(self.observe()))  # :73
         self.reward_range = (-float("inf"), float("inf"))                  # :74
+
+    def _rebuild_engine(self, engine_config: EngineConfig) -> None:
+        """A new engine handle with another EngineConfig (scene bodies are part of pnr_config at pnr_create), the env's state carried over."""
+        old = self._vec
+        state = old.get_state().clone()
+        dyn = old.get_dyn_state().clone() if old.engine_config.mode == "dynamic" else None
+        self._vec = PioneerVectorEnv(1, device=old.device, seed=self._seed_value, pioneer_config=self.config,
+                                     simulation_config=self.simulation_config, engine_config=engine_config)
+        self._vec.reset()
+        self._vec.set_state(state)
+        if dyn is not None:
+            self._vec.set_dyn_state(dyn)
+        old.close()
 
     # -- pickling: by constructor arguments, like gym.utils.EzPickle (pioneer_knm_env.py:38, :51) --
     def __reduce__(self):
@@ -132,9 +149,20 @@ class PioneerKinematicEnv(compat.GymEnv):
             tp = np.asarray(target_position, dtype=np.float32)[None]
         obs = self._vec.reset(joint_positions=jp, target_positions=tp)
         self._obs = obs[0].double().cpu().numpy()
+        # :96-102: the target marker is an item of the scene (visual only).  (The reference asserts on a second 'target' when
+        # reset_world() is called twice without reset_simulator(), quirk Q9; here the item is replaced.)
+        from .scene import Item
+        tgt = Item("target", "sphere", self._obs[129:132], (0.0, 0.0, 0.0, 1.0), False, (self.config.target_radius, 0.0, 0.0))
+        self.scene.items = [i for i in self.scene.items if i.name != "target"] + [tgt]
+        self.scene.items_by_name["target"] = tgt
         return self._obs
 
     def reset(self) -> Observation:                                        # bullet_env.py:187-190
+        # reset_simulator() (:90-101): a fresh World and Scene — bodies created through env.scene are gone, as in the reference
+        from .scene import Scene, World
+        if self._vec.engine_config != self._base_engine:
+            self._rebuild_engine(self._base_engine)
+        self.scene, self.world = Scene(self), World(self)
         self.world_index += 1
         self.step_index = 0
         return self.reset_world()

@@ -590,3 +590,59 @@ def test_first_reset_on_a_fresh_non_blocking_stream_sees_the_zeroed_state():
         assert np.array_equal(w, w_ref) and torch.equal(o, o_ref)
         env.close()
     ref.close()
+
+
+def test_scene_and_world_objects_of_the_reference_demo():
+    """env.scene / env.world as the reference's `__main__` demo drives them (pioneer_knm_env.py:245-296): bodies, rpy2quat,
+    joints_by_name[...].position() / limits / reset_state(position, velocity), world.step() / step_time.  Kinematic mode: a created
+    body is a record (the reference's arm has no collision shapes either); a joint reset with a velocity moves by velocity x
+    step_time per world.step() and stops at its limit; reset() starts from a fresh scene.  Dynamics mode: a body with a collision
+    shape becomes a static scene body of the engine (the handle is rebuilt, the state carried over)."""
+    from pioneer_amd import PioneerKinematicEnv, EngineConfig, SimulationConfig
+    env = PioneerKinematicEnv()
+    assert [j.name for j in env.scene.joints] == ["robot:base_to_rotator1", "robot:hinge1_to_arm1", "robot:arm1_to_arm2",
+                                                  "robot:arm2_to_rotator2", "robot:hinge2_to_arm3", "robot:arm3_to_rotator3"]
+    assert "target" in env.scene.items_by_name and abs(env.world.step_time - 10.0 / 240.0) < 1e-15
+    q = env.scene.rpy2quat((0, 0, 0))
+    assert q == (0.0, 0.0, 0.0, 1.0) and np.allclose(env.scene.quat2rpy(env.scene.rpy2quat((0.3, -0.2, 1.1))), (0.3, -0.2, 1.1))
+    env.scene.create_body_box(name="obstacle:1", collision=True, mass=0.0, half_extents=(0.5, 0.5, 5.0), position=(10, 5, 0),
+                              orientation=q, rgba_color=(0, 0, 0, 1))
+    env.scene.create_body_plane(name="ground", mass=0.0, normal=(0, 0, 1.0), position=(0, 0, 0), orientation=q)
+    assert set(env.scene.items_by_name) == {"target", "obstacle:1", "ground"}
+    with pytest.raises(AssertionError):
+        env.scene.create_body_box(name="ground", collision=True, mass=0.0, half_extents=(1, 1, 1), position=(0, 0, 0), orientation=q)
+    with pytest.raises(AssertionError):
+        env.scene.create_body_sphere(name="ball", collision=True, mass=1.0, radius=0.2, position=(0, 0, 0), orientation=q)
+    j = env.scene.joints_by_name["robot:hinge1_to_arm1"]
+    assert abs(j.upper_limit - 1.309) < 1e-6 and j.lower_limit == -j.upper_limit
+    # the demo's loop: reset_state(position(), velocity) then world.step(): the joint sweeps to its limit and stops there
+    j.reset_state(0.25, velocity=1.0)
+    others = env.joint_positions().copy()
+    for k in range(3):
+        env.world.step()
+    assert abs(j.position() - (0.25 + 3 * env.world.step_time)) < 1e-6 and abs(j.velocity() - 1.0) < 1e-7
+    now = env.joint_positions()
+    assert np.array_equal(np.delete(now, 1), np.delete(others, 1))                  # nothing else moved
+    for k in range(40):
+        env.world.step()
+    assert j.position() == pytest.approx(j.upper_limit, abs=1e-7) and j.velocity() == 0.0
+    obs = env.observe()
+    assert abs(obs[1] - j.position()) < 1e-7                                        # the env observes the joint where the scene put it
+    with pytest.raises(NotImplementedError):
+        j.control_velocity(velocity=1.0)
+    env.reset()                                                                     # reset_simulator(): a fresh scene
+    assert set(env.scene.items_by_name) == {"target"}
+    env.close()
+    # dynamics mode: the plane is a real collision body of the engine
+    dyn = PioneerKinematicEnv(simulation_config=SimulationConfig(gravity=9.81),
+                              engine_config=EngineConfig(mode="dynamic", contact_kp=2000.0, contact_kd=50.0, link_contacts=True))
+    r_before = dyn.joint_positions().copy()
+    dyn.scene.create_body_plane(name="ground", mass=0.0, normal=(0, 0, 1.0), position=(0, 0, 0), orientation=q)
+    assert len(dyn._vec.engine_config.scene) == 1 and np.array_equal(dyn.joint_positions(), r_before)     # state carried over
+    o, r, d, info = dyn.step(np.zeros(6, dtype=np.float32))
+    assert np.isfinite(o).all()
+    with pytest.raises(NotImplementedError):
+        dyn.world.step()
+    dyn.reset()
+    assert len(dyn._vec.engine_config.scene) == 0
+    dyn.close()
