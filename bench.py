@@ -670,7 +670,7 @@ def run_rank(args):
                 "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                 "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
 
-    def emit(ppo_loop, ppo_large, ppo_f32=None):
+    def emit(ppo_loop, ppo_large, ppo_f32=None, ppo_x2=None):
         if rank != 0:
             return
         launches = K // T
@@ -726,13 +726,15 @@ def run_rank(args):
             out["ppo_loop"] = ppo_loop
         if ppo_f32:
             out["ppo_loop_f32"] = ppo_f32
+        if ppo_x2:
+            out["ppo_loop_bf16x2"] = ppo_x2
         if ppo_large:
             out["ppo_loop_large_minibatch"] = ppo_large
         if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    ppo_loop = ppo_large = ppo_f32 = None
+    ppo_loop = ppo_large = ppo_f32 = ppo_x2 = None
     rc = 0
     if args.ppo_iters < 0:
         args.ppo_iters = 10 if args.mode == "kinematic" else 0      # ~90 ms of timed work per PPO leg
@@ -762,24 +764,29 @@ def run_rank(args):
                 # learner is float32 torch (pioneer_knm_train.py:47), so THIS is the reference-precision figure; `ppo_loop` is the
                 # bf16-operand extra
                 ppo_f32 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "f32")
+                # two planes: 16 significant bits per operand — heads within 8e-6, gradients within 1.4e-5 of float32
+                # (profiles/r04_f_accuracy_by_precision.jsonl), between the two in speed
+                ppo_x2 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "bf16x2")
             if args.ppo_large_minibatch > 0 and args.ppo_large_minibatch != args.ppo_minibatch:
                 ppo_large = ppo_leg(args.ppo_iters, args.ppo_large_minibatch)
         except Exception as exc:
             err = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             if ppo_loop is None:
                 ppo_loop = err
-            elif args.ppo_f32 and ppo_f32 is None:
+            elif args.ppo_f32 and world == 1 and ppo_f32 is None:
                 ppo_f32 = err
+            elif args.ppo_f32 and world == 1 and ppo_x2 is None:
+                ppo_x2 = err
             else:
                 ppo_large = err
             rc = 5
         with lock:
             state["done"] = True
         wd.cancel()
-        for leg in (ppo_loop, ppo_large, ppo_f32):
+        for leg in (ppo_loop, ppo_large, ppo_f32, ppo_x2):
             if leg and leg.get("losses_finite") is False:
                 rc = 5
-    emit(ppo_loop, ppo_large, ppo_f32)
+    emit(ppo_loop, ppo_large, ppo_f32, ppo_x2)
 
     if world > 1:
         dist.barrier()

@@ -51,7 +51,7 @@ if has ppo; then
 fi
 if has learner; then
   cp $R/profiles/learner_pmc_traffic.json $O/prof_${TAG}_learner_pmc_traffic.json 2>/dev/null || true
-  for P in 1 3; do
+  for P in 1 2 3; do
     export PLANES=$P
     STEP="$R/tools/mlp_step_bench.py 32768 100"
     db=$(prof lstat$P --kernel-trace -d /tmp/p_lstat$P -o t -- python3 $STEP)
