@@ -404,7 +404,8 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
  * [pnr_mlp_grad_floats()] floats each.  wpack / bias must hold the CURRENT weights on entry (pnr_mlp_pack once, then
  * every update refreshes them).  All pointers are device pointers; `means` receives (policy_loss, vf_loss, kl,
  * entropy, total, 0, 0, 0).  partials: scratch of partial_rows >= 2 * ceil(batch / 64) rows of 8 floats; `head` is not
- * written (the head rows never leave the chip); g_head [2][batch][16] is.
+ * written (the head rows never leave the chip); g_head [2][batch][16] is.  wpack, bias, adam_m, adam_v, slabs and flat_grad
+ * must be 16-byte aligned (PNR_ERR_INVALID otherwise: the optimiser kernel moves them four floats at a time).
  */
 typedef struct pnr_mlp_step {
     uint32_t struct_size;   /* sizeof(pnr_mlp_step) */

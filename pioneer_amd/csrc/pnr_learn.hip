@@ -330,6 +330,8 @@ static int mlp_step_check(const pnr_mlp_step* s, const char* who)
     if (s->first_net < 0 || s->n_nets < 0 || s->first_net + (s->n_nets ? s->n_nets : kMlpNets) > kMlpNets)
         return fail(nullptr, PNR_ERR_INVALID, "%s: bad net range (first_net %d, n_nets %d)", who, s->first_net, s->n_nets);
     if (s->planes < 0 || s->planes > kMlpMaxPlanes) return fail(nullptr, PNR_ERR_INVALID, "%s: planes must be 0 .. 3 (got %d)", who, s->planes);
+    if ((reinterpret_cast<uintptr_t>(s->wpack) | reinterpret_cast<uintptr_t>(s->bias) | reinterpret_cast<uintptr_t>(s->adam_m) | reinterpret_cast<uintptr_t>(s->adam_v)) & 15)
+        return fail(nullptr, PNR_ERR_INVALID, "%s: wpack, bias, adam_m and adam_v must be 16-byte aligned (mlp_adam_kernel moves them four floats at a time)", who);
     return PNR_OK;
 }
 
@@ -351,7 +353,7 @@ static void mlp_launch_adam(const pnr_mlp_step* s, const float* grad, int slices
     A.m = s->adam_m; A.v = s->adam_v; A.step = s->adam_step;
     A.lr = s->lr; A.beta1 = s->beta1; A.beta2 = s->beta2; A.eps = s->eps;
     A.wpack = static_cast<__bf16*>(s->wpack); A.bias = s->bias; A.planes = s->planes > 1 ? s->planes : 1;
-    hipLaunchKernelGGL(mlp_adam_kernel, dim3((kGradElems + 255) / 256 + 1, step_nets(s)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(mlp_adam_kernel, dim3(kAdamBlocks + 1, step_nets(s)), dim3(256), 0, st, A);
 }
 
 int pnr_ppo_pack_record(int64_t rows, const float* actions, const float* logp_old, const float* mean_old, const float* log_std_old,
@@ -407,6 +409,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: null argument or empty batch");
     if ((s->f_loc || s->f_inv || s->f_lo || s->f_hi) && !(s->f_loc && s->f_inv && s->f_lo && s->f_hi))
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: the four filter vectors come together or not at all");
+    if (reinterpret_cast<uintptr_t>(s->slabs) & 15) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: slabs must be 16-byte aligned");
     long long slices, rows;
     mlp_slicing(B, &slices, &rows);
     if (s->slab_floats < slices * kMlpNets * kGradElems)
@@ -465,7 +468,9 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
         const unsigned per_net = (unsigned)std::max(1, cus / kMlpNets);
         hipLaunchKernelGGL(mlp_train_kernel, dim3(std::min(tiles.x, per_net), nets), dim3(kFwdThreads), 0, st, F);
     } else if (planes == 1) {
-        hipLaunchKernelGGL((mlp_forward_kernel<true, 1>), tiles, dim3(kFwdThreads), 0, st, F);
+        // both nets of a tile in one workgroup (input tile staged once; every workgroup resident from the start) when both are asked for
+        F.paired = PNR_MLP_PAIRED && nets == 2;
+        hipLaunchKernelGGL((mlp_forward_kernel<true, 1>), F.paired ? dim3(tiles.x, 1) : tiles, dim3(kFwdThreads), 0, st, F);
     } else if (planes == 2) {
         hipLaunchKernelGGL((mlp_forward_kernel<true, 2>), tiles, dim3(kFwdThreads), 0, st, F);
     } else {
@@ -500,7 +505,7 @@ int pnr_mlp_adam(const pnr_mlp_step* s, const float* flat_grad, float grad_scale
 {
     int rc = mlp_step_check(s, "pnr_mlp_adam");
     if (rc) return rc;
-    if (!flat_grad) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_adam: null gradient");
+    if (!flat_grad || (reinterpret_cast<uintptr_t>(flat_grad) & 15)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_adam: null or not 16-byte aligned gradient");
     mlp_launch_adam(s, flat_grad, 1, grad_scale, (hipStream_t)stream);
     HIP_TRY(nullptr, hipGetLastError());
     return PNR_OK;

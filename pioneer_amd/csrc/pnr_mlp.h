@@ -62,6 +62,14 @@ static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implem
 #define PNR_MLP_W3_LDS 0          // 1: the fused kernel (bf16 operands) keeps W3 in LDS for its head product.  A/B r04: 51.2 vs 50.6 us, train_step 84.1 vs 84.2 — no gain
                                   // (the co-resident workgroup fills the head phase's L2 round trip anyway), so the fragments keep coming from L2 and LDS stays 53 KB
 #endif
+#ifndef PNR_MLP_PAIRED
+#define PNR_MLP_PAIRED 0           // 1: fused kernel (bf16): ONE workgroup takes a tile through BOTH nets (input tile staged once: stage 0 is 3 900 of a unit's
+                                  // 34 000 cycles; 512 resident workgroups instead of two rounds).  A/B r04 g: bit-identical, SLOWER — 54.5 vs 50.1 us, train_step
+                                  // 86.6 vs 82.2: the back edge costs the schedule more (106 SGPRs, spills) than the second stage 0 was worth
+#endif
+#ifndef PNR_MLP_PRIO
+#define PNR_MLP_PRIO 0             // fused kernel (bf16): bit k set = the k-th group of 256 workgroups (dispatch order) runs at wave priority 1 (A/B r04 g)
+#endif
 #ifndef PNR_MLP_DEPHASE
 #define PNR_MLP_DEPHASE 0         // > 0: the fused kernel's second workgroup per CU starts this many x 64 cycles late (A/B r04)
 #endif
@@ -88,7 +96,7 @@ constexpr int kMlpStampSlots = 26;   // 0..22 phase boundaries (s_memtime), 24 /
 #define MLP_STAMP(i) do { if (P.stamps && lane == 0) { stamp_lds_[w][(i)] = __builtin_amdgcn_s_memtime(); \
     if ((i) == 0) stamp_lds_[w][24] = __builtin_amdgcn_s_memrealtime(); if ((i) == 22) stamp_lds_[w][25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define MLP_STAMP_FLUSH do { if (P.stamps && lane < kMlpStampSlots) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    P.stamps[(((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kFwdWaves + w) * kMlpStampSlots + lane] = stamp_lds_[w][lane]; } } while (0)
+    P.stamps[(((size_t)blockIdx.x * stamp_ny_ + stamp_yi_) * kFwdWaves + w) * kMlpStampSlots + lane] = stamp_lds_[w][lane]; } } while (0)
 #else
 #define MLP_STAMP_DECL
 #define MLP_STAMP(i) do { } while (0)
@@ -499,6 +507,7 @@ struct MlpFwdParams {
     __bf16* h2;                // [2][B][256]
     long long B;
     int first_net, n_nets;     // blockIdx.y + first_net = net
+    int paired;                // FUSED, bf16 operands, n_nets == 2: grid (tiles, 1), the workgroup runs net 0 then net 1 of its tile
     // the sampler's action draw, fused into the layer-3 epilogue (all null in the learner): a = mean + exp(log_std) * noise
     // with log_std = clamp(raw, -20, 2) (RLlib DiagGaussian's sample(); SquashedGaussian is not the reference's choice),
     // the env's action = clamp(a, -a_max, a_max) when a_max is given (RLlib clip_actions, the reference's default)
@@ -538,6 +547,8 @@ struct MlpFwdParams {
 // MFMA) — and per wave that chain is products + epilogues + tile stores + reload, all proportional to the rows a wave owns.
 constexpr int kFwdWaves = 8;
 constexpr int kFwdThreads = 64 * kFwdWaves;
+constexpr int kFusedScratchFloats = kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats + 4 * 8;     // head rows, head gradients, record, loss sums: 13 KB
+static_assert(kFusedScratchFloats % 4 == 0, "");
 static_assert((kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats + 4 * 8) * 4 <= kMlpBM * kXS * 2, "head rows, head gradients, record and loss sums fit the dead input tile");
 static_assert(kFwdWaves * 32 == kMlpHid, "one 32-row block of the 256 hidden units per wave");
 
@@ -861,17 +872,33 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     // fragments' round trip stood in the middle of the tile's chain (head phase 2 070 cycles for 128 cycles of MFMA on four of the
     // eight waves, the others waiting at the next barrier: profiles/r03_j_mlp_stamps.json).  (NS = 3 has no LDS left for it.)
     constexpr bool kW3Lds = PNR_MLP_W3_LDS && NS == 1 && FUSED;      // (the plain forward keeps three workgroups per CU: 53 KB each)
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0)];
-    static_assert(NS >= 1 && NS <= kMlpMaxPlanes && NS * kTilePlane * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
+    // PAIRED (r04 g, bf16 operands): the workgroup takes its tile through net 0 and then net 1 — the input tile is staged once and
+    // has to survive the first net, so the head rows, head gradients, record and loss sums get 13 KB of their own instead of the
+    // dead input tile: 66 KB, still two workgroups per CU
+    constexpr bool kPairedBuild = PNR_MLP_PAIRED && FUSED && NS == 1;
+    constexpr int kScratchElems = kPairedBuild ? 2 * kFusedScratchFloats : 0;
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0) + kScratchElems];
+    static_assert(NS >= 1 && NS <= kMlpMaxPlanes && (NS * kTilePlane + kScratchElems) * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
+    static_assert(!kPairedBuild || 2 * ((kTilePlane + kScratchElems + (kW3Lds ? kMlpHead * kMlpHid : 0)) * 2 + (PNR_MLP_STAMPS ? 2048 : 0)) <= 160 * 1024, "two paired workgroups per CU");
     MLP_STAMP_DECL;
     __bf16* xt = lds;
     __bf16* ht = lds + kMlpBM * kXS;
     __bf16* w3l = lds + NS * kTilePlane;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int net = blockIdx.y + P.first_net;
     const long long row0 = (long long)blockIdx.x * kMlpBM;
-    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
-    const float* bias = P.bias + net * kBiasElems;
+    float* const scr = kPairedBuild ? reinterpret_cast<float*>(lds + NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0)) : reinterpret_cast<float*>(xt);
+    const bool paired = kPairedBuild && P.paired;
+    [[maybe_unused]] const int units = paired ? 2 : 1;
+    // one (tile, net) unit per pass.  (The back edge exists in the paired instantiation only: wrapped in a `for` — even one of constant
+    // trip count 1 — every other instantiation lost its schedule: 78 -> 105, 178 -> 204, 242 -> 256 registers; as a lambda called from
+    // a loop, the closure cost every instantiation 40 bytes of scratch.)
+    int u = 0;
+unit_begin: __attribute__((unused));
+    {
+    // (the thread index is re-read behind an opaque barrier in every unit: as a loop invariant, the body's few hundred tile and
+    // fragment addresses were all hoisted in front of the loop and spilled — 396 bytes of scratch per lane)
+    int tid_ = threadIdx.x;
+    if constexpr (kPairedBuild) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, w = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     // ---- which blocks of a layer's [256 rows][64 samples] output this wave's two accumulators hold.  8 x 1 layout (r03): row block w,
     // column blocks 0 and 1.  4 x 2 layout (r04, bf16 operands): row blocks 2 (w >> 1) and + 1, column block w & 1.
@@ -902,6 +929,13 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
         for (int cb = 0; cb < kMlpCB; ++cb) acc[cb] = b[L42 ? cb : 0];
     };
+    const int yi = paired ? u : (int)blockIdx.y;                  // index of this (tile, net) unit among the tile's units
+    const int net = yi + P.first_net;
+    [[maybe_unused]] const int stamp_yi_ = yi, stamp_ny_ = paired ? 2 : (int)gridDim.y;
+    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    const float* bias = P.bias + net * kBiasElems;
+    // the second unit of a pair overwrites the hidden tile the first one's dZ1 store is still reading
+    if (u > 0) mlp_barrier();
     // layer 1's bias and first weight fragments do not depend on the tile: requested before anything else
     MLP_STAMP(0);
     f32x4 bq1[NRB][4];
@@ -922,12 +956,21 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         }
     }
 #endif
+#if PNR_MLP_PRIO
+    if constexpr (FUSED && NS == 1) {
+        // Of a CU's two workgroups the older one wins every contended issue slot: it ends at ~17.3 us, its neighbour at ~22.5, and
+        // the pair that follows them inherits the skew (stamps r04 g: first round ends 17 / 22.5 us, second 35.5 / 41-42.6) — the launch
+        // ends with half-empty CUs.  PNR_MLP_PRIO: wave priority by dispatch group of 256 workgroups (bit k of the value = priority of group k)
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((PNR_MLP_PRIO >> ((lin >> 8) & 3)) & 1) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     if constexpr (FUSED) {       // this launch is one optimiser update: counted here, read by the Adam kernel two launches on
-        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
+        if (blockIdx.x == 0 && yi == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
     }
 
-    // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero)
-    {
+    // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero); a pair's second unit finds it in place
+    if (u == 0) {
         static_assert(kMlpHead * kMlpHid / 8 == kFwdThreads, "W3: one 16-byte piece per thread");
         uint4 w3v = make_uint4(0u, 0u, 0u, 0u);
         if constexpr (kW3Lds) w3v = *reinterpret_cast<const uint4*>(wp + kOffW3 + 8 * tid);    // travels with the tile's rows
@@ -1119,7 +1162,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         else g2.run(ht, acc, lane, l2_hook, &b16_2[0]);
     }
     if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
-        if (rec_early) rect.park(reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
+        if (rec_early) rect.park(scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
     }
     MLP_STAMP(6);                         // layer-2 product issued
     mlp_barrier();
@@ -1158,7 +1201,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             const f32x4 hq = a3;
             if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = hq;
             if constexpr (FUSED) {                                    // head rows of the tile, float32 [64][16], in the dead input tile
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(xt) + (16 * w + r16) * kMlpHead + 4 * g) = hq;
+                *reinterpret_cast<f32x4*>(scr + (16 * w + r16) * kMlpHead + 4 * g) = hq;
             } else if (P.noise) {
                 if (net == 1) {
                     if (b < P.B && g == 0) P.values[b] = hq[0];
@@ -1205,10 +1248,10 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         if (P.h2 && !(PNR_MLP_DIAG & 64)) store_planes(P.h2);
     }
     if constexpr (FUSED) {
-        float* hd = reinterpret_cast<float*>(xt);                         // [64][16] float32 head rows (written above)
-        __bf16* gt = xt + kMlpBM * kMlpHead * 2;                          // [64][kGS] bf16 head gradients, behind them
-        const float* rl = reinterpret_cast<const float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2;   // the parked record
-        float* wsum = reinterpret_cast<float*>(xt) + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats; // [8 waves][4] loss sums
+        float* hd = scr;                                                  // [64][16] float32 head rows (written above)
+        __bf16* gt = reinterpret_cast<__bf16*>(scr) + kMlpBM * kMlpHead * 2;    // [64][kGS] bf16 head gradients, behind them
+        const float* rl = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2;     // the parked record
+        float* wsum = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats;   // [8 waves][4] loss sums
         // W3^T's fragment for the first backward product: requested before the H2 store and the loss
         bf16x8 w3t[NS * NRB];                                            // [plane] (8 x 1) or [row block] (4 x 2, one plane)
 #pragma unroll
@@ -1227,7 +1270,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < kFwdWaves; ++k) t += *reinterpret_cast<const f32x4*>(wsum + 4 * k);
-            float* pr = P.partials + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * 8;
+            float* pr = P.partials + ((size_t)blockIdx.x * P.n_nets + yi) * 8;
             *reinterpret_cast<f32x4*>(pr) = t;
             *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -1272,7 +1315,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         };
         // ---- layer 3's weight-gradient partials of this tile (dW3 = G^T . H2, db3 = G^T . 1), while H2 is still in the tile: this wave's
         // 32 feature columns are the ones only it overwrites below
-        float* w3p = P.w3part ? P.w3part + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * kW3PartFloats : nullptr;
+        float* w3p = P.w3part ? P.w3part + ((size_t)blockIdx.x * P.n_nets + yi) * kW3PartFloats : nullptr;
         if (w3p) {
             f32x4 aw3[2], ab3;
             mlp_tile_w3_products<NS>(gt, kGS, ht, kHS, lane, w, aw3, ab3, kTilePlane, kTilePlane);
@@ -1353,6 +1396,8 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         MLP_STAMP(22);                    // end
         MLP_STAMP_FLUSH;
     }
+    }   // unit
+    if constexpr (kPairedBuild) { if (++u < units) goto unit_begin; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1411,6 +1456,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void mlp_train_kernel(const MlpFwdP
     __bf16* w3l = reinterpret_cast<__bf16*>(bl + 2 * kMlpHid);      // W3 and W3^T as they are packed (fragment-native, 8 KB each):
     __bf16* w3tl = w3l + kMlpHead * kMlpHid;                        // read per tile with no register and no L2 round trip
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    [[maybe_unused]] const int stamp_yi_ = blockIdx.y, stamp_ny_ = gridDim.y;
     const int net = blockIdx.y + P.first_net;
     const long long tiles = (P.B + kMlpBM - 1) / kMlpBM;
     const __bf16* wp = P.wpack + (size_t)net * kPackElems;
@@ -2856,78 +2902,112 @@ struct MlpAdamParams {
     int planes;                // bf16 planes of the packed weights that are refreshed (1: bf16 operands; 2, 3: split float32)
 };
 
+constexpr int kAdamVec = 4;          // consecutive gradient-layout elements per thread (every region of the layout starts on a multiple of 4)
+constexpr int kAdamBlocks = (kGradElems / kAdamVec + 255) / 256;     // + 1: the loss-means block
+static_assert(kGradElems % kAdamVec == 0 && kGW2 % 4 == 0 && kGW3 % 4 == 0 && kGB1 % 4 == 0 && kGB2 % 4 == 0 && kGB3 % 4 == 0 && kMlpInPad % 4 == 0, "");
+
+// r04: FOUR elements per thread — the bias corrections' two powf once per four elements, the 32 slabs as 32 16-byte loads in one batch
+// (slice order in the sum: same bits as before), one 8-byte store per fragment-native bf16 group; 840 waves instead of 6 712.  Measured
+// (tools/adam_floor.py, profiles/r04_g_adam_four_per_thread_ab.txt): 10.6 -> 10.1 us with the learner's 32 slabs, 8.0 -> 7.7 us back to
+// back with ONE flat gradient — neither the instruction stream (~700 per wave before) nor the slabs' four dependent round trips were
+// the bound: ~6 us of the launch are its floor (launch, one load round trip from HBM, the stores' drain) and ~4 us the 27 MB of slabs.
 __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
 {
     const int net = blockIdx.y + P.first_net;
     if (blockIdx.x == 0) {
-        // the extra block (the FIRST one, so that it starts with the launch and not as its tail): the five loss means from the fused kernel's per-workgroup rows (ppo_loss_finish_split_kernel's
-        // job), in the shadow of the other 838 blocks
-        // instead of a 5.6 us launch of its own
+        // the extra block (the FIRST one, so that it starts with the launch and not as its tail): the five loss means from the fused
+        // kernel's per-workgroup rows (ppo_loss_finish_split_kernel's job), in the shadow of the other blocks instead of a launch of its own
         __shared__ float red[4][kPpoSums];
         if (blockIdx.y != 0 || !P.partials) return;
         ppo_loss_means_block(P.partials, P.loss_rows, P.batch, P.means, P.kl_coeff, P.ent_coeff, P.vf_coeff, red);
         return;
     }
-    const int e = (blockIdx.x - 1) * 256 + threadIdx.x;
+    const int e = ((blockIdx.x - 1) * 256 + threadIdx.x) * kAdamVec;
     if (e >= kGradElems) return;
+    const size_t si = (size_t)net * kGradElems + e;
+    // requested first, so that they arrive under the slabs' round trip
+    const float t = *P.step;
+    const f32x4 m4 = *reinterpret_cast<const f32x4*>(P.m + si), v4 = *reinterpret_cast<const f32x4*>(P.v + si);
+
+    // where the four elements live: master parameter (dst, `valid` of them exist), fragment-native bf16 copies (wp0: four consecutive
+    // elements of one fragment row; wp1[j]: the transposed copy, one row each), bias copy
     float* dst = nullptr;
-    int wp0 = -1, wp1 = -1, bp = -1;               // where the bf16 / bias copies of this element go
+    int valid = kAdamVec, wp0 = -1, bp = -1;
+    int wp1[kAdamVec] = {-1, -1, -1, -1};
     if (e < kGW2) {
         const int o = e / kMlpInPad, k = e % kMlpInPad;
         wp0 = kOffW1 + frag32_off(o, k, kMlpInPad / 16);
-        if (k < kMlpIn) dst = P.w1[net] + o * kMlpIn + k;
+        dst = P.w1[net] + o * kMlpIn + k; valid = kMlpIn - k;
     } else if (e < kGW3) {
         const int r = e - kGW2, o = r / kMlpHid, i = r % kMlpHid;
-        dst = P.w2[net] + r; wp0 = kOffW2 + frag32_off(o, i, kMlpHid / 16); wp1 = kOffW2T + frag32_off(i, o, kMlpHid / 16);
+        dst = P.w2[net] + r; wp0 = kOffW2 + frag32_off(o, i, kMlpHid / 16);
+#pragma unroll
+        for (int j = 0; j < kAdamVec; ++j) wp1[j] = kOffW2T + frag32_off(i + j, o, kMlpHid / 16);
     } else if (e < kGB1) {
         const int r = e - kGW3, row = r / kMlpHid, f = r % kMlpHid;
-        wp0 = kOffW3 + frag16_off(row, f); wp1 = kOffW3T + frag32_off(f, row, 1);
-        if (row < P.n3[net]) dst = P.w3[net] + r;
+        wp0 = kOffW3 + frag16_off(row, f);
+#pragma unroll
+        for (int j = 0; j < kAdamVec; ++j) wp1[j] = kOffW3T + frag32_off(f + j, row, 1);
+        dst = P.w3[net] + r; valid = row < P.n3[net] ? kAdamVec : 0;
     } else if (e < kGB2) { dst = P.b1[net] + (e - kGB1); bp = e - kGB1; }
     else if (e < kGB3) { dst = P.b2[net] + (e - kGB2); bp = kMlpHid + (e - kGB2); }
-    else { bp = 2 * kMlpHid + (e - kGB3); if (e - kGB3 < P.n3[net]) dst = P.b3[net] + (e - kGB3); }
+    else { bp = 2 * kMlpHid + (e - kGB3); dst = P.b3[net] + (e - kGB3); valid = P.n3[net] - (e - kGB3); }
+    float p0[kAdamVec];
+#pragma unroll
+    for (int j = 0; j < kAdamVec; ++j) p0[j] = j < valid ? dst[j] : 0.f;
 
-    float pv = 0.f;
-    if (dst) {
-        float g = 0.f;
-        const float* gp = P.grad + (size_t)net * kGradElems + e;
-        // the slices' partial gradients, summed in slice order (the order mlp_reduce_flat_kernel uses: same bits), eight
-        // loads in flight at a time: as a plain loop with a runtime trip count every load waited for the previous add
+    // the slices' partial gradients, summed in slice order per element (the order mlp_reduce_flat_kernel uses: same bits)
+    f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+    if (valid > 0) {
         constexpr size_t kStride = (size_t)kMlpNets * kGradElems;
+        const float* gp = P.grad + si;
         int k = 0;
+        if (P.slices == 32) {                               // the learner's slab count: one batch of loads, one round trip
+            f32x4 x[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gp + (size_t)j * kStride));
+#pragma unroll
+            for (int j = 0; j < 32; ++j) g4 += x[j];
+            k = 32;
+        }
         for (; k + 8 <= P.slices; k += 8) {
-            float x[8];
+            f32x4 x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = gp[(size_t)(k + j) * kStride];
+            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const f32x4*>(gp + (size_t)(k + j) * kStride);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g += x[j];
+            for (int j = 0; j < 8; ++j) g4 += x[j];
         }
-        for (; k < P.slices; ++k) g += gp[(size_t)k * kStride];
-        g *= P.grad_scale;
-        const size_t si = (size_t)net * kGradElems + e;
-        const float t = *P.step;
-        float m = P.m[si], v = P.v[si];
-        m = m + (g - m) * (1.0f - P.beta1);
-        v = P.beta2 * v + (1.0f - P.beta2) * g * g;
-        const float bc1 = 1.0f - powf(P.beta1, t), bc2 = 1.0f - powf(P.beta2, t);
-        const float denom = sqrtf(v) / sqrtf(bc2) + P.eps;
-        pv = *dst - (P.lr / bc1) * (m / denom);
-        P.m[si] = m; P.v[si] = v; *dst = pv;
+        for (; k < P.slices; ++k) g4 += *reinterpret_cast<const f32x4*>(gp + (size_t)k * kStride);
     }
+    const float bc1 = 1.0f - powf(P.beta1, t), bc2 = 1.0f - powf(P.beta2, t);
+    const float rbc2 = sqrtf(bc2), lr1 = P.lr / bc1;
+    f32x4 mo = m4, vo = v4;
+    float pv[kAdamVec];
+#pragma unroll
+    for (int j = 0; j < kAdamVec; ++j) {
+        pv[j] = 0.f;
+        if (j < valid) {
+            const float g = g4[j] * P.grad_scale;
+            const float m = m4[j] + (g - m4[j]) * (1.0f - P.beta1);
+            const float v = P.beta2 * v4[j] + (1.0f - P.beta2) * g * g;
+            const float denom = sqrtf(v) / rbc2 + P.eps;
+            pv[j] = p0[j] - lr1 * (m / denom);
+            mo[j] = m; vo[j] = v; dst[j] = pv[j];
+        }
+    }
+    if (valid > 0) { *reinterpret_cast<f32x4*>(P.m + si) = mo; *reinterpret_cast<f32x4*>(P.v + si) = vo; }
     __bf16* wp = P.wpack + (size_t)net * kPackElems;
-    if (P.planes <= 1) {
-        if (wp0 >= 0) wp[wp0] = (__bf16)pv;
-        if (wp1 >= 0) wp[wp1] = (__bf16)pv;
-    } else {
-        float r = pv;
-        for (int pl = 0; pl < P.planes; ++pl) {
-            const __bf16 b = (__bf16)r;
-            if (wp0 >= 0) wp[pl * kWPlane + wp0] = b;
-            if (wp1 >= 0) wp[pl * kWPlane + wp1] = b;
-            r -= (float)b;
-        }
+    float r[kAdamVec] = {pv[0], pv[1], pv[2], pv[3]};
+    for (int pl = 0; pl < P.planes; ++pl) {
+        bf16x4 b;
+#pragma unroll
+        for (int j = 0; j < kAdamVec; ++j) { b[j] = (__bf16)r[j]; r[j] -= (float)b[j]; }
+        __bf16* w = wp + (size_t)pl * kWPlane;
+        if (wp0 >= 0) *reinterpret_cast<bf16x4*>(w + wp0) = b;
+#pragma unroll
+        for (int j = 0; j < kAdamVec; ++j) if (wp1[j] >= 0) w[wp1[j]] = b[j];
     }
-    if (bp >= 0) P.bias[net * kBiasElems + bp] = pv;
+    if (bp >= 0) *reinterpret_cast<f32x4*>(P.bias + net * kBiasElems + bp) = f32x4{pv[0], pv[1], pv[2], pv[3]};
 }
 
 }  // namespace pnr

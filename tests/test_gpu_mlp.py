@@ -257,6 +257,25 @@ def test_train_step_equals_autograd_plus_torch_adam(B):
     assert torch.equal(w_now, mlp.wpack) and torch.equal(b_now, mlp.bias)         # the refreshed bf16 copies are exact
 
 
+def test_adam_refuses_a_gradient_that_is_not_16_byte_aligned():
+    """The optimiser kernel moves its operands four floats at a time (include/pioneer_amd.h, pnr_mlp_step): a misaligned
+    bucket is an argument error, not a fault."""
+    from pioneer_amd._lib import PnrError
+    model, mlp, obs, _, filt = make(64, seed=3, rows=64, with_filter=False)
+    mlp.pack()
+    n = int(mlp.lib.pnr_mlp_grad_floats())
+    store = torch.zeros(n + 4, device=obs.device)
+    before = [p.detach().clone() for p in mlp.params]
+    with pytest.raises(PnrError, match="16-byte aligned"):
+        mlp.adam(store[1:n + 1], 1.0, 1e-3)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(before, mlp.params))
+    mlp.adam_state()[2].fill_(1.0)               # (the update count the fused kernel would have written)
+    mlp.adam(store[4:n + 4], 1.0, 1e-3)          # aligned view of the same storage: accepted (zero gradient: parameters unchanged)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(before, mlp.params))
+
+
 @pytest.mark.parametrize("B", [8192, 4099, 16421])
 def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
     """pnr_mlp_gather + train_step(xs_in=...) against train_step(obs, idx, filt): the same filter arithmetic and rounding,

@@ -30,12 +30,19 @@ if not hasattr(raw, "pnr_mlp_set_stamp_buffer"):
     sys.exit("this library was not built with -DPNR_MLP_STAMPS=1")
 torch.manual_seed(0)
 model = ActorCritic(PPOConfig()).to(dev)
-mlp = HipMLP(model, B, dev)
+PLANES = int(os.environ.get("PLANES", "1"))      # 1: bf16 operands; 2, 3: split float32 operands
+mlp = HipMLP(model, B, dev, planes=PLANES)
 mlp.pack()
 R = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
 act, mean, ls = R(B, 6), 0.1 * R(B, 6), 0.1 * R(B, 6)
 rec = {"actions": act, "mean": mean, "log_std": ls, "logp": gaussian_logp(act, mean, ls), "values": R(B), "adv": R(B), "vtarg": R(B)}
-xs = R(B, 144).bfloat16().contiguous()
+x32 = R(B, 144)
+x32[:, 137:] = 0
+planes_of_x = []
+for _ in range(PLANES):                       # the split planes of the float32 input: p0 = bf16(x), p1 = bf16(x - p0), ...
+    planes_of_x.append(x32.bfloat16())
+    x32 = x32 - planes_of_x[-1].float()
+xs = planes_of_x[0].contiguous() if PLANES == 1 else torch.stack(planes_of_x).contiguous()
 klc, entc, means = torch.tensor(0.2, device=dev), torch.tensor(0.01, device=dev), torch.zeros(8, device=dev)
 wgs = (B // 64) * 2
 stamps = torch.zeros((wgs, 8, 26), dtype=torch.int64, device=dev)
@@ -63,6 +70,14 @@ for i in range(22):
            "waves1_3": [int(np.median(b)), int(np.percentile(b, 10)), int(np.percentile(b, 90))]}
     out["phases"].append(row)
     print(f"{NAMES[i + 1]:44s} {row['wave0'][0]:9d} {row['wave0'][1]:7d} {row['wave0'][2]:7d} | {row['waves1_3'][0]:9d} {row['waves1_3'][1]:7d} {row['waves1_3'][2]:7d}")
+# when do workgroups start?  (dispatch order = linear block id: x fastest, then net)
+order = np.arange(wgs)
+out["tile_start_us_every_5_percent"] = [round(float(np.percentile(start_us, q)), 2) for q in range(0, 101, 5)]
+out["tile_start_us_by_block_id_blocks_of_64"] = [round(float(np.median(start_us[i:i + 64])), 2) for i in range(0, wgs, 64)]
+out["tile_end_us_every_5_percent"] = [round(float(np.percentile((rt1 - rt0.min()) / 100.0, q)), 2) for q in range(0, 101, 5)]
+print("start times (us), every 5 %:", out["tile_start_us_every_5_percent"])
+print("median start time (us) of blocks 0-63, 64-127, ...:", out["tile_start_us_by_block_id_blocks_of_64"])
+print("end times (us), every 5 %:", out["tile_end_us_every_5_percent"])
 early = start_us < 0.25 * span_us
 out["tile_us_first_round"] = float(np.median(tile_us[early]))
 out["tile_us_later"] = float(np.median(tile_us[~early])) if (~early).any() else None
