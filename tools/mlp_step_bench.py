@@ -42,8 +42,14 @@ streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
 means2 = torch.zeros(2, 8, device=dev)
 
 
+INKERNEL = os.environ.get("INKERNEL_GATHER", "0") == "1"      # the minibatch's rows gathered (and filtered) by the fused kernel's stage 0 instead of pnr_mlp_gather
+
+
 def step(i):
     s = (i % 16) * B
+    if INKERNEL:
+        mlp.train_step(obs, perm[s:s + B], filt, rec, klc, entc, 0.3, 10.0, 1.0, means, 2e-5)
+        return
     if CHAINS:
         for net, st in enumerate(streams):
             with torch.cuda.stream(st):
@@ -93,6 +99,6 @@ for _ in range(N):
     act_call()
 e1.record()
 torch.cuda.synchronize()
-print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "planes": PLANES, "chains": CHAINS, "w3_partials": mlp.w3_partials, "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
+print(json.dumps({"lib": os.environ.get("PNR_LIB_PATH", "default"), "planes": PLANES, "in_kernel_gather": INKERNEL, "chains": CHAINS, "w3_partials": mlp.w3_partials, "batch": B, "train_step_us": us, "act_16384_us": e0.elapsed_time(e1) / N * 1e3,
                   "param_sums": [round(float(p_.double().sum()), 6) for p_ in mlp.params[:2]] + [round(float(p_.double().sum()), 6) for p_ in mlp.params[6:8]],
                   "means_finite": bool(torch.isfinite(means[:5]).all()), "means": [round(float(x), 5) for x in means[:5]]}))
