@@ -87,14 +87,16 @@ constexpr int kMlpThreads = 256;  // four waves
 #ifndef PNR_MLP_STAMPS
 #define PNR_MLP_STAMPS 0
 #endif
-constexpr int kMlpStampSlots = 26;   // 0..22 phase boundaries (s_memtime), 24 / 25 s_memrealtime (100 MHz) at start / end
+constexpr int kMlpStampSlots = 26;   // 0..22 phase boundaries (s_memtime), 23 HW_REG_XCC_ID << 32 | HW_REG_HW_ID, 24 / 25 s_memrealtime (100 MHz) at start / end
 #if PNR_MLP_STAMPS
 // The stamps wait in LDS and leave for global memory at the kernel's end: written to global memory where they are taken (r03b - r03i),
 // every stamp was a store that the next s_waitcnt vmcnt(..) of the wave — the weight ring's, in order — also waited for, i.e. the
 // instrument stretched exactly the phases it was pointed at (found on mlp_wgrad_kernel, r03i).
 #define MLP_STAMP_DECL __shared__ unsigned long long stamp_lds_[kFwdWaves][kMlpStampSlots]
 #define MLP_STAMP(i) do { if (P.stamps && lane == 0) { stamp_lds_[w][(i)] = __builtin_amdgcn_s_memtime(); \
-    if ((i) == 0) stamp_lds_[w][24] = __builtin_amdgcn_s_memrealtime(); if ((i) == 22) stamp_lds_[w][25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+    if ((i) == 0) { stamp_lds_[w][24] = __builtin_amdgcn_s_memrealtime(); \
+        stamp_lds_[w][23] = ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | __builtin_amdgcn_s_getreg(0xF804); }   /* XCC_ID | HW_ID: where the wave runs */ \
+    if ((i) == 22) stamp_lds_[w][25] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define MLP_STAMP_FLUSH do { if (P.stamps && lane < kMlpStampSlots) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     P.stamps[(((size_t)blockIdx.x * stamp_ny_ + stamp_yi_) * kFwdWaves + w) * kMlpStampSlots + lane] = stamp_lds_[w][lane]; } } while (0)
 #else

@@ -78,6 +78,37 @@ out["tile_end_us_every_5_percent"] = [round(float(np.percentile((rt1 - rt0.min()
 print("start times (us), every 5 %:", out["tile_start_us_every_5_percent"])
 print("median start time (us) of blocks 0-63, 64-127, ...:", out["tile_start_us_by_block_id_blocks_of_64"])
 print("end times (us), every 5 %:", out["tile_end_us_every_5_percent"])
+# where do workgroups run?  slot 23 = XCC_ID << 32 | HW_ID of wave 0 (gfx9 HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13)
+hw = full[:, 0, 23]
+xcc, hwid = (hw >> 32) & 0xF, hw & 0xFFFFFFFF
+cu_key = (xcc << 16) | (hwid & 0xFF00)                 # XCC, SE, SH, CU
+end_us = (rt1 - rt0.min()) / 100.0
+by_cu = {}
+for i in range(wgs):
+    by_cu.setdefault(int(cu_key[i]), []).append((float(start_us[i]), float(end_us[i]), i))
+per_cu = sorted(len(v) for v in by_cu.values())
+out["compute_units_seen"] = len(by_cu)
+out["workgroups_per_cu_min_median_max"] = [per_cu[0], per_cu[len(per_cu) // 2], per_cu[-1]]
+# per CU: its workgroups in start order; first-round pair = the two that start first
+first_fast, first_slow, last_end = [], [], []
+for v in by_cu.values():
+    v.sort()
+    if len(v) >= 2:
+        a, b = v[0], v[1]
+        d0, d1 = a[1] - a[0], b[1] - b[0]
+        first_fast.append(min(d0, d1)); first_slow.append(max(d0, d1))
+    last_end.append(max(x[1] for x in v))
+out["first_round_pair_on_a_cu_us_fast_slow_median"] = [float(np.median(first_fast)), float(np.median(first_slow))]
+out["last_end_per_cu_us_percentiles_0_10_50_90_100"] = [float(np.percentile(last_end, q)) for q in (0, 10, 50, 90, 100)]
+per_xcc = {}
+for i in range(wgs):
+    per_xcc.setdefault(int(xcc[i]), []).append(float(tile_us[i]))
+out["tile_us_median_by_xcc"] = {str(k): round(float(np.median(v)), 2) for k, v in sorted(per_xcc.items())}
+out["workgroups_by_xcc"] = {str(k): len(v) for k, v in sorted(per_xcc.items())}
+print("CUs seen:", out["compute_units_seen"], "workgroups per CU (min / median / max):", out["workgroups_per_cu_min_median_max"])
+print("first-round pair of a CU, tile time (us) of the faster / slower one (medians):", out["first_round_pair_on_a_cu_us_fast_slow_median"])
+print("end of the last tile per CU (us), p0/10/50/90/100:", out["last_end_per_cu_us_percentiles_0_10_50_90_100"])
+print("tile time by XCC:", out["tile_us_median_by_xcc"], "workgroups by XCC:", out["workgroups_by_xcc"])
 early = start_us < 0.25 * span_us
 out["tile_us_first_round"] = float(np.median(tile_us[early]))
 out["tile_us_later"] = float(np.median(tile_us[~early])) if (~early).any() else None
