@@ -114,7 +114,7 @@ class PioneerRLlibVectorEnv(compat.RLlibVectorEnv):
         if max_steps > 0:
             for i in np.nonzero(self._elapsed >= max_steps)[0]:
                 infos[int(i)]["TimeLimit.truncated"] = bool(not term[i])
-        return list(obs), [float(x) for x in rew], [bool(x) for x in done], infos
+        return list(obs), rew.tolist(), done.tolist(), infos          # (tolist: Python floats / bools, as RLlib's sampler expects)
 
     def get_unwrapped(self) -> List:
         """RLlib asks for the underlying gym envs (for rendering / custom callbacks); a batched engine has none."""
