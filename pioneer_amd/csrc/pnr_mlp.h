@@ -67,6 +67,9 @@ static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implem
                                   // 34 000 cycles; 512 resident workgroups instead of two rounds).  A/B r04 g: bit-identical, SLOWER — 54.5 vs 50.1 us, train_step
                                   // 86.6 vs 82.2: the back edge costs the schedule more (106 SGPRs, spills) than the second stage 0 was worth
 #endif
+#ifndef PNR_MLP_LDS_PAD
+#define PNR_MLP_LDS_PAD 0          // bf16 elements of unused LDS in the fused kernel: 20000 leaves ONE workgroup per CU (occupancy probe, tools/stamps.sh)
+#endif
 #ifndef PNR_MLP_PRIO
 #define PNR_MLP_PRIO 0             // fused kernel (bf16): bit k set = the k-th group of 256 workgroups (dispatch order) runs at wave priority 1 (A/B r04 g)
 #endif
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     // dead input tile: 66 KB, still two workgroups per CU
     constexpr bool kPairedBuild = PNR_MLP_PAIRED && FUSED && NS == 1;
     constexpr int kScratchElems = kPairedBuild ? 2 * kFusedScratchFloats : 0;
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0) + kScratchElems];
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0) + kScratchElems + ((FUSED && NS == 1) ? PNR_MLP_LDS_PAD : 0)];
     static_assert(NS >= 1 && NS <= kMlpMaxPlanes && (NS * kTilePlane + kScratchElems) * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
     static_assert(!kPairedBuild || 2 * ((kTilePlane + kScratchElems + (kW3Lds ? kMlpHead * kMlpHid : 0)) * 2 + (PNR_MLP_STAMPS ? 2048 : 0)) <= 160 * 1024, "two paired workgroups per CU");
     MLP_STAMP_DECL;
