@@ -467,6 +467,10 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
         }
         const unsigned per_net = (unsigned)std::max(1, cus / kMlpNets);
         hipLaunchKernelGGL(mlp_train_kernel, dim3(std::min(tiles.x, per_net), nets), dim3(kFwdThreads), 0, st, F);
+#if PNR_MLP_FAT
+    } else if (planes == 1 && F.xs_in) {
+        hipLaunchKernelGGL(mlp_fused4_kernel, tiles, dim3(kFatThreads), 0, st, F);       // four 64-row waves per tile, three tiles per CU (A/B r04 g)
+#endif
     } else if (planes == 1) {
         // both nets of a tile in one workgroup (input tile staged once; every workgroup resident from the start) when both are asked for
         F.paired = PNR_MLP_PAIRED && nets == 2;

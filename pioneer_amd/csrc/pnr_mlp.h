@@ -1406,6 +1406,300 @@ unit_begin: __attribute__((unused));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The fused training tile with FOUR 64-row waves (r04 g; -DPNR_MLP_FAT=1, bf16 operands, pre-gathered rows): grid (tiles, nets), 256
+// threads, each wave owns two 32-row blocks of every layer for the WHOLE 64-sample tile (four accumulators), so a weight fragment
+// still reaches the CU once per tile (the 4 x 2 layout's flaw) while a sample fragment read from LDS now serves two MFMAs — and a
+// tile is four waves at <= 168 registers: THREE tiles per CU where the eight-wave form fits two (the occupancy probe, DESIGN §7:
+// one tile's chain leaves most of a CU idle).  Same arithmetic in the same order as mlp_forward_kernel<true, 1>: bit-identical
+// (tests/test_gpu_mlp.py builds the variant and compares).  Measured slower: the comment at PNR_MLP_FAT.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef PNR_MLP_FAT
+#define PNR_MLP_FAT 0             // A/B r04 g: built, bit-identical, SLOWER — mlp_fused4_kernel 64.9 us against mlp_forward_kernel<true>'s 49.8 (train_step 98.1 vs
+                                  // 80.7; ring depth 2 / 4 / 5: 99.3 / 105.7 / 110.4): with ONE wave per SIMD a tile cannot hide its own LDS and L2 latencies, and
+                                  // three such tiles per CU are three waves per SIMD where the eight-wave form has four (168 registers, 64 bytes of scratch)
+#endif
+#if PNR_MLP_FAT
+#ifndef PNR_MLP_RING22
+#define PNR_MLP_RING22 3          // weight-fragment prefetch depth of the four-wave tile (two fragments = 8 registers per slot)
+#endif
+constexpr int kFatThreads = 256, kFatWaves = 4;
+
+// acc[j][cb] += W[row block rb0 + j][K] . tile[column block cb][K]^T, j, cb = 0, 1: two weight fragments (L2) and two sample fragments
+// (LDS) per k-step for four MFMAs
+template <int K, int STRIDE>
+struct MlpGemm22 {
+    static constexpr int KS = K / 16;
+    static constexpr int D = PNR_MLP_RING22;
+    bf16x8 a[D][2];
+    const __bf16* wa;
+    __device__ __forceinline__ void prefetch(const __bf16* __restrict__ w_blocks, int lane)
+    {
+        wa = w_blocks + lane * 8;
+#pragma unroll
+        for (int p = 0; p < D - 1; ++p)
+            if (p < KS) {
+                a[p][0] = ld_global_bf16x8(wa + 512 * p);
+                a[p][1] = ld_global_bf16x8(wa + 512 * (KS + p));
+            }
+    }
+    template <class F>
+    __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[2][kMlpCB], int lane, F&& after_loads, const f32x16* init = nullptr)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const __bf16* tb = tile + r * STRIDE + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + D - 1 < KS) {
+                a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
+                a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 512 * (KS + ks + D - 1));
+            }
+            if (ks == (KS > D ? KS - D : 0)) {
+                __builtin_amdgcn_sched_barrier(0);
+                after_loads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 b[kMlpCB];
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int cb = 0; cb < kMlpCB; ++cb)
+                    acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][j], b[cb], (ks == 0 && init) ? init[j] : acc[j][cb], 0, 0, 0);
+        }
+    }
+};
+
+__global__ __launch_bounds__(kFatThreads, 3) void mlp_fused4_kernel(const MlpFwdParams P)
+{
+    static_assert(kMlpCB == 2 && kFatWaves * 64 == kMlpHid, "four waves of two 32-row blocks, two 32-sample column blocks");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[kTilePlane];
+    __bf16* xt = lds;
+    __bf16* ht = lds + kMlpBM * kXS;
+    float* const scr = reinterpret_cast<float*>(xt);             // the dead input tile: head rows, head gradients, record, loss sums
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int net = blockIdx.y + P.first_net;
+    const long long row0 = (long long)blockIdx.x * kMlpBM;
+    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    const float* bias = P.bias + net * kBiasElems;
+    const int c = lane & 31, h = lane >> 5, rb0 = 2 * w;
+    const auto bias_load = [&](const float* b, f32x4 (&q)[2][4]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[r][k] = *reinterpret_cast<const f32x4*>(b + 32 * (rb0 + r) + 8 * k + 4 * h);
+    };
+    const auto bias16 = [&](const f32x4 (&q)[2][4], int r) {
+        f32x16 b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[4 * k + j] = q[r][k][j];
+        return b;
+    };
+    const auto at = [&](int r, int cb, int q) { return ht + (32 * cb + c) * kHS + 32 * (rb0 + r) + 8 * q + 4 * h; };
+    const auto store_tile = [&](__bf16* dst) { mlp_store_htile_nt<kFatThreads>(ht, dst + (size_t)net * P.B * kMlpHid, row0, P.B, tid); };
+
+    f32x4 bq1[2][4];
+    bias_load(bias, bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    MlpGemm22<kMlpInPad, kXS> g1;
+    g1.prefetch(wp + kOffW1 + rb0 * (kMlpInPad / 16) * 512, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
+
+    // ---- stage 0: the tile's 64 pre-gathered rows (18 KB of contiguous bf16), every load in flight before the first LDS write
+    {
+        constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFatThreads - 1) / kFatThreads;
+        uint4 v[kIt];
+        if (row0 + kMlpBM <= P.B) {
+            const __bf16* base = P.xs_in + row0 * kMlpInPad + tid * 8;
+#pragma unroll
+            for (int i = 0; i < kIt; ++i) {
+                v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < kCh / kFatThreads || tid + kFatThreads * i < kCh) v[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * kFatThreads * 8);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kIt; ++i) {
+                const int ch = tid + kFatThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+                v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (ch < kCh && row0 + row < P.B) v[i] = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int ch = tid + kFatThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
+            if (ch < kCh) *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = v[i];
+        }
+        mlp_barrier();
+    }
+
+    f32x16 acc[2][kMlpCB];
+    bf16x4 h1keep[2][kMlpCB][4];
+    const auto epilogue = [&](bool keep) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x4 pk = tanh_quad(acc[r][cb], q);
+                    *reinterpret_cast<bf16x4*>(at(r, cb, q)) = pk;
+                    if (keep) h1keep[r][cb][q] = pk;
+                }
+    };
+    const auto zero_acc = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][cb][i] = 0.f;
+    };
+
+    // ---- layer 1
+    {
+        const f32x16 b16[2] = {bias16(bq1, 0), bias16(bq1, 1)};
+        g1.run(xt, acc, lane, [] {}, b16);
+    }
+    epilogue(true);
+    f32x4 bq2[2][4];
+    bias_load(bias + kMlpHid, bq2);
+    __builtin_amdgcn_sched_barrier(0);
+    MlpGemm22<kMlpHid, kHS> g2;
+    g2.prefetch(wp + kOffW2 + rb0 * (kMlpHid / 16) * 512, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mlp_barrier();
+
+    // ---- layer 2 (the H1 tile and the record request leave from inside the product)
+    MlpRecordTile<kFatThreads> rect;
+    {
+        const f32x16 b16[2] = {bias16(bq2, 0), bias16(bq2, 1)};
+        g2.run(ht, acc, lane, [&] {
+            const float* const src[5] = {P.rec_actions, P.rec_mean, P.rec_log_std, net == 0 ? P.rec_adv : P.rec_vtarg, net == 0 ? P.rec_logp : P.rec_values};
+            rect.load(src, net, row0, P.B, tid);
+            if (P.h1) store_tile(P.h1);
+        }, b16);
+    }
+    rect.park(scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
+    mlp_barrier();
+    epilogue(false);
+    mlp_barrier();
+
+    // ---- layer 3: head^T [16][samples] with 16x16x32 MFMAs, 16 samples per wave
+    {
+        const int r16 = lane & 15, g = lane >> 4;
+        f32x4 a3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);
+        const __bf16* w3 = wp + kOffW3 + lane * 8;
+        bf16x8 w3f[kMlpHid / 32];
+#pragma unroll
+        for (int ks = 0; ks < kMlpHid / 32; ++ks) w3f[ks] = ld_global_bf16x8(w3 + 512 * ks);
+#pragma unroll
+        for (int ks = 0; ks < kMlpHid / 32; ++ks) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (16 * w + r16) * kHS + 32 * ks + 8 * g);
+            a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks], b, a3, 0, 0, 0);
+        }
+        const long long b = row0 + 16 * w + r16;
+        if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = a3;
+        *reinterpret_cast<f32x4*>(scr + (16 * w + r16) * kMlpHead + 4 * g) = a3;
+    }
+    float* hd = scr;
+    __bf16* gt = reinterpret_cast<__bf16*>(scr) + kMlpBM * kMlpHead * 2;
+    const float* rl = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2;
+    float* wsum = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats;
+    bf16x8 w3t[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) w3t[r] = ld_global_bf16x8(wp + kOffW3T + (rb0 + r) * 512 + lane * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    if (P.h2) store_tile(P.h2);
+    mlp_barrier();
+    // ---- the tile's loss: the eight-wave form's two halves (samples 0-31, 32-63) by the same four waves, one after the other
+    mlp_tile_loss<1>(P, net, row0, tid, hd, gt, rl, wsum, true);
+    mlp_tile_loss<1>(P, net, row0, tid + kFatThreads, hd, gt, rl, wsum, true);
+    mlp_barrier();
+    if (tid == 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kFwdWaves; ++k) t += *reinterpret_cast<const f32x4*>(wsum + 4 * k);
+        float* pr = P.partials + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * 8;
+        *reinterpret_cast<f32x4*>(pr) = t;
+        *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- layer 3's weight-gradient partials of this tile while H2 is in the tile (this wave's 64 feature columns: only it overwrites them)
+    float* w3p = P.w3part ? P.w3part + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * kW3PartFloats : nullptr;
+    if (w3p) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ww = rb0 + r;
+            f32x4 aw3[2], ab3;
+            mlp_tile_w3_products<1>(gt, kGS, ht, kHS, lane, ww, aw3, ab3, kTilePlane, kTilePlane);
+            const int c16 = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w3p[(4 * g + j) * kMlpHid + 32 * ww + 16 * b + c16] = aw3[b][j];
+            if (ww == 0 && c16 == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w3p[kMlpHead * kMlpHid + kMlpHid + 4 * g + j] = ab3[j];
+            }
+        }
+    }
+    // ---- dH2^T = W3^T . G^T, dZ2 in place over H2
+    zero_acc();
+    {
+        bf16x8 b[kMlpCB];
+#pragma unroll
+        for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb) acc[r][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[r], b[cb], acc[r][cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __bf16* a_ = at(r, cb, q);
+                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(a_);
+                *reinterpret_cast<bf16x4*>(a_) = dtanh_quad(acc[r][cb], q, hv);
+            }
+    if (w3p) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int ww = rb0 + r;
+            f32x4 ab2[2];
+            mlp_tile_b2_products<1>(ht, kHS, lane, ww, ab2, kTilePlane);
+            if ((lane >> 4) == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * ww + 16 * b + (lane & 15)] = ab2[b][0];
+            }
+        }
+    }
+    MlpGemm22<kMlpHid, kHS> g4;
+    g4.prefetch(wp + kOffW2T + rb0 * (kMlpHid / 16) * 512, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mlp_barrier();
+
+    // ---- dH1^T = W2^T . dZ2^T (the dZ2 tile leaves from inside the product), dZ1 into the free tile
+    zero_acc();
+    g4.run(ht, acc, lane, [&] { store_tile(P.dz2); });
+    mlp_barrier();
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int cb = 0; cb < kMlpCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(at(r, cb, q)) = dtanh_quad(acc[r][cb], q, h1keep[r][cb][q]);
+    mlp_barrier();
+    store_tile(P.dz1);
+}
+#endif   // PNR_MLP_FAT
+
+// ---------------------------------------------------------------------------------------------------------------
 // The fused training tile, WEIGHT-STATIONARY (r03f): grid (G, nets), 512 threads, ONE workgroup per CU that walks the tiles
 // g, g + G, .. of its net.  mlp_forward_kernel<true> streams a tile's 344 KB of weight fragments from L2 while it multiplies
 // (1 KiB per wave and k-step for two MFMAs: the products ran at 1/6 of their MFMA time, paced by those loads — 42 B/clk/CU,

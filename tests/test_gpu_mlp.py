@@ -281,7 +281,7 @@ def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
     """pnr_mlp_gather + train_step(xs_in=...) against train_step(obs, idx, filt): the same filter arithmetic and rounding,
     the same record rows, so gradients, loss means and updated weights are bit-identical — on a minibatch that is a slice
     of a longer gathered epoch (pointer offsets into the gathered arrays).  In the PNR_MLP_STATIONARY=1 variant
-    (test_weight_stationary_training_kernel_is_bit_identical runs this test on it) the two calls also run two different
+    (test_alternative_forms_of_the_fused_kernel_are_bit_identical runs this test on it) the two calls also run two different
     kernels: mlp_forward_kernel<true> (one workgroup per tile, weights streamed) and mlp_train_kernel (one workgroup per CU
     walking its tiles — one, a partial last one, or up to three of them at these sizes — with its weights in registers)."""
     import copy
@@ -325,17 +325,19 @@ def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
         assert torch.equal(a, b)
 
 
-def test_weight_stationary_training_kernel_is_bit_identical(tmp_path):
-    """mlp_train_kernel — the weight-stationary, half-tile-pipelined form of the fused learner kernel, kept behind
-    -DPNR_MLP_STATIONARY=1 as the measured alternative (58 us against 51) — produces the same bits as
-    mlp_forward_kernel<true>: the learner translation unit is rebuilt with the switch (seconds) and the comparison above,
-    whose pre-gathered calls then run mlp_train_kernel, is run on that library in a child process."""
+@pytest.mark.parametrize("switch", ["-DPNR_MLP_STATIONARY=1", "-DPNR_MLP_FAT=1"])
+def test_alternative_forms_of_the_fused_kernel_are_bit_identical(tmp_path, switch):
+    """The measured alternatives of the fused learner kernel that stay in the tree behind a build switch — mlp_train_kernel
+    (-DPNR_MLP_STATIONARY=1: weight-stationary, half-tile-pipelined; r03f: 58 us against 51) and mlp_fused4_kernel (-DPNR_MLP_FAT=1: four
+    64-row waves per tile, three tiles per CU; r04: 64.9 us against 49.8) — produce the same bits as mlp_forward_kernel<true>: the
+    learner translation unit is rebuilt with the switch and the comparison above, whose pre-gathered calls then run the
+    alternative, is run on that library in a child process."""
     import os
     import subprocess
     import sys
     from pioneer_amd import _lib
-    out = str(tmp_path / "libpioneer_amd_stationary.so")
-    _lib.build_library(units=("pnr_learn.hip",), extra_flags=["-DPNR_MLP_STATIONARY=1"], out_path=out)
+    out = str(tmp_path / "libpioneer_amd_variant.so")
+    _lib.build_library(units=("pnr_learn.hip",), extra_flags=[switch], out_path=out)
     env = dict(os.environ, PNR_LIB_PATH=out)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_mlp.py"), "-q", "-x", "-m", "gpu", "-k",
