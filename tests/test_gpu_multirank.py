@@ -106,7 +106,8 @@ R = lambda *s: torch.randn(*s, generator=g, device=dev)
 act, mean, log_std = R(B, 6), 0.1 * R(B, 6), 0.1 * R(B, 6)
 batch = {"obs": R(B, 137), "actions": act, "mean": mean, "log_std": log_std, "logp": gaussian_logp(act, mean, log_std) + 0.2 * R(B),
          "values": R(B), "adv": R(B), "vtarg": R(B)}
-cfg = PPOConfig(num_sgd_iter=3, sgd_minibatch_size=B // 2, lr=1e-3, seed=11)
+prec = os.environ.get("PNR_TEST_PRECISION", "bf16")
+cfg = PPOConfig(num_sgd_iter=3, sgd_minibatch_size=B // 2, lr=1e-3, seed=11, hip_kernels=True if prec == "bf16" else prec)
 out = {}
 for chains in (True, False):
     L = PPOLearner(cfg, dev)
@@ -130,15 +131,16 @@ dist.destroy_process_group()
 '''
 
 
-def test_hip_learner_keeps_two_ranks_in_lock_step(tmp_path):
-    """Several ranks on the kernels: every update's gradient is all-reduced before Adam, so master weights, Adam's moments and
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_hip_learner_keeps_two_ranks_in_lock_step(tmp_path, precision):
+    """(bf16 operands, and the float32-accurate three-plane form: PPOConfig(hip_kernels="f32").)  Several ranks on the kernels: every update's gradient is all-reduced before Adam, so master weights, Adam's moments and
     the reported (rank-averaged) losses are identical on both ranks although each rank trains on its own share of the batch —
     and the two-chain form (each net on its own stream with its own all-reduce, what a multi-GPU run uses) leaves exactly the
     weights and moments of the serial one-bucket form."""
     script = tmp_path / "learner.py"
     script.write_text(LEARNER_WORKER)
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    env = dict(os.environ, PNR_ROOT=ROOT, PNR_OUT=str(tmp_path), OMP_NUM_THREADS="2")
+    env = dict(os.environ, PNR_ROOT=ROOT, PNR_OUT=str(tmp_path), OMP_NUM_THREADS="2", PNR_TEST_PRECISION=precision)
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=600)
