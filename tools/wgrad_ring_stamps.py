@@ -21,12 +21,19 @@ raw = C.CDLL(_lib.LIB_PATH)
 if not hasattr(raw, "pnr_mlp_set_wgrad_stamp_buffer"):
     sys.exit("this library was not built with -DPNR_MLP_STAMPS=1")
 torch.manual_seed(0)
-mlp = HipMLP(ActorCritic(PPOConfig()).to(dev), B, dev)
+PLANES = int(os.environ.get("PLANES", "1"))      # 1: bf16 operands; 2, 3: split float32 operands
+mlp = HipMLP(ActorCritic(PPOConfig()).to(dev), B, dev, planes=PLANES)
 mlp.pack()
 R = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
 act, mean, ls = R(B, 6), 0.1 * R(B, 6), 0.1 * R(B, 6)
 rec = {"actions": act, "mean": mean, "log_std": ls, "logp": gaussian_logp(act, mean, ls), "values": R(B), "adv": R(B), "vtarg": R(B)}
-xs = R(B, 144).bfloat16().contiguous()
+x32 = R(B, 144)
+x32[:, 137:] = 0
+planes_of_x = []
+for _ in range(PLANES):
+    planes_of_x.append(x32.bfloat16())
+    x32 = x32 - planes_of_x[-1].float()
+xs = planes_of_x[0].contiguous() if PLANES == 1 else torch.stack(planes_of_x).contiguous()
 klc, entc, means = torch.tensor(0.2, device=dev), torch.tensor(0.01, device=dev), torch.zeros(8, device=dev)
 st = torch.zeros((2, 4, 32, 8, 26), dtype=torch.int64, device=dev)
 raw.pnr_mlp_set_wgrad_stamp_buffer(C.c_void_p(st.data_ptr()))
