@@ -17,10 +17,10 @@ from pioneer_amd import _lib  # noqa: E402
 from pioneer_amd.mlp import HipMLP  # noqa: E402
 from pioneer_amd.ppo import ActorCritic, PPOConfig, gaussian_logp  # noqa: E402
 
-NAMES = ["prefetch W1", "stage 0 (tile copy, barriers)", "layer-1 product", "layer-1 epilogue (tanh)", "barrier", "H1 store issue",
-         "layer-2 product", "barrier", "layer-2 epilogue (tanh)", "W3 fetch + barrier", "H2 store issue", "head product", "W3T fetch + barrier",
-         "loss (wave 0)", "barrier after loss", "dH2 product + epilogue", "W2T prefetch + barrier", "dZ2 store + W2T product",
-         "vmcnt(0) + H1 reload request", "barrier", "H1 into tile + barrier", "dZ1 epilogue", "barrier + dZ1 store issue"]
+NAMES = ["prefetch W1", "stage 0 (tile copy, barriers)", "layer-1 product", "layer-1 epilogue (tanh)", "barrier", "(unused slot)",
+         "layer-2 product", "barrier", "layer-2 epilogue (tanh)", "barrier", "(unused slot)", "head product", "W3T fetch + barrier",
+         "loss (all waves)", "barrier after loss", "layer-3 partial products + dH2 product + epilogue", "W2T prefetch + barrier", "dZ2 store + W2T product",
+         "(unused slot)", "barrier", "(unused slot)", "dZ1 epilogue", "barrier + dZ1 store issue"]
 
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
 dev = torch.device("cuda", 0)
