@@ -253,6 +253,7 @@ static void fill_base(pnr_handle h)
     P.penalty = (float)c.penalty_step;
     P.award_done = (float)c.award_done;
     P.done_dist = (float)c.done_distance;
+    P.done_dist_d = c.done_distance;
 }
 
 int pnr_create(const pnr_config* cfg, int64_t num_envs, int64_t env_id_offset, int device_id,

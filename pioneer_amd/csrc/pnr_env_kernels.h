@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kWave * kStepWaves) void step_kernel(float4* __rest
         // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
         const float old_pot = s.pot;
         const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
-        const bool done = q.dist < P.done_dist;                       // :160
+        const bool done = done_predicate(s, p, q.dist, P.done_dist, P.done_dist_d);   // :160
         const float r_pot = pot - old_pot;
         const float r_step = -P.penalty;
         const float r_done = done ? P.award_done : 0.0f;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void dyn_finish_tile(const KParams& P, const DynParam
     // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
     const float old_pot = s.pot;
     const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
-    const bool done = q.dist < P.done_dist;                       // :160
+    const bool done = done_predicate(o, p, q.dist, P.done_dist, P.done_dist_d);   // :160
     const float r_pot = pot - old_pot;
     const float r_step = -P.penalty;
     const float r_done = done ? P.award_done : 0.0f;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void dyn_rollout_tile(const KParams& P, const DynPara
     // -- reward block, pioneer_knm_env.py:157-165 (both lanes, identical) ----------
     const float old_pot = s.pot;
     const float pot = P.pot_m / (q.dist / P.pot_s + 1.0f);        // :232-236
-    const bool done = q.dist < P.done_dist;                       // :160
+    const bool done = done_predicate(o, p, q.dist, P.done_dist, P.done_dist_d);   // :160
     const float r_pot = pot - old_pot;
     const float r_step = -P.penalty;
     const float r_done = done ? P.award_done : 0.0f;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
             // reward block, pioneer_knm_env.py:157-165 (both lanes, identical)
             const float old_pot = s.pot;
             const float pot = S.K.pot_m / (q.dist / S.K.pot_s + 1.0f);
-            const bool done = q.dist < S.K.done_dist;
+            const bool done = done_predicate(s, p, q.dist, S.K.done_dist, S.K.done_dist_d);
             const float r_pot = pot - old_pot;
             const float r_step = -S.K.penalty;
             const float r_done = done ? S.K.award_done : 0.0f;
