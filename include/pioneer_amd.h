@@ -404,8 +404,12 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
  * [pnr_mlp_grad_floats()] floats each.  wpack / bias must hold the CURRENT weights on entry (pnr_mlp_pack once, then
  * every update refreshes them).  All pointers are device pointers; `means` receives (policy_loss, vf_loss, kl,
  * entropy, total, 0, 0, 0).  partials: scratch of partial_rows >= 2 * ceil(batch / 64) rows of 8 floats; `head` is not
- * written (the head rows never leave the chip); g_head [2][batch][16] is.  wpack, bias, adam_m, adam_v, slabs and flat_grad
- * must be 16-byte aligned (PNR_ERR_INVALID otherwise: the optimiser kernel moves them four floats at a time).
+ * written (the head rows never leave the chip); g_head [2][batch][16] is written ONLY when w3_partials is NULL (with
+ * w3_partials nothing outside the tile reads the head gradients, they stay on the chip, g_head is left as it was and may be
+ * NULL).  wpack, bias, adam_m, adam_v, slabs and flat_grad must be 16-byte aligned (PNR_ERR_INVALID otherwise: the optimiser
+ * kernel moves them four floats at a time); so must xs_in, and with planes > 1 xs_in_plane must be 0 or a multiple of 8
+ * elements >= batch * 144 (the kernels read 16-byte vectors at xs_in + plane * xs_in_plane).  Every argument is checked
+ * before the first launch: an error return has launched nothing and counted no update.
  */
 typedef struct pnr_mlp_step {
     uint32_t struct_size;   /* sizeof(pnr_mlp_step) */
@@ -472,6 +476,12 @@ int64_t pnr_num_envs(pnr_handle h);
 const char* pnr_last_error(pnr_handle h);
 
 int pnr_abi_version(void);
+
+/* What this binary was built from: "api=<sha16>;learn=<sha16>;" — per translation unit, the first 16 hex digits of sha256 over
+ * the compile flags, the unit's source files and this header, baked in at compile time (-DPNR_UNIT_FINGERPRINT).  The Python
+ * loader (pioneer_amd/_lib.py load_library) recomputes it from the tree and refuses a library that differs; bench.py prints
+ * it next to the fingerprints of the committed counter passes.  (No reference counterpart: build hygiene.) */
+const char* pnr_build_fingerprint(void);
 
 #ifdef __cplusplus
 }

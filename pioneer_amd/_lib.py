@@ -122,6 +122,7 @@ class PnrMlpStep(C.Structure):
 _VP = C.c_void_p
 SIGNATURES = {
     "pnr_abi_version": (C.c_int, []),
+    "pnr_build_fingerprint": (C.c_char_p, []),
     "pnr_config_default": (C.c_int, [C.POINTER(PnrConfig)]),
     "pnr_get_constants": (C.c_int, [C.POINTER(PnrConfig), C.POINTER(PnrConstants)]),
     "pnr_create": (C.c_int, [C.POINTER(PnrConfig), C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.POINTER(_VP)]),
@@ -190,28 +191,57 @@ def source_fingerprint(files=ENV_KERNEL_SOURCES) -> str:
     return h.hexdigest()[:16]
 
 
+UNIT_TAGS = {"pnr_api.hip": "api", "pnr_learn.hip": "learn"}       # the names the units stamp themselves with (g_unit_fp)
+
+
+def unit_fingerprint(unit: str, extra_flags=()) -> str:
+    """What a unit's object must have been built from: the compile flags, its own files, the C-ABI header."""
+    import hashlib
+    h = hashlib.sha256(" ".join([*HIPCC_FLAGS, *extra_flags]).encode())
+    for f in UNITS[unit]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    with open(HEADER, "rb") as fh:
+        h.update(b"pioneer_amd.h\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def tree_fingerprint(extra_flags=()) -> str:
+    """The string pnr_build_fingerprint() of a library built from THIS tree returns."""
+    return "".join(f"{UNIT_TAGS[u]}={unit_fingerprint(u, extra_flags)};" for u in UNITS)
+
+
+def embedded_fingerprints(path: str) -> dict:
+    """The pnr_build_fp tags inside an object or library file ({} if there are none): read from the bytes, nothing is loaded."""
+    import re
+    if not os.path.exists(path):
+        return {}
+    with open(path, "rb") as f:
+        blob = f.read()
+    return {m.group(1).decode(): m.group(2).decode() for m in re.finditer(rb"pnr_build_fp:([a-z]+)=([0-9a-f]{16});", blob)}
+
+
 def _obj_path(unit: str, tag: str = "") -> str:
     return os.path.join(CSRC, os.path.splitext(unit)[0] + tag + ".o")
 
 
-def _newer(deps, target) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+def _unit_stale(unit: str, obj: str, extra_flags=()) -> bool:
+    return embedded_fingerprints(obj).get(UNIT_TAGS[unit]) != unit_fingerprint(unit, extra_flags)
 
 
 def _stale() -> bool:
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
-    return _newer(deps, LIB_PATH)
+    """The in-tree library is stale unless every unit inside it carries the fingerprint of the tree's sources (content, not mtime)."""
+    have = embedded_fingerprints(LIB_PATH)
+    return any(have.get(UNIT_TAGS[u]) != unit_fingerprint(u) for u in UNITS)
 
 
 def build_library(force: bool = False, verbose: bool = False, extra_flags=(), out_path: str = None, units=None) -> str:
     """hipcc --offload-arch=gfx950 -> pioneer_amd/csrc/libpioneer_amd.so (in-tree): the two translation units are compiled in
-    parallel (only those whose sources changed) and linked.  extra_flags / out_path build a variant next to it (e.g.
-    -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B, -DPNR_DIAG_BUILD=1 for the timing-only ablations), with objects of its own;
-    `units` names the translation units the flags concern (e.g. ("pnr_learn.hip",) for an MLP kernel A/B: seconds instead of
-    minutes) — the others are linked from the default build's objects."""
+    parallel (only those whose object does not carry the fingerprint of the current sources) and linked.  extra_flags / out_path
+    build a variant next to it (e.g. -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B, -DPNR_DIAG_BUILD=1 for the timing-only
+    ablations), with objects of its own; `units` names the translation units the flags concern (e.g. ("pnr_learn.hip",) for an
+    MLP kernel A/B) — the others are linked from the default build's objects.  A full forced build takes ~90 s on 8 cores
+    (pnr_learn.hip: 85 s, pnr_api.hip: 60 s, in parallel)."""
     variant = out_path is not None or bool(extra_flags)
     if variant:
         force = True
@@ -228,15 +258,17 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     for unit, deps in UNITS.items():
         if variant and units is not None and unit not in units:
             objs.append(_obj_path(unit))                 # the default build's object (build_library() must have run)
-            if not os.path.exists(objs[-1]):
-                raise RuntimeError(f"{objs[-1]} is missing: build the default library first")
+            if _unit_stale(unit, objs[-1]):
+                raise RuntimeError(f"{objs[-1]} is missing or not built from the current sources: build the default library first")
             continue
         obj = _obj_path(unit, tag)
         objs.append(obj)
         own.append(obj)
-        if not force and not _newer([os.path.join(CSRC, d) for d in deps] + [HEADER], obj):
+        flags = list(extra_flags) if (variant and (units is None or unit in units)) else []
+        if not force and not _unit_stale(unit, obj, flags):
             continue
-        cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-c", "-o", obj, os.path.join(CSRC, unit)]
+        cmd = [hipcc, *HIPCC_FLAGS, *flags, f'-DPNR_UNIT_FINGERPRINT="{unit_fingerprint(unit, flags)}"', "-c", "-o", obj,
+               os.path.join(CSRC, unit)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
@@ -280,6 +312,12 @@ def load_library():
         fn.argtypes = args
     if lib.pnr_abi_version() != ABI_VERSION:
         raise ImportError(f"libpioneer_amd.so reports ABI {lib.pnr_abi_version()}, include/pioneer_amd.h says {ABI_VERSION}; rebuild")
+    # the binary must be the one these sources build (content fingerprints baked in at compile time, not file times); a library
+    # named explicitly through PNR_LIB_PATH is somebody's A/B variant with flags of its own and is taken as it is
+    built, tree = lib.pnr_build_fingerprint().decode(), tree_fingerprint()
+    if built != tree and not os.environ.get("PNR_LIB_PATH"):
+        raise ImportError(f"{LIB_PATH} was built from other sources (binary {built}, tree {tree}): rebuild it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
 

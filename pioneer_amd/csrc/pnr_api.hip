@@ -82,9 +82,18 @@ static int fail(pnr_handle h, int code, const char* fmt, ...)
 }
 
 
+static const char g_unit_fp[] = "pnr_build_fp:api=" PNR_UNIT_FINGERPRINT ";";
+
 extern "C" {
 
 int pnr_abi_version(void) { return PNR_ABI_VERSION; }
+
+const char* pnr_build_fingerprint(void)
+{
+    static char buf[96] = "";
+    if (!buf[0]) snprintf(buf, sizeof(buf), "%s%s", g_unit_fp + 13, pnr_unit_fingerprint_learn() + 13);   // past "pnr_build_fp:"
+    return buf;
+}
 
 int pnr_config_default(pnr_config* c)
 {

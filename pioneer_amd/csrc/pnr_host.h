@@ -8,6 +8,14 @@
 
 #include "../../include/pioneer_amd.h"
 
+// Build identity (pioneer_amd/_lib.py): every translation unit is compiled with -DPNR_UNIT_FINGERPRINT="<sha16>" — sha256 over the
+// compile flags, the unit's own files and include/pioneer_amd.h — and keeps it as a tagged string, so that the loader can refuse a
+// binary that was not built from the sources lying next to it (the tag is also what _lib.py scans objects and the .so for).
+#ifndef PNR_UNIT_FINGERPRINT
+#define PNR_UNIT_FINGERPRINT "unstamped"
+#endif
+extern "C" __attribute__((visibility("hidden"))) const char* pnr_unit_fingerprint_learn(void);
+
 // writes the message into the handle's buffer (or the thread's, for handle-less calls) and returns `code`
 __attribute__((visibility("hidden"))) int pnr_failv(char* handle_err, int code, const char* fmt, va_list ap);
 

@@ -28,6 +28,9 @@ static int fail(pnr_handle, int code, const char* fmt, ...)
     return rc;
 }
 
+static const char g_unit_fp[] = "pnr_build_fp:learn=" PNR_UNIT_FINGERPRINT ";";
+extern "C" const char* pnr_unit_fingerprint_learn(void) { return g_unit_fp; }
+
 #if PNR_MLP_STAMPS
 // diagnostic variant only (tools/mlp_stamps.py): where the fused kernel's waves write their phase stamps
 static unsigned long long* g_mlp_stamps = nullptr;
@@ -404,8 +407,8 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     if (rc) return rc;
     const long long B = s->batch;
     if (B < 1 || (!s->obs && !s->xs_in) || !s->actions || !s->logp_old || !s->mean_old || !s->log_std_old || !s->adv || !s->value_target ||
-        !s->value_old || !s->kl_coeff || !s->entropy_coeff || !s->head || !s->g_head || !s->xs || !s->h1 || !s->h2 || !s->dz1 ||
-        !s->dz2 || !s->partials || !s->slabs || !s->means)
+        !s->value_old || !s->kl_coeff || !s->entropy_coeff || !s->head || (!s->g_head && !s->w3_partials) || !s->xs || !s->h1 || !s->h2 ||
+        !s->dz1 || !s->dz2 || !s->partials || !s->slabs || !s->means)
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: null argument or empty batch");
     if ((s->f_loc || s->f_inv || s->f_lo || s->f_hi) && !(s->f_loc && s->f_inv && s->f_lo && s->f_hi))
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: the four filter vectors come together or not at all");
@@ -420,6 +423,13 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     const int planes = s->planes > 1 ? s->planes : 1;
     if (planes > 1 && (!s->w3_partials || !s->xs_in))
         return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: split operands (planes %d) need w3_partials and the pre-gathered input planes (xs_in, pnr_mlp_gather)", planes);
+    if (planes > kMlpMaxPlanes) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: planes %d (1, 2 or 3)", planes);
+    // the kernels read the pre-gathered rows as 16-byte vectors at xs_in + plane * xs_in_plane: checked before anything is launched
+    if (s->xs_in && (reinterpret_cast<uintptr_t>(s->xs_in) & 15))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: xs_in must be 16-byte aligned");
+    if (planes > 1 && s->xs_in_plane != 0 && (s->xs_in_plane % 8 != 0 || s->xs_in_plane < B * kMlpInPad))
+        return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: xs_in_plane %lld: a multiple of 8 elements, at least batch * 144 = %lld (or 0: exactly that)",
+                    (long long)s->xs_in_plane, B * kMlpInPad);
     const dim3 tiles((unsigned)((B + kMlpBM - 1) / kMlpBM), nets);
     const long long prow = (long long)tiles.x * nets;           // one row of loss sums per workgroup of the fused kernel
     if (s->partial_rows < prow)
@@ -442,10 +452,8 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
     F.act_plane = (size_t)kMlpNets * (size_t)B * kMlpHid;            // planes of h1 / dz1 / dz2: [planes][2][B][256]
     F.xs_plane = s->xs_in_plane > 0 ? (size_t)s->xs_in_plane : (size_t)B * kMlpInPad;
-    // layer 3's weight gradients per tile from the fused kernel (then H2 never leaves the CU) when the caller gave the scratch for it;
-    // the weight-stationary variant of the fused kernel stores H2 as before (the two forms give the same bits)
-    const bool stationary = F.xs_in && kTrainStationary && planes == 1;
-    if (s->w3_partials && !stationary) {
+    // layer 3's weight gradients per tile from the fused kernel (then H2 never leaves the CU) when the caller gave the scratch for it
+    if (s->w3_partials) {
         if (s->w3_partial_floats < (long long)tiles.x * nets * kW3PartFloats)
             return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_train_step: w3_partials hold %lld floats, the launch needs %lld",
                         (long long)s->w3_partial_floats, (long long)tiles.x * nets * kW3PartFloats);
@@ -456,30 +464,9 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
 #if PNR_MLP_STAMPS
     F.stamps = g_mlp_stamps;
 #endif
-    if (stationary) {
-        // contiguous inputs: the weight-stationary form, one workgroup per CU and net walking the tiles
-        static int cus = 0;                                      // (every GPU of a node is the same part)
-        if (!cus) {
-            int dev = 0, n = 0;
-            HIP_TRY(nullptr, hipGetDevice(&dev));
-            HIP_TRY(nullptr, hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-            cus = n;
-        }
-        const unsigned per_net = (unsigned)std::max(1, cus / kMlpNets);
-        hipLaunchKernelGGL(mlp_train_kernel, dim3(std::min(tiles.x, per_net), nets), dim3(kFwdThreads), 0, st, F);
-#if PNR_MLP_FAT
-    } else if (planes == 1 && F.xs_in) {
-        hipLaunchKernelGGL(mlp_fused4_kernel, tiles, dim3(kFatThreads), 0, st, F);       // four 64-row waves per tile, three tiles per CU (A/B r04 g)
-#endif
-    } else if (planes == 1) {
-        // both nets of a tile in one workgroup (input tile staged once; every workgroup resident from the start) when both are asked for
-        F.paired = PNR_MLP_PAIRED && nets == 2;
-        hipLaunchKernelGGL((mlp_forward_kernel<true, 1>), F.paired ? dim3(tiles.x, 1) : tiles, dim3(kFwdThreads), 0, st, F);
-    } else if (planes == 2) {
-        hipLaunchKernelGGL((mlp_forward_kernel<true, 2>), tiles, dim3(kFwdThreads), 0, st, F);
-    } else {
-        hipLaunchKernelGGL((mlp_forward_kernel<true, 3>), tiles, dim3(kFwdThreads), 0, st, F);
-    }
+    if (planes == 1) hipLaunchKernelGGL((mlp_forward_kernel<true, 1>), tiles, dim3(kFwdThreads), 0, st, F);
+    else if (planes == 2) hipLaunchKernelGGL((mlp_forward_kernel<true, 2>), tiles, dim3(kFwdThreads), 0, st, F);
+    else hipLaunchKernelGGL((mlp_forward_kernel<true, 3>), tiles, dim3(kFwdThreads), 0, st, F);
     if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
         hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
                            s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
@@ -491,7 +478,6 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     Wp.stamps = g_wg_stamps;
 #endif
     Wp.act_plane = F.act_plane; Wp.xs_plane = F.xs_plane;
-    if (planes > 1 && !PNR_WG_GLDS) return fail(nullptr, PNR_ERR_UNSUPPORTED, "pnr_mlp_train_step: this build's weight-gradient kernel is bf16-only");
     const dim3 wgrid((unsigned)slices, kWgParts, nets);
     if (planes == 1) hipLaunchKernelGGL(mlp_wgrad_kernel<1>, wgrid, dim3(kWgThreads), 0, st, Wp);
     else if (planes == 2) hipLaunchKernelGGL(mlp_wgrad_kernel<2>, wgrid, dim3(kWgThreads), 0, st, Wp);

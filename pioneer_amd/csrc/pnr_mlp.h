@@ -58,31 +58,8 @@ static_assert(kMlpBM == 64 || kMlpBM == 128, "tile heights 64 and 128 are implem
 #ifndef PNR_MLP_DIAG
 #define PNR_MLP_DIAG 0
 #endif
-#ifndef PNR_MLP_W3_LDS
-#define PNR_MLP_W3_LDS 0          // 1: the fused kernel (bf16 operands) keeps W3 in LDS for its head product.  A/B r04: 51.2 vs 50.6 us, train_step 84.1 vs 84.2 — no gain
-                                  // (the co-resident workgroup fills the head phase's L2 round trip anyway), so the fragments keep coming from L2 and LDS stays 53 KB
-#endif
-#ifndef PNR_MLP_PAIRED
-#define PNR_MLP_PAIRED 0           // 1: fused kernel (bf16): ONE workgroup takes a tile through BOTH nets (input tile staged once: stage 0 is 3 900 of a unit's
-                                  // 34 000 cycles; 512 resident workgroups instead of two rounds).  A/B r04 g: bit-identical, SLOWER — 54.5 vs 50.1 us, train_step
-                                  // 86.6 vs 82.2: the back edge costs the schedule more (106 SGPRs, spills) than the second stage 0 was worth
-#endif
 #ifndef PNR_MLP_LDS_PAD
 #define PNR_MLP_LDS_PAD 0          // bf16 elements of unused LDS in the fused kernel: 20000 leaves ONE workgroup per CU (occupancy probe, tools/stamps.sh)
-#endif
-#ifndef PNR_MLP_PRIO
-#define PNR_MLP_PRIO 0             // fused kernel (bf16): bit k set = the k-th group of 256 workgroups (dispatch order) runs at wave priority 1 (A/B r04 g)
-#endif
-#ifndef PNR_MLP_DEPHASE
-#define PNR_MLP_DEPHASE 0         // > 0: the fused kernel's second workgroup per CU starts this many x 64 cycles late (A/B r04)
-#endif
-#ifndef PNR_MLP_STATIONARY
-#define PNR_MLP_STATIONARY 0      // 1: pnr_mlp_train_step on contiguous inputs runs mlp_train_kernel (weight-stationary; r03f A/B: bit-identical, 58 us
-                                  // against mlp_forward_kernel<true>'s 51 us per 32 768-sample update — kept as the measured alternative)
-#endif
-constexpr bool kTrainStationary = PNR_MLP_STATIONARY != 0;
-#ifndef PNR_MLP_TRAIN_LOOKAHEAD
-#define PNR_MLP_TRAIN_LOOKAHEAD 1     // k-steps between a sample fragment's LDS read and its MFMA in mlp_train_kernel (3: no faster, r03f)
 #endif
 constexpr int kMlpThreads = 256;  // four waves
 // PNR_MLP_STAMPS=1 (a diagnostic variant, tools/mlp_stamps.py): every wave of the fused kernel writes s_memtime at its phase
@@ -286,20 +263,10 @@ __device__ __forceinline__ bf16x8 ld_global_bf16x8(const __bf16* p) { return *re
 // Workgroup rendezvous for hand-offs that go through LDS only (every tile exchange in these kernels): the wave's DS operations
 // have completed (lgkmcnt), then s_barrier.  __syncthreads() additionally waits for vmcnt(0), i.e. for every global store
 // and prefetched weight fragment still in flight — each barrier then costs a write acknowledgement from HBM (the tile stores of
-// h1 / h2 / dz2 / dz1) or an L2 round trip (the next product's first weight fragments).  PNR_MLP_LDS_BARRIER=0 restores it (A/B).
-#ifndef PNR_MLP_SCHED_PIN
-#define PNR_MLP_SCHED_PIN 0       // 1: pin every k-step's [fragment loads][LDS reads][MFMAs] order (A/B r03: no gain in the fused kernel, +20 % time in the sampler's forward)
-#endif
-#ifndef PNR_MLP_LDS_BARRIER
-#define PNR_MLP_LDS_BARRIER 1
-#endif
+// h1 / h2 / dz2 / dz1) or an L2 round trip (the next product's first weight fragments).
 __device__ __forceinline__ void mlp_barrier()
 {
-#if PNR_MLP_LDS_BARRIER
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
 }
 
 // acc[rb][cb] += W[64 rows of this wave][K] . tile[BM samples][K]^T.  W: fragment-native packing (global, L2);
@@ -350,14 +317,6 @@ struct MlpGemm {
 #pragma unroll
                 for (int cb = 0; cb < kMlpCB; ++cb)
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][rb], b[cb], acc[rb][cb], 0, 0, 0);
-#if PNR_MLP_SCHED_PIN
-            // pin the k-step's shape in the emitted code: [the two fragment loads for k-step ks + D - 1] [this k-step's
-            // LDS reads] [its MFMAs].  Left to itself hipcc sinks the fragment loads next to their use (some directly in
-            // front of an s_waitcnt vmcnt(0)), which exposes an L2 round trip inside every product.
-            if (ks + D - 1 < KS) __builtin_amdgcn_sched_group_barrier(0x20, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, kMlpCB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x8, 2 * kMlpCB, 0);
-#endif
         }
     }
 };
@@ -379,48 +338,6 @@ __device__ __forceinline__ void mlp_zero_acc(f32x16 (&acc)[2][kMlpCB])
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 }
-
-// the accumulators START at the bias (row = output feature, the same for every column / sample): the bias loads then
-// travel together with the first weight fragments of the product, instead of costing the epilogue a round trip of its own
-__device__ __forceinline__ void mlp_bias_acc(f32x16 (&acc)[2][kMlpCB], const float* __restrict__ b, int w, int h)
-{
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 bq = *reinterpret_cast<const f32x4*>(b + 64 * w + 32 * rb + 8 * q + 4 * h);
-#pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[rb][cb][4 * q + j] = bq[j];
-        }
-}
-
-// The same in two steps: the eight 16-byte bias loads of a wave are REQUESTED early — in front of the product's weight-fragment
-// prefetch, so that they are the older operations (vector-memory results return in order: asked for behind the fragments, as
-// the accumulators' initial values, each bias load made the compiler wait for vmcnt(0), draining the prefetch ring inside the
-// product) — and consumed when the accumulators are initialised.
-struct MlpBias {
-    f32x4 q[2][4];
-    __device__ __forceinline__ void load(const float* __restrict__ b, int w, int h)
-    {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[rb][k] = *reinterpret_cast<const f32x4*>(b + 64 * w + 32 * rb + 8 * k + 4 * h);
-    }
-    __device__ __forceinline__ void init(f32x16 (&acc)[2][kMlpCB]) const
-    {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int cb = 0; cb < kMlpCB; ++cb)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[rb][cb][4 * k + j] = q[rb][k][j];
-    }
-};
 
 // The tile's share of the rollout record, FUSED kernel, contiguous rows (no idx): requested early by all 256 threads as 16-byte
 // pieces (policy net: actions | mean | log_std [64][6], adv, logp [64]; value net: vtarg, values [64]), parked in the dead input
@@ -512,7 +429,6 @@ struct MlpFwdParams {
     __bf16* h2;                // [2][B][256]
     long long B;
     int first_net, n_nets;     // blockIdx.y + first_net = net
-    int paired;                // FUSED, bf16 operands, n_nets == 2: grid (tiles, 1), the workgroup runs net 0 then net 1 of its tile
     // the sampler's action draw, fused into the layer-3 epilogue (all null in the learner): a = mean + exp(log_std) * noise
     // with log_std = clamp(raw, -20, 2) (RLlib DiagGaussian's sample(); SquashedGaussian is not the reference's choice),
     // the env's action = clamp(a, -a_max, a_max) when a_max is given (RLlib clip_actions, the reference's default)
@@ -612,59 +528,6 @@ struct MlpGemm1 {
                 for (int cb = 0; cb < kMlpCB; ++cb)
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb],
                                                                       (ks == 0 && pi == 0 && init) ? *init : acc[cb], 0, 0, 0);
-        }
-    }
-};
-
-// The product of the 4 (row groups) x 2 (sample halves) wave layout: acc[j] += W[row block rb0 + j][K] . tile[32 samples of column
-// block cbk][K]^T, j = 0, 1.  ONE sample-fragment read per k-step serves both MFMAs (the 8 x 1 layout of MlpGemm1 reads two for its
-// two), at the price of every weight fragment being requested by two waves.  Timing-only ablation of the 8 x 1 layout with one read
-// serving both of its MFMAs: fused kernel 49.0 -> 42.1 us (profiles/r04_e_fused_timing_only_ablations_kernel_stats.txt).
-#ifndef PNR_MLP_WAVE_LAYOUT
-#define PNR_MLP_WAVE_LAYOUT 0     // bf16 fused kernel: 0 = 8 row blocks x whole tile (r03); 1 = 4 row groups x 2 sample halves — built, bit-identical, SLOWER (r04 A/B:
-                                  // fused kernel 57.5 vs 52.1 us, train_step 92.3 vs 85.7): the doubled weight stream costs more than the halved LDS reads save
-#endif
-#ifndef PNR_MLP_RING2
-#define PNR_MLP_RING2 4           // prefetch ring depth of the 4 x 2 layout (two fragments per k-step: 8 registers per slot)
-#endif
-template <int K, int STRIDE>
-struct MlpGemm2R {
-    static constexpr int KS = K / 16;
-    static constexpr int D = PNR_MLP_RING2;
-    bf16x8 a[D][2];
-    const __bf16* wa;
-    // w_blocks: the first of this wave's two row blocks in the fragment-native packing: block (rb, ks) at (rb KS + ks) * 512
-    __device__ __forceinline__ void prefetch(const __bf16* __restrict__ w_blocks, int lane)
-    {
-        wa = w_blocks + lane * 8;
-#pragma unroll
-        for (int p = 0; p < D - 1; ++p)
-            if (p < KS) {
-                a[p][0] = ld_global_bf16x8(wa + 512 * p);
-                a[p][1] = ld_global_bf16x8(wa + 512 * (KS + p));
-            }
-    }
-    // init: [2] what the two accumulators start from (this wave's bias rows), as the first MFMAs' C operands; or null
-    template <class F>
-    __device__ __forceinline__ void run(const __bf16* tile, int cbk, f32x16 (&acc)[2], int lane, F&& after_loads, const f32x16* init = nullptr)
-    {
-        const int r = lane & 31, h = lane >> 5;
-        const __bf16* tb = tile + (32 * cbk + r) * STRIDE + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + D - 1 < KS) {
-                a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
-                a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 512 * (KS + ks + D - 1));
-            }
-            if (ks == (KS > D ? KS - D : 0)) {
-                __builtin_amdgcn_sched_barrier(0);
-                after_loads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(tb + 16 * ks);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][j], b, (ks == 0 && init) ? init[j] : acc[j], 0, 0, 0);
         }
     }
 };
@@ -873,45 +736,20 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
 template <bool FUSED, int NS = 1>
 __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
-    // NS == 1: W3 (8 KB, fragment-native as packed) lives in LDS for the head product — fetched from L2 where it is used, its eight
-    // fragments' round trip stood in the middle of the tile's chain (head phase 2 070 cycles for 128 cycles of MFMA on four of the
-    // eight waves, the others waiting at the next barrier: profiles/r03_j_mlp_stamps.json).  (NS = 3 has no LDS left for it.)
-    constexpr bool kW3Lds = PNR_MLP_W3_LDS && NS == 1 && FUSED;      // (the plain forward keeps three workgroups per CU: 53 KB each)
-    // PAIRED (r04 g, bf16 operands): the workgroup takes its tile through net 0 and then net 1 — the input tile is staged once and
-    // has to survive the first net, so the head rows, head gradients, record and loss sums get 13 KB of their own instead of the
-    // dead input tile: 66 KB, still two workgroups per CU
-    constexpr bool kPairedBuild = PNR_MLP_PAIRED && FUSED && NS == 1;
-    constexpr int kScratchElems = kPairedBuild ? 2 * kFusedScratchFloats : 0;
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0) + kScratchElems + ((FUSED && NS == 1) ? PNR_MLP_LDS_PAD : 0)];
-    static_assert(NS >= 1 && NS <= kMlpMaxPlanes && (NS * kTilePlane + kScratchElems) * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
-    static_assert(!kPairedBuild || 2 * ((kTilePlane + kScratchElems + (kW3Lds ? kMlpHead * kMlpHid : 0)) * 2 + (PNR_MLP_STAMPS ? 2048 : 0)) <= 160 * 1024, "two paired workgroups per CU");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + ((FUSED && NS == 1) ? PNR_MLP_LDS_PAD : 0)];
+    static_assert(NS >= 1 && NS <= kMlpMaxPlanes && NS * kTilePlane * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
     MLP_STAMP_DECL;
     __bf16* xt = lds;
     __bf16* ht = lds + kMlpBM * kXS;
-    __bf16* w3l = lds + NS * kTilePlane;
     const long long row0 = (long long)blockIdx.x * kMlpBM;
-    float* const scr = kPairedBuild ? reinterpret_cast<float*>(lds + NS * kTilePlane + (kW3Lds ? kMlpHead * kMlpHid : 0)) : reinterpret_cast<float*>(xt);
-    const bool paired = kPairedBuild && P.paired;
-    [[maybe_unused]] const int units = paired ? 2 : 1;
-    // one (tile, net) unit per pass.  (The back edge exists in the paired instantiation only: wrapped in a `for` — even one of constant
-    // trip count 1 — every other instantiation lost its schedule: 78 -> 105, 178 -> 204, 242 -> 256 registers; as a lambda called from
-    // a loop, the closure cost every instantiation 40 bytes of scratch.)
-    int u = 0;
-unit_begin: __attribute__((unused));
-    {
-    // (the thread index is re-read behind an opaque barrier in every unit: as a loop invariant, the body's few hundred tile and
-    // fragment addresses were all hoisted in front of the loop and spilled — 396 bytes of scratch per lane)
-    int tid_ = threadIdx.x;
-    if constexpr (kPairedBuild) asm volatile("" : "+v"(tid_));
-    const int tid = tid_, lane = tid & 63, w = tid >> 6;
+    float* const scr = reinterpret_cast<float*>(xt);          // the dead input tile: head rows, head gradients, record, loss sums
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
-    // ---- which blocks of a layer's [256 rows][64 samples] output this wave's two accumulators hold.  8 x 1 layout (r03): row block w,
-    // column blocks 0 and 1.  4 x 2 layout (r04, bf16 operands): row blocks 2 (w >> 1) and + 1, column block w & 1.
-    constexpr bool L42 = PNR_MLP_WAVE_LAYOUT == 1 && NS == 1 && kMlpCB == 2 && FUSED;     // (the plain forward keeps its 78 registers: three workgroups per CU)
-    constexpr int NRB = L42 ? 2 : 1;                              // row blocks (and bias sets) of a wave
-    const int rowblk0 = L42 ? 2 * (w >> 1) : w, colblk0 = L42 ? (w & 1) : 0;
-    const auto rowblk = [&](int j) { return L42 ? rowblk0 + j : rowblk0; };
-    const auto colblk = [&](int j) { return L42 ? colblk0 : j; };
+    // this wave's accumulators hold row block w of a layer's [256 rows][64 samples] output, column blocks 0 and 1
+    constexpr int NRB = 1;                                        // row blocks (and bias sets) of a wave
+    const int rowblk0 = w;
+    const auto rowblk = [&](int) { return w; };
+    const auto colblk = [&](int j) { return j; };
     // a wave's four 16-byte bias pieces (rows 32 w + 8 k + 4 h ..): requested in FRONT of the product's weight-fragment prefetch,
     // so that they are the older operations (vector-memory results return in order: asked for behind the fragments, as the
     // accumulators' initial values, each bias load made the compiler wait for vmcnt(0), draining the prefetch ring inside the product)
@@ -932,53 +770,27 @@ unit_begin: __attribute__((unused));
     };
     const auto bias_init = [&](f32x16 (&acc)[kMlpCB], const f32x16 (&b)[NRB]) {       // (timing-only builds that skip a product)
 #pragma unroll
-        for (int cb = 0; cb < kMlpCB; ++cb) acc[cb] = b[L42 ? cb : 0];
+        for (int cb = 0; cb < kMlpCB; ++cb) acc[cb] = b[0];
     };
-    const int yi = paired ? u : (int)blockIdx.y;                  // index of this (tile, net) unit among the tile's units
+    const int yi = (int)blockIdx.y;                               // index of this (tile, net) unit among the tile's units
     const int net = yi + P.first_net;
-    [[maybe_unused]] const int stamp_yi_ = yi, stamp_ny_ = paired ? 2 : (int)gridDim.y;
+    [[maybe_unused]] const int stamp_yi_ = yi, stamp_ny_ = (int)gridDim.y;
     const __bf16* wp = P.wpack + (size_t)net * kPackElems;
     const float* bias = P.bias + net * kBiasElems;
-    // the second unit of a pair overwrites the hidden tile the first one's dZ1 store is still reading
-    if (u > 0) mlp_barrier();
     // layer 1's bias and first weight fragments do not depend on the tile: requested before anything else
     MLP_STAMP(0);
     f32x4 bq1[NRB][4];
     bias_load(bias, bq1);
     __builtin_amdgcn_sched_barrier(0);
-    typename std::conditional<L42, MlpGemm2R<kMlpInPad, kXS>, MlpGemm1<kMlpInPad, kXS, NS>>::type g1;
+    MlpGemm1<kMlpInPad, kXS, NS> g1;
     g1.prefetch(wp + kOffW1 + rowblk0 * (kMlpInPad / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
-#if PNR_MLP_DEPHASE
-    if constexpr (FUSED) {
-        // The two workgroups of a CU start together and walk the same phases in lock-step: four waves per SIMD want the matrix pipe
-        // in the product phases and the vector ALU in the epilogues, in turn instead of together.  The second workgroup of every CU
-        // (dispatch order = linear block id: the first 256 take a CU each) starts PNR_MLP_DEPHASE x 64 cycles late.
-        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if ((lin >> 8) == 1u) {
-#pragma unroll 1
-            for (int i = 0; i < PNR_MLP_DEPHASE; i += 8) __builtin_amdgcn_s_sleep(8);
-        }
-    }
-#endif
-#if PNR_MLP_PRIO
-    if constexpr (FUSED && NS == 1) {
-        // Of a CU's two workgroups the older one wins every contended issue slot: it ends at ~17.3 us, its neighbour at ~22.5, and
-        // the pair that follows them inherits the skew (stamps r04 g: first round ends 17 / 22.5 us, second 35.5 / 41-42.6) — the launch
-        // ends with half-empty CUs.  PNR_MLP_PRIO: wave priority by dispatch group of 256 workgroups (bit k of the value = priority of group k)
-        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if ((PNR_MLP_PRIO >> ((lin >> 8) & 3)) & 1) __builtin_amdgcn_s_setprio(1);
-    }
-#endif
     if constexpr (FUSED) {       // this launch is one optimiser update: counted here, read by the Adam kernel two launches on
         if (blockIdx.x == 0 && yi == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
     }
 
-    // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero); a pair's second unit finds it in place
-    if (u == 0) {
-        static_assert(kMlpHead * kMlpHid / 8 == kFwdThreads, "W3: one 16-byte piece per thread");
-        uint4 w3v = make_uint4(0u, 0u, 0u, 0u);
-        if constexpr (kW3Lds) w3v = *reinterpret_cast<const uint4*>(wp + kOffW3 + 8 * tid);    // travels with the tile's rows
+    // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero)
+    {
         float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
         if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy,
             // every load of the thread in flight before the first LDS write
@@ -1068,7 +880,6 @@ unit_begin: __attribute__((unused));
             }
         }
         }
-        if constexpr (kW3Lds) *reinterpret_cast<uint4*>(w3l + 8 * tid) = w3v;
         mlp_barrier();
         if (P.xs && net == 0) {                                   // the input is the same for both nets: saved once
             for (int ch = tid; ch < kMlpBM * (kMlpInPad / 8); ch += kFwdThreads) {
@@ -1127,7 +938,6 @@ unit_begin: __attribute__((unused));
 #pragma unroll
         for (int r = 0; r < NRB; ++r) b16[r] = bias16(bq1, r);
         if (PNR_MLP_DIAG & 8) bias_init(acc, b16);
-        else if constexpr (L42) g1.run(xt, colblk0, acc, lane, [] {}, b16);
         else g1.run(xt, acc, lane, [] {}, &b16[0]);
     }
     MLP_STAMP(2);                         // layer-1 product issued
@@ -1137,7 +947,7 @@ unit_begin: __attribute__((unused));
     f32x4 bq2[NRB][4];
     bias_load(bias + kMlpHid, bq2);
     __builtin_amdgcn_sched_barrier(0);
-    typename std::conditional<L42, MlpGemm2R<kMlpHid, kHS>, MlpGemm1<kMlpHid, kHS, NS>>::type g2;
+    MlpGemm1<kMlpHid, kHS, NS> g2;
     g2.prefetch(wp + kOffW2 + rowblk0 * (kMlpHid / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
     mlp_barrier();
@@ -1163,8 +973,7 @@ unit_begin: __attribute__((unused));
         if (P.h1 && !(PNR_MLP_DIAG & 64)) store_planes(P.h1);
     };
     if (!(PNR_MLP_DIAG & 4)) {
-        if constexpr (L42) g2.run(ht, colblk0, acc, lane, l2_hook, b16_2);
-        else g2.run(ht, acc, lane, l2_hook, &b16_2[0]);
+        g2.run(ht, acc, lane, l2_hook, &b16_2[0]);
     }
     if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
         if (rec_early) rect.park(scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
@@ -1189,8 +998,7 @@ unit_begin: __attribute__((unused));
         for (int ks = 0; ks < kMlpHid / 32; ++ks)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                if constexpr (kW3Lds) w3f[ks][s] = *reinterpret_cast<const bf16x8*>(w3l + 512 * ks + lane * 8);
-                else w3f[ks][s] = ld_global_bf16x8(w3 + s * kWPlane + 512 * ks);
+                w3f[ks][s] = ld_global_bf16x8(w3 + s * kWPlane + 512 * ks);
             }
 #pragma unroll
         for (int ks = 0; ks < kMlpHid / 32; ++ks) {
@@ -1258,10 +1066,9 @@ unit_begin: __attribute__((unused));
         const float* rl = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2;     // the parked record
         float* wsum = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats;   // [8 waves][4] loss sums
         // W3^T's fragment for the first backward product: requested before the H2 store and the loss
-        bf16x8 w3t[NS * NRB];                                            // [plane] (8 x 1) or [row block] (4 x 2, one plane)
+        bf16x8 w3t[NS];                                                  // [plane]
 #pragma unroll
-        for (int s = 0; s < NS * NRB; ++s)
-            w3t[s] = ld_global_bf16x8(wp + (L42 ? 0 : s) * kWPlane + kOffW3T + (L42 ? rowblk(s) : w) * 512 + lane * 8);
+        for (int s = 0; s < NS; ++s) w3t[s] = ld_global_bf16x8(wp + s * kWPlane + kOffW3T + w * 512 + lane * 8);
         __builtin_amdgcn_sched_barrier(0);
         if (P.h2 && !(PNR_MLP_DIAG & 64)) store_planes(P.h2);      // (null: layer 3's gradients are made here, below)
         mlp_barrier();
@@ -1334,17 +1141,9 @@ unit_begin: __attribute__((unused));
                 for (int j = 0; j < 4; ++j) w3p[kMlpHead * kMlpHid + kMlpHid + 4 * g + j] = ab3[j];     // every column of G^T . 1 is db3
             }
         }
-        // (4 x 2 layout: a wave's feature columns 32 w .. are overwritten by itself AND by its partner of the other sample half:
-        // both have read them above before either writes)
-        if constexpr (L42) { if (w3p) mlp_barrier(); }
         // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
         zero_acc();
         {
-            if constexpr (L42) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(gt + (32 * colblk0 + c) * kGS + 8 * h);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[j], b, acc[j], 0, 0, 0);
-            } else {
             bf16x8 b[NS][kMlpCB];
 #pragma unroll
             for (int s = 0; s < NS; ++s)
@@ -1355,7 +1154,6 @@ unit_begin: __attribute__((unused));
 #pragma unroll
                 for (int cb = 0; cb < kMlpCB; ++cb)
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb], acc[cb], 0, 0, 0);
-            }
         }
         bwd_epilogue();
         const auto b2_products = [&] {                             // db2 = 1^T . dZ2 of this wave's columns 32 w .., now that they hold dZ2
@@ -1368,20 +1166,18 @@ unit_begin: __attribute__((unused));
                 }
             }
         };
-        if constexpr (!L42) b2_products();                          // (8 x 1: only this wave wrote these columns)
+        b2_products();                                             // (only this wave wrote these columns)
         MLP_STAMP(15);                    // dH2 product + its epilogue
-        typename std::conditional<L42, MlpGemm2R<kMlpHid, kHS>, MlpGemm1<kMlpHid, kHS, NS>>::type g4;    // W2^T's first fragments ahead of the barrier
+        MlpGemm1<kMlpHid, kHS, NS> g4;    // W2^T's first fragments ahead of the barrier
         g4.prefetch(wp + kOffW2T + rowblk0 * (kMlpHid / 16) * 512, lane);
         __builtin_amdgcn_sched_barrier(0);
         mlp_barrier();
-        if constexpr (L42) b2_products();                           // (4 x 2: the partner's half of the columns is in place now)
         MLP_STAMP(16);                    // barrier after it
 
         // ---- dH1^T = W2^T . dZ2^T (the dZ2 tile leaves from inside the product), then H1 into the tile and dZ1 in place over it
         zero_acc();
         const auto dz2_hook = [&] { if (!(PNR_MLP_DIAG & 64)) store_planes(P.dz2); };
-        if constexpr (L42) g4.run(ht, colblk0, acc, lane, dz2_hook);
-        else g4.run(ht, acc, lane, dz2_hook);
+        g4.run(ht, acc, lane, dz2_hook);
         MLP_STAMP(17);                    // dZ2 store + W2^T product issued
         MLP_STAMP(18);
         mlp_barrier();                         // every read of dZ2 (the product and the store inside it) is done: the tile is free
@@ -1401,608 +1197,6 @@ unit_begin: __attribute__((unused));
         MLP_STAMP(22);                    // end
         MLP_STAMP_FLUSH;
     }
-    }   // unit
-    if constexpr (kPairedBuild) { if (++u < units) goto unit_begin; }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The fused training tile with FOUR 64-row waves (r04 g; -DPNR_MLP_FAT=1, bf16 operands, pre-gathered rows): grid (tiles, nets), 256
-// threads, each wave owns two 32-row blocks of every layer for the WHOLE 64-sample tile (four accumulators), so a weight fragment
-// still reaches the CU once per tile (the 4 x 2 layout's flaw) while a sample fragment read from LDS now serves two MFMAs — and a
-// tile is four waves at <= 168 registers: THREE tiles per CU where the eight-wave form fits two (the occupancy probe, DESIGN §7:
-// one tile's chain leaves most of a CU idle).  Same arithmetic in the same order as mlp_forward_kernel<true, 1>: bit-identical
-// (tests/test_gpu_mlp.py builds the variant and compares).  Measured slower: the comment at PNR_MLP_FAT.
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef PNR_MLP_FAT
-#define PNR_MLP_FAT 0             // A/B r04 g: built, bit-identical, SLOWER — mlp_fused4_kernel 64.9 us against mlp_forward_kernel<true>'s 49.8 (train_step 98.1 vs
-                                  // 80.7; ring depth 2 / 4 / 5: 99.3 / 105.7 / 110.4): with ONE wave per SIMD a tile cannot hide its own LDS and L2 latencies, and
-                                  // three such tiles per CU are three waves per SIMD where the eight-wave form has four (168 registers, 64 bytes of scratch)
-#endif
-#if PNR_MLP_FAT
-#ifndef PNR_MLP_RING22
-#define PNR_MLP_RING22 3          // weight-fragment prefetch depth of the four-wave tile (two fragments = 8 registers per slot)
-#endif
-constexpr int kFatThreads = 256, kFatWaves = 4;
-
-// acc[j][cb] += W[row block rb0 + j][K] . tile[column block cb][K]^T, j, cb = 0, 1: two weight fragments (L2) and two sample fragments
-// (LDS) per k-step for four MFMAs
-template <int K, int STRIDE>
-struct MlpGemm22 {
-    static constexpr int KS = K / 16;
-    static constexpr int D = PNR_MLP_RING22;
-    bf16x8 a[D][2];
-    const __bf16* wa;
-    __device__ __forceinline__ void prefetch(const __bf16* __restrict__ w_blocks, int lane)
-    {
-        wa = w_blocks + lane * 8;
-#pragma unroll
-        for (int p = 0; p < D - 1; ++p)
-            if (p < KS) {
-                a[p][0] = ld_global_bf16x8(wa + 512 * p);
-                a[p][1] = ld_global_bf16x8(wa + 512 * (KS + p));
-            }
-    }
-    template <class F>
-    __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[2][kMlpCB], int lane, F&& after_loads, const f32x16* init = nullptr)
-    {
-        const int r = lane & 31, h = lane >> 5;
-        const __bf16* tb = tile + r * STRIDE + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + D - 1 < KS) {
-                a[(ks + D - 1) % D][0] = ld_global_bf16x8(wa + 512 * (ks + D - 1));
-                a[(ks + D - 1) % D][1] = ld_global_bf16x8(wa + 512 * (KS + ks + D - 1));
-            }
-            if (ks == (KS > D ? KS - D : 0)) {
-                __builtin_amdgcn_sched_barrier(0);
-                after_loads();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            bf16x8 b[kMlpCB];
-#pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * ks);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int cb = 0; cb < kMlpCB; ++cb)
-                    acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][j], b[cb], (ks == 0 && init) ? init[j] : acc[j][cb], 0, 0, 0);
-        }
-    }
-};
-
-__global__ __launch_bounds__(kFatThreads, 3) void mlp_fused4_kernel(const MlpFwdParams P)
-{
-    static_assert(kMlpCB == 2 && kFatWaves * 64 == kMlpHid, "four waves of two 32-row blocks, two 32-sample column blocks");
-    __shared__ __attribute__((aligned(16))) __bf16 lds[kTilePlane];
-    __bf16* xt = lds;
-    __bf16* ht = lds + kMlpBM * kXS;
-    float* const scr = reinterpret_cast<float*>(xt);             // the dead input tile: head rows, head gradients, record, loss sums
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int net = blockIdx.y + P.first_net;
-    const long long row0 = (long long)blockIdx.x * kMlpBM;
-    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
-    const float* bias = P.bias + net * kBiasElems;
-    const int c = lane & 31, h = lane >> 5, rb0 = 2 * w;
-    const auto bias_load = [&](const float* b, f32x4 (&q)[2][4]) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q[r][k] = *reinterpret_cast<const f32x4*>(b + 32 * (rb0 + r) + 8 * k + 4 * h);
-    };
-    const auto bias16 = [&](const f32x4 (&q)[2][4], int r) {
-        f32x16 b;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[4 * k + j] = q[r][k][j];
-        return b;
-    };
-    const auto at = [&](int r, int cb, int q) { return ht + (32 * cb + c) * kHS + 32 * (rb0 + r) + 8 * q + 4 * h; };
-    const auto store_tile = [&](__bf16* dst) { mlp_store_htile_nt<kFatThreads>(ht, dst + (size_t)net * P.B * kMlpHid, row0, P.B, tid); };
-
-    f32x4 bq1[2][4];
-    bias_load(bias, bq1);
-    __builtin_amdgcn_sched_barrier(0);
-    MlpGemm22<kMlpInPad, kXS> g1;
-    g1.prefetch(wp + kOffW1 + rb0 * (kMlpInPad / 16) * 512, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;
-
-    // ---- stage 0: the tile's 64 pre-gathered rows (18 KB of contiguous bf16), every load in flight before the first LDS write
-    {
-        constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFatThreads - 1) / kFatThreads;
-        uint4 v[kIt];
-        if (row0 + kMlpBM <= P.B) {
-            const __bf16* base = P.xs_in + row0 * kMlpInPad + tid * 8;
-#pragma unroll
-            for (int i = 0; i < kIt; ++i) {
-                v[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (i < kCh / kFatThreads || tid + kFatThreads * i < kCh) v[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * kFatThreads * 8);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < kIt; ++i) {
-                const int ch = tid + kFatThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                v[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (ch < kCh && row0 + row < P.B) v[i] = *reinterpret_cast<const uint4*>(P.xs_in + (row0 + row) * kMlpInPad + cc * 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kIt; ++i) {
-            const int ch = tid + kFatThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-            if (ch < kCh) *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = v[i];
-        }
-        mlp_barrier();
-    }
-
-    f32x16 acc[2][kMlpCB];
-    bf16x4 h1keep[2][kMlpCB][4];
-    const auto epilogue = [&](bool keep) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bf16x4 pk = tanh_quad(acc[r][cb], q);
-                    *reinterpret_cast<bf16x4*>(at(r, cb, q)) = pk;
-                    if (keep) h1keep[r][cb][q] = pk;
-                }
-    };
-    const auto zero_acc = [&]() {
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[r][cb][i] = 0.f;
-    };
-
-    // ---- layer 1
-    {
-        const f32x16 b16[2] = {bias16(bq1, 0), bias16(bq1, 1)};
-        g1.run(xt, acc, lane, [] {}, b16);
-    }
-    epilogue(true);
-    f32x4 bq2[2][4];
-    bias_load(bias + kMlpHid, bq2);
-    __builtin_amdgcn_sched_barrier(0);
-    MlpGemm22<kMlpHid, kHS> g2;
-    g2.prefetch(wp + kOffW2 + rb0 * (kMlpHid / 16) * 512, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    mlp_barrier();
-
-    // ---- layer 2 (the H1 tile and the record request leave from inside the product)
-    MlpRecordTile<kFatThreads> rect;
-    {
-        const f32x16 b16[2] = {bias16(bq2, 0), bias16(bq2, 1)};
-        g2.run(ht, acc, lane, [&] {
-            const float* const src[5] = {P.rec_actions, P.rec_mean, P.rec_log_std, net == 0 ? P.rec_adv : P.rec_vtarg, net == 0 ? P.rec_logp : P.rec_values};
-            rect.load(src, net, row0, P.B, tid);
-            if (P.h1) store_tile(P.h1);
-        }, b16);
-    }
-    rect.park(scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
-    mlp_barrier();
-    epilogue(false);
-    mlp_barrier();
-
-    // ---- layer 3: head^T [16][samples] with 16x16x32 MFMAs, 16 samples per wave
-    {
-        const int r16 = lane & 15, g = lane >> 4;
-        f32x4 a3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);
-        const __bf16* w3 = wp + kOffW3 + lane * 8;
-        bf16x8 w3f[kMlpHid / 32];
-#pragma unroll
-        for (int ks = 0; ks < kMlpHid / 32; ++ks) w3f[ks] = ld_global_bf16x8(w3 + 512 * ks);
-#pragma unroll
-        for (int ks = 0; ks < kMlpHid / 32; ++ks) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(ht + (16 * w + r16) * kHS + 32 * ks + 8 * g);
-            a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks], b, a3, 0, 0, 0);
-        }
-        const long long b = row0 + 16 * w + r16;
-        if (b < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + b) * kMlpHead + 4 * g) = a3;
-        *reinterpret_cast<f32x4*>(scr + (16 * w + r16) * kMlpHead + 4 * g) = a3;
-    }
-    float* hd = scr;
-    __bf16* gt = reinterpret_cast<__bf16*>(scr) + kMlpBM * kMlpHead * 2;
-    const float* rl = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2;
-    float* wsum = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats;
-    bf16x8 w3t[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) w3t[r] = ld_global_bf16x8(wp + kOffW3T + (rb0 + r) * 512 + lane * 8);
-    __builtin_amdgcn_sched_barrier(0);
-    if (P.h2) store_tile(P.h2);
-    mlp_barrier();
-    // ---- the tile's loss: the eight-wave form's two halves (samples 0-31, 32-63) by the same four waves, one after the other
-    mlp_tile_loss<1>(P, net, row0, tid, hd, gt, rl, wsum, true);
-    mlp_tile_loss<1>(P, net, row0, tid + kFatThreads, hd, gt, rl, wsum, true);
-    mlp_barrier();
-    if (tid == 0) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < kFwdWaves; ++k) t += *reinterpret_cast<const f32x4*>(wsum + 4 * k);
-        float* pr = P.partials + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * 8;
-        *reinterpret_cast<f32x4*>(pr) = t;
-        *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-
-    // ---- layer 3's weight-gradient partials of this tile while H2 is in the tile (this wave's 64 feature columns: only it overwrites them)
-    float* w3p = P.w3part ? P.w3part + ((size_t)blockIdx.x * P.n_nets + blockIdx.y) * kW3PartFloats : nullptr;
-    if (w3p) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ww = rb0 + r;
-            f32x4 aw3[2], ab3;
-            mlp_tile_w3_products<1>(gt, kGS, ht, kHS, lane, ww, aw3, ab3, kTilePlane, kTilePlane);
-            const int c16 = lane & 15, g = lane >> 4;
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w3p[(4 * g + j) * kMlpHid + 32 * ww + 16 * b + c16] = aw3[b][j];
-            if (ww == 0 && c16 == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w3p[kMlpHead * kMlpHid + kMlpHid + 4 * g + j] = ab3[j];
-            }
-        }
-    }
-    // ---- dH2^T = W3^T . G^T, dZ2 in place over H2
-    zero_acc();
-    {
-        bf16x8 b[kMlpCB];
-#pragma unroll
-        for (int cb = 0; cb < kMlpCB; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(gt + (32 * cb + c) * kGS + 8 * h);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb) acc[r][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[r], b[cb], acc[r][cb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int cb = 0; cb < kMlpCB; ++cb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __bf16* a_ = at(r, cb, q);
-                const bf16x4 hv = *reinterpret_cast<const bf16x4*>(a_);
-                *reinterpret_cast<bf16x4*>(a_) = dtanh_quad(acc[r][cb], q, hv);
-            }
-    if (w3p) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ww = rb0 + r;
-            f32x4 ab2[2];
-            mlp_tile_b2_products<1>(ht, kHS, lane, ww, ab2, kTilePlane);
-            if ((lane >> 4) == 0) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * ww + 16 * b + (lane & 15)] = ab2[b][0];
-            }
-        }
-    }
-    MlpGemm22<kMlpHid, kHS> g4;
-    g4.prefetch(wp + kOffW2T + rb0 * (kMlpHid / 16) * 512, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    mlp_barrier();
-
-    // ---- dH1^T = W2^T . dZ2^T (the dZ2 tile leaves from inside the product), dZ1 into the free tile
-    zero_acc();
-    g4.run(ht, acc, lane, [&] { store_tile(P.dz2); });
-    mlp_barrier();
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int cb = 0; cb < kMlpCB; ++cb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(at(r, cb, q)) = dtanh_quad(acc[r][cb], q, h1keep[r][cb][q]);
-    mlp_barrier();
-    store_tile(P.dz1);
-}
-#endif   // PNR_MLP_FAT
-
-// ---------------------------------------------------------------------------------------------------------------
-// The fused training tile, WEIGHT-STATIONARY (r03f): grid (G, nets), 512 threads, ONE workgroup per CU that walks the tiles
-// g, g + G, .. of its net.  mlp_forward_kernel<true> streams a tile's 344 KB of weight fragments from L2 while it multiplies
-// (1 KiB per wave and k-step for two MFMAs: the products ran at 1/6 of their MFMA time, paced by those loads — 42 B/clk/CU,
-// the L2 -> CU rate — and two co-resident workgroups were all the overlap 125 registers allowed).  Here a wave keeps ITS
-// 32-row blocks of W1, W2 and W2^T in registers (36 + 64 + 64) for the whole launch: the products read LDS and registers
-// only.  The 160 KB of LDS (one workgroup per CU) buy separate tiles for X, H1, H2 / dZ2 and dZ1 (six barriers per tile
-// instead of ten: no product -> epilogue barrier, nothing is overwritten in place under a reader) and the next tile's input
-// arrives under the last product.  Same arithmetic in the same order as mlp_forward_kernel<true>: the outputs are bit-identical
-// (tests/test_gpu_mlp.py).  Contiguous inputs only (xs_in, no idx: what pnr_mlp_gather prepares once per epoch).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kTrainMiscFloats = kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats + 4 * kFwdWaves + 2 * kMlpHid;
-constexpr int kTrainLdsElems = kMlpBM * kXS + 3 * kMlpBM * kHS + 2 * kTrainMiscFloats + 2 * kMlpHead * kMlpHid;     // + W3 and W3^T
-static_assert(kTrainLdsElems * 2 <= 160 * 1024, "the training tile's LDS fits one CU");
-
-// acc[cb] += A[32 rows of this wave][16 KS] . tile[BM samples][16 KS]^T with the wave's A fragments in registers.  The sample fragments
-// are read one k-step ahead of their MFMAs and the k-steps stay in order (sched_barrier): left alone, the scheduler hoists a whole
-// product's LDS reads (128 registers) above its first MFMA and spills the stationary weights.
-template <int KS, int STRIDE>
-__device__ __forceinline__ void mlp_gemm_regs(const bf16x8 (&a)[KS], const __bf16* tile, f32x16 (&acc)[kMlpCB], int lane)
-{
-    const int r = lane & 31, h = lane >> 5;
-    const __bf16* tb = tile + r * STRIDE + 8 * h;
-    bf16x8 b[2][kMlpCB];
-#pragma unroll
-    for (int cb = 0; cb < kMlpCB; ++cb) b[0][cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-#pragma unroll
-            for (int cb = 0; cb < kMlpCB; ++cb) b[(ks + 1) & 1][cb] = *reinterpret_cast<const bf16x8*>(tb + cb * 32 * STRIDE + 16 * (ks + 1));
-        }
-#pragma unroll
-        for (int cb = 0; cb < kMlpCB; ++cb)
-            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks & 1][cb], acc[cb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-__global__ __launch_bounds__(kFwdThreads, 2) void mlp_train_kernel(const MlpFwdParams P)
-{
-    static_assert(kMlpBM == 64, "written for 64-sample tiles");
-    __shared__ __attribute__((aligned(16))) __bf16 lds[kTrainLdsElems];
-    MLP_STAMP_DECL;
-    __bf16* xt = lds;                                               // [64][144] the tile's input
-    __bf16* h1t = xt + kMlpBM * kXS;                                // [64][256] H1
-    __bf16* h2t = h1t + kMlpBM * kHS;                               // H2, then dZ2 in place (a lane's own quads)
-    __bf16* d1t = h2t + kMlpBM * kHS;                               // dZ1
-    float* hd = reinterpret_cast<float*>(d1t + kMlpBM * kHS);       // [64][16] float32 head rows
-    __bf16* gt = reinterpret_cast<__bf16*>(hd + kMlpBM * kMlpHead); // [64][kGS] bf16 head gradients
-    float* rl = hd + kMlpBM * kMlpHead + kMlpBM * kGS / 2;          // the tile's record
-    float* wsum = rl + kRecLdsFloats;                               // [8 waves][4] loss sums
-    float* bl = wsum + 4 * kFwdWaves;                               // b1 | b2
-    __bf16* w3l = reinterpret_cast<__bf16*>(bl + 2 * kMlpHid);      // W3 and W3^T as they are packed (fragment-native, 8 KB each):
-    __bf16* w3tl = w3l + kMlpHead * kMlpHid;                        // read per tile with no register and no L2 round trip
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    [[maybe_unused]] const int stamp_yi_ = blockIdx.y, stamp_ny_ = gridDim.y;
-    const int net = blockIdx.y + P.first_net;
-    const long long tiles = (P.B + kMlpBM - 1) / kMlpBM;
-    const __bf16* wp = P.wpack + (size_t)net * kPackElems;
-    const float* bias = P.bias + net * kBiasElems;
-    const int c = lane & 31, h = lane >> 5;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && P.adam_step) *P.adam_step += 1.0f;   // one optimiser update per launch
-    MLP_STAMP(0);
-
-    // a tile's 18 KB of contiguous input rows: requested into registers, written to LDS when the tile before it is done with xt
-    constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFwdThreads - 1) / kFwdThreads;
-    uint4 xv[kIt];
-    const auto x_load = [&](long long r0, int tid) {
-#pragma unroll
-        for (int i = 0; i < kIt; ++i) {
-            const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-            xv[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (ch < kCh && r0 + row < P.B) xv[i] = *reinterpret_cast<const uint4*>(P.xs_in + (r0 + row) * kMlpInPad + cc * 8);
-        }
-    };
-    const auto x_park = [&](int tid) {
-#pragma unroll
-        for (int i = 0; i < kIt; ++i) {
-            const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-            if (ch < kCh) *reinterpret_cast<uint4*>(xt + row * kXS + cc * 8) = xv[i];
-        }
-    };
-    long long t = blockIdx.x;
-    x_load(t * kMlpBM, tid);                                             // the oldest requests: waited for alone
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 2 * kMlpHid / 4) bv = *reinterpret_cast<const f32x4*>(bias + 4 * tid);
-    static_assert(kMlpHead * kMlpHid / 8 == kFwdThreads, "W3, W3^T: one 16-byte piece per thread each");
-    const uint4 w3v0 = *reinterpret_cast<const uint4*>(wp + kOffW3 + 8 * tid), w3v1 = *reinterpret_cast<const uint4*>(wp + kOffW3T + 8 * tid);
-    // W1 streams through the ring as in mlp_forward_kernel (its first fragments requested a product ahead) ..
-    MlpGemm1<kMlpInPad, kXS> g1;
-    g1.prefetch(wp + kOffW1 + w * (kMlpInPad / 16) * 512, lane);
-    // .. this wave's row blocks of W2 and W2^T (fragment-native: k-step ks at ks * 512) stay in registers for every tile of the launch
-    bf16x8 w2f[kMlpHid / 16], w2tf[kMlpHid / 16];
-#pragma unroll
-    for (int ks = 0; ks < kMlpHid / 16; ++ks) w2f[ks] = ld_global_bf16x8(wp + kOffW2 + (w * (kMlpHid / 16) + ks) * 512 + lane * 8);
-#pragma unroll
-    for (int ks = 0; ks < kMlpHid / 16; ++ks) w2tf[ks] = ld_global_bf16x8(wp + kOffW2T + (w * (kMlpHid / 16) + ks) * 512 + lane * 8);
-    x_park(tid);
-    if (tid < 2 * kMlpHid / 4) *reinterpret_cast<f32x4*>(bl + 4 * tid) = bv;
-    *reinterpret_cast<uint4*>(w3l + 8 * tid) = w3v0;
-    *reinterpret_cast<uint4*>(w3tl + 8 * tid) = w3v1;
-    mlp_barrier();
-    MLP_STAMP(1);                                                   // weights, biases and the first input landed
-
-    const f32x4 b3q = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * (lane >> 4));     // the head rows' bias (rows 4 g ..)
-    // ---- the stages of one 32-sample HALF of the tile (column block hb; acc = that half's accumulators)
-    const auto bias_half = [&](f32x16& acc, const float* b) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(b + 32 * w + 8 * k + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[4 * k + j] = q[j];
-        }
-    };
-    // acc += A[32 rows of this wave][256] . tile[32 samples of the half][256]^T, the wave's A fragments in registers, the sample
-    // fragments read one k-step ahead of their MFMA
-    const auto prod_half = [&](const bf16x8 (&a)[kMlpHid / 16], const __bf16* tile, int hb, f32x16& acc) {
-        constexpr int LA = PNR_MLP_TRAIN_LOOKAHEAD;      // k-steps between a sample fragment's LDS read and its MFMA
-        const __bf16* tb = tile + (32 * hb + c) * kHS + 8 * h;
-        bf16x8 b[LA + 1];
-#pragma unroll
-        for (int p = 0; p < LA; ++p) b[p] = *reinterpret_cast<const bf16x8*>(tb + 16 * p);
-#pragma unroll
-        for (int ks = 0; ks < kMlpHid / 16; ++ks) {
-            if (ks + LA < kMlpHid / 16) b[(ks + LA) % (LA + 1)] = *reinterpret_cast<const bf16x8*>(tb + 16 * (ks + LA));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b[ks % (LA + 1)], acc, 0, 0, 0);
-        }
-    };
-    // tanh in registers, each register quad = four consecutive features of one sample -> one ds_write_b64
-    const auto tanh_half = [&](const f32x16& acc, __bf16* tile, int hb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<bf16x4*>(tile + (32 * hb + c) * kHS + 32 * w + 8 * q + 4 * h) = tanh_quad(acc, q);
-        }
-    };
-    // acc * (1 - h^2), h at this lane's own quads of `htile`, the product into `dst` (which may be htile itself)
-    const auto bwd_half = [&](const f32x16& acc, const __bf16* htile, __bf16* dst, int hb) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = (32 * hb + c) * kHS + 32 * w + 8 * q + 4 * h;
-            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(htile + o);
-            *reinterpret_cast<bf16x4*>(dst + o) = dtanh_quad(acc, q, hv);
-        }
-    };
-    // head^T [16][16 samples sb ..] = W3 . H2^T + b3 by one wave (16 x 16 x 32 MFMAs, W3's fragments from LDS)
-    const auto head16 = [&](int sb, long long row0) {
-        const int r16 = lane & 15, g = lane >> 4;
-        f32x4 a3 = b3q;
-#pragma unroll
-        for (int ks = 0; ks < kMlpHid / 32; ++ks) {
-            const bf16x8 bq = *reinterpret_cast<const bf16x8*>(h2t + (sb + r16) * kHS + 32 * ks + 8 * g);
-            a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(w3l + 512 * ks + lane * 8), bq, a3, 0, 0, 0);
-        }
-        const long long bb = row0 + sb + r16;
-        if (bb < P.B && P.head) *reinterpret_cast<f32x4*>(P.head + ((size_t)net * P.B + bb) * kMlpHead + 4 * g) = a3;
-        *reinterpret_cast<f32x4*>(hd + (sb + r16) * kMlpHead + 4 * g) = a3;
-    };
-    // dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2: one half
-    const auto dh2_half = [&](f32x16& acc, int hb) {
-        const bf16x8 w3t = *reinterpret_cast<const bf16x8*>(w3tl + w * 512 + lane * 8);
-        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(gt + (32 * hb + c) * kGS + 8 * h);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t, bq, acc, 0, 0, 0);
-        bwd_half(acc, h2t, h2t, hb);
-    };
-    const auto zero_half = [&](f32x16& acc) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    };
-
-    // ---- The tile loop, software-pipelined over the two halves: half 1 runs one slot behind half 0, so that every slot has a
-    // matrix job (a product of one half) and a vector job (an epilogue, the loss, the tile stores of the other half) that share
-    // nothing.  The two waves of a SIMD (w and w + 4) take them in OPPOSITE order — waves 0-3 the product first, waves 4-7 the
-    // vector job first — so the SIMD's matrix pipe and its vector ALU are busy together instead of in turn (as whole-tile phases,
-    // one workgroup per CU, nothing overlapped: 25 400 cycles per tile, profiles/r03_f_train_stamps_phases.json).  One barrier per
-    // slot; a half's rows of a tile are only ever written a slot (and a barrier) after their last reader.
-    //   s1  P1(T, both halves: W1 streams once)   | dZ1 epilogue (T-1, 1)
-    //   s2                                         | tanh1(T, 0); dZ1 store (T-1)
-    //   s3  P2(T, 0)                               | tanh1(T, 1); record request
-    //   s4  P2(T, 1)                               | tanh2(T, 0); H1 store
-    //   s5  head(T, 0) [waves 0, 1]                | tanh2(T, 1); record park
-    //   s6  head(T, 1) [waves 4, 5]                | loss(T, 0) [waves 0-3]; H2 store
-    //   s7  dH2 + dZ2 epilogue (T, 0)              | loss(T, 1) [waves 4-7]
-    //   s8  P5(T, 0) = W2^T . dZ2^T                | dH2 + dZ2 epilogue (T, 1); loss sums; next input + W1 requested
-    //   s9  P5(T, 1)                               | dZ1 epilogue (T, 0); dZ2 store; next input parked
-    const bool mfirst = w < 4;
-#define TRAIN_SLOT(M, V) do { if (mfirst) { M; V; } else { V; M; } } while (0)
-    f32x16 acc0, acc1;
-    bool prev = false;
-    long long prow0 = 0;
-    for (; t < tiles; t += gridDim.x) {
-        const long long row0 = t * kMlpBM, next0 = (t + gridDim.x) * kMlpBM;
-        // the thread id as the loop body sees it: opaque, so that the ~40 per-thread global addresses of a tile (tile stores, record
-        // pieces, input rows) are computed where they are used instead of being hoisted out of the loop — as loop invariants they
-        // took 80 registers from the stationary weights and went to scratch
-        int tv = tid;
-        asm volatile("" : "+v"(tv));
-#if PNR_MLP_STAMPS
-        const bool stamped = t == (long long)blockIdx.x + gridDim.x || tiles <= gridDim.x;   // the workgroup's second tile (or its only one)
-#define TRAIN_STAMP(i) do { if (stamped) MLP_STAMP(i); } while (0)
-#else
-#define TRAIN_STAMP(i) do { } while (0)
-#endif
-        TRAIN_STAMP(2);
-        // ---- s1 (the dZ1 epilogue of the tile before reads acc1, which layer 1 then overwrites: it goes first on every wave)
-        if (prev) bwd_half(acc1, h1t, d1t, 1);
-        {
-            f32x16 l1[kMlpCB], b16;
-            bias_half(b16, bl);
-            g1.run(xt, l1, lane, [] {}, &b16);
-            acc0 = l1[0]; acc1 = l1[1];
-        }
-        mlp_barrier();
-        TRAIN_STAMP(3);
-        // ---- s2
-        tanh_half(acc0, h1t, 0);
-        if (prev) mlp_store_htile_nt<kFwdThreads>(d1t, P.dz1 + (size_t)net * P.B * kMlpHid, prow0, P.B, tv);
-        mlp_barrier();
-        TRAIN_STAMP(4);
-        // ---- s3
-        MlpRecordTile<kFwdThreads> rect;
-        {
-            const float* const src[5] = {P.rec_actions, P.rec_mean, P.rec_log_std, net == 0 ? P.rec_adv : P.rec_vtarg, net == 0 ? P.rec_logp : P.rec_values};
-            rect.load(src, net, row0, P.B, tv);
-        }
-        {
-            f32x16 nxt;
-            bias_half(nxt, bl + kMlpHid);
-            TRAIN_SLOT(prod_half(w2f, h1t, 0, nxt), tanh_half(acc1, h1t, 1));
-            acc0 = nxt;
-        }
-        mlp_barrier();
-        TRAIN_STAMP(5);
-        // ---- s4
-        {
-            f32x16 nxt;
-            bias_half(nxt, bl + kMlpHid);
-            TRAIN_SLOT(prod_half(w2f, h1t, 1, nxt), tanh_half(acc0, h2t, 0));
-            acc1 = nxt;
-        }
-        mlp_store_htile_nt<kFwdThreads>(h1t, P.h1 + (size_t)net * P.B * kMlpHid, row0, P.B, tv);
-        mlp_barrier();
-        TRAIN_STAMP(6);
-        // ---- s5
-        if (w < 2) head16(16 * w, row0);
-        tanh_half(acc1, h2t, 1);
-        rect.park(rl, net, tv);
-        mlp_barrier();
-        TRAIN_STAMP(7);
-        // ---- s6
-        if (w == 4 || w == 5) head16(32 + 16 * (w - 4), row0);
-        if (w < 4) mlp_tile_loss(P, net, row0, tv, hd, gt, rl, wsum, true);
-        mlp_store_htile_nt<kFwdThreads>(h2t, P.h2 + (size_t)net * P.B * kMlpHid, row0, P.B, tv);
-        mlp_barrier();
-        TRAIN_STAMP(8);
-        // ---- s7
-        if (w >= 4) mlp_tile_loss(P, net, row0, tv, hd, gt, rl, wsum, true);
-        dh2_half(acc0, 0);
-        mlp_barrier();
-        TRAIN_STAMP(9);
-        // ---- s8
-        if (tv == 0) {                                              // the eight waves' sums in wave order: one row per tile and net
-            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < kFwdWaves; ++k) s4 += *reinterpret_cast<const f32x4*>(wsum + 4 * k);
-            float* pr = P.partials + ((size_t)t * P.n_nets + blockIdx.y) * 8;
-            *reinterpret_cast<f32x4*>(pr) = s4;
-            *reinterpret_cast<f32x4*>(pr + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        // (both unconditional: behind an `if (more)` the old values of 32 registers would stay live around the whole loop; past the
-        // batch's end x_load requests nothing and returns zeros)
-        x_load(next0, tv);
-        g1.prefetch(wp + kOffW1 + (tv >> 6) * (kMlpInPad / 16) * 512, tv & 63);
-        {
-            zero_half(acc0);
-            TRAIN_SLOT(prod_half(w2tf, h2t, 0, acc0), dh2_half(acc1, 1));
-        }
-        mlp_barrier();
-        TRAIN_STAMP(10);
-        // ---- s9
-        {
-            f32x16 nxt;
-            zero_half(nxt);
-            TRAIN_SLOT(prod_half(w2tf, h2t, 1, nxt), bwd_half(acc0, h1t, d1t, 0));
-            acc1 = nxt;
-        }
-        mlp_store_htile_nt<kFwdThreads>(h2t, P.dz2 + (size_t)net * P.B * kMlpHid, row0, P.B, tv);
-        x_park(tv);
-        mlp_barrier();
-        TRAIN_STAMP(11);
-        prev = true;
-        prow0 = row0;
-    }
-    if (prev) {                                                     // the last tile's second half of dZ1
-        bwd_half(acc1, h1t, d1t, 1);
-        mlp_barrier();
-        mlp_store_htile_nt<kFwdThreads>(d1t, P.dz1 + (size_t)net * P.B * kMlpHid, prow0, P.B, tid);
-    }
-    MLP_STAMP(22);
-    MLP_STAMP_FLUSH;
-#undef TRAIN_STAMP
-#undef TRAIN_SLOT
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2362,7 +1556,7 @@ __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, in
 // r04: the hot roles of the weight-gradient kernel (dW2 halves; dW1 halves) stage their chunks with DIRECT-TO-LDS loads
 // (global_load_lds_dwordx4, "glds": 1 KiB per wave-instruction, no VGPR destination, no ds_write pass) into a THREE-stage ring,
 // one raw barrier per chunk and counted s_waitcnt vmcnt(N): chunk c + 2 is requested at the start of chunk c's products and has two
-// chunks of MFMAs to arrive, where the register-staged form (PNR_WG_GLDS=0, kept for the A/B) had one chunk of prefetch, two
+// chunks of MFMAs to arrive, where the register-staged form of r03 (bit-identical; git history) had one chunk of prefetch, two
 // barriers and a VGPR -> LDS write pass per chunk: 3 150 cycles per 64-sample chunk for 16 MFMAs per wave (1 024 cycles of matrix
 // pipe per SIMD), the same for every chunk (profiles/r03_i_wgrad_stamps.json) — a workgroup alone on its CU has nothing else to run
 // while it waits (cdna_hip_programming.md section 5, "Pipelining across barriers": the regime where the 3-buffer span pays).
@@ -2373,9 +1567,6 @@ __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, in
 // B-operand reads of the dW1 roles, ~2 of 32 cycles per MFMA gap); db1 comes from a fragment of ones in registers instead of a
 // column of ones in the tile.  The products, their k order and the chunk order are those of the register-staged form: same bits.
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef PNR_WG_GLDS
-#define PNR_WG_GLDS 1
-#endif
 // the ring's geometry by the number of operand planes (NS > 1: float32-accurate split operands): chunks of 64 samples and three
 // stages for bf16; 32-sample chunks for split operands (a stage holds every plane's tiles), three stages with two planes, two with three
 template <int NS> struct WgGeom {
@@ -2393,7 +1584,7 @@ constexpr int kWgRingBytes = WgGeom<1>::kRing > WgGeom<2>::kRing ? (WgGeom<1>::k
                                                                  : (WgGeom<2>::kRing > WgGeom<3>::kRing ? WgGeom<2>::kRing : WgGeom<3>::kRing);
 static_assert(kWgRingBytes <= 150 * 1024, "the ring fits one CU beside the stamps");
 constexpr int kWgLdsBytesOld = (kWgChunk * kTrH + kWgChunk * kTrH + kWgChunk * kTrG) * 2;
-constexpr int kWgLdsBytes = PNR_WG_GLDS ? (kWgRingBytes > kWgLdsBytesOld ? kWgRingBytes : kWgLdsBytesOld) : kWgLdsBytesOld;
+constexpr int kWgLdsBytes = kWgRingBytes > kWgLdsBytesOld ? kWgRingBytes : kWgLdsBytesOld;
 
 // one direct-to-LDS piece: lane l's 16 bytes at sbase + voff land at LDS byte address lds_dst + 16 l (lds_dst, sbase wave-uniform).
 // M0 carries the LDS base and is compiler-reserved: written and restored in the same statement (cdna_hip_programming.md, inline asm)
@@ -2857,69 +2048,9 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
     unsigned long long* my_stamps = nullptr;
     const auto flush_stamps = [] {};
 #endif
-    if (PNR_WG_GLDS && part < 2) {
+    if (part < 2) {
         wgrad_dw2_glds<NS>(P, lds_raw, part, nb, s_begin, s_end, slab, tid, my_stamps);
         flush_stamps();
-    } else if (part < 2) {
-        // dW2[:, 128 part .. +128] = dZ2^T . H1[:, that half]; waves 4 x 2, each 64 (o) x 64 (i)
-        __bf16* ta = lds;                        // dZ2 chunk [64][256], stride kTrH
-        __bf16* tb = lds + kWgChunk * kTrH;      // H1 chunk [64][128], stride kTrHalf
-        const int wo = w >> 1, wi = w & 1;
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-        WG_STAMP(0);
-        int ci = 0;
-        WgChunk<kMlpHid> ca; WgChunk<128> cb;
-        ca.load(P.dz2 + nb, kMlpHid, s_begin, s_end, tid);
-        cb.load(P.h1 + nb + 128 * part, kMlpHid, s_begin, s_end, tid);
-        for (long long s = s_begin; s < s_end; s += kWgChunk) {
-            mlp_barrier();                                         // every wave is done with the previous chunk
-            if (ci < 17) WG_STAMP(1 + ci);
-            ++ci;
-            ca.store(ta, kTrH, tid); cb.store(tb, kTrHalf, tid);
-            mlp_barrier();
-            if (s + kWgChunk < s_end) {                              // the next chunk travels while this one is multiplied
-                ca.load(P.dz2 + nb, kMlpHid, s + kWgChunk, s_end, tid);
-                cb.load(P.h1 + nb + 128 * part, kMlpHid, s + kWgChunk, s_end, tid);
-            }
-            // Tried and dropped (r03h / r03i, each bit-identical, none faster: 35.0-35.6 us against 35.1): two chunks in flight (two register
-            // sets), two sets of LDS tiles with one barrier per chunk, and the two waves of a SIMD staging / multiplying in opposite order.
-            // Counters of the kernel: LDS active 20 % of the time (3 % of that bank conflicts), MFMA busy 18.5 %, waves waiting 41 %.
-            // the fragments of k-step ks + 1 are read before the MFMAs of k-step ks are issued (16 more registers): left to the
-            // compiler, every k-step began with the round trip of its own transposed reads (r03i)
-            bf16x8 fa[2][2], fb[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) fa[0][a] = wg_frag32(ta, kTrH, 0, 64 * wo + 32 * a, lane);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) fb[0][b] = wg_frag32(tb, kTrHalf, 0, 64 * wi + 32 * b, lane);
-#pragma unroll
-            for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-                if (ks + 1 < kWgChunk / 16) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) fa[(ks + 1) & 1][a] = wg_frag32(ta, kTrH, 16 * (ks + 1), 64 * wo + 32 * a, lane);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) fb[(ks + 1) & 1][b] = wg_frag32(tb, kTrHalf, 16 * (ks + 1), 64 * wi + 32 * b, lane);
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        WG_STAMP(20);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-                wg_store_block(slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
-        WG_STAMP(22);
     } else if (P.w3part) {
         // ---- with the fused kernel's layer-3 partials the fourth role has next to nothing to do (9 us of adding 16 partial rows), and dW1 was the
         // longest role (27 us against dW2's 23.5: five MFMAs per wave and k-step against four, tools/wgrad_stamps.py): roles 2 and 3 each take
@@ -2927,96 +2058,8 @@ __global__ __launch_bounds__(kWgThreads) void mlp_wgrad_kernel(const MlpWgradPar
         // (column groups: blocks 0-2 | blocks 3-4 of X's 160 columns).  Every element's products are accumulated in the same order as in the
         // one-role form below: the same bits.
         const int half = part - 2;
-        if (PNR_WG_GLDS) {
-            wgrad_dw1_glds<NS>(P, lds_raw, half, nb, s_begin, s_end, slab, tid, my_stamps);
-        } else {
-            __bf16* ta = lds;                        // dZ1 chunk, this half's columns: [64][128], stride kTrHalf
-            __bf16* tb = lds + kWgChunk * kTrH;      // X chunk [64][160]: 144 inputs | 1 | 15 zeros
-            WG_STAMP(0);
-            const int rb = w & 3, cg = w >> 2;       // row block of the half, column group
-            f32x16 acc[3];
-    #pragma unroll
-            for (int b = 0; b < 3; ++b)
-    #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-            WgChunk<128> ca; WgChunk<kMlpInPad> cb;
-            ca.load(P.dz1 + nb + 128 * half, kMlpHid, s_begin, s_end, tid);
-            cb.load(P.xs, kMlpInPad, s_begin, s_end, tid);
-            for (long long s = s_begin; s < s_end; s += kWgChunk) {
-                mlp_barrier();
-                ca.store(ta, kTrHalf, tid); cb.store(tb, kTrX, tid);
-                if (tid < kWgChunk) {                                     // columns 144..159: a one (real rows only), zeros
-                    bf16x8 one = {(__bf16)((s + tid < s_end) ? 1.0f : 0.0f), (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                    bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-                    *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad) = one;
-                    *reinterpret_cast<bf16x8*>(tb + tid * kTrX + kMlpInPad + 8) = zero;
-                }
-                mlp_barrier();
-                if (s + kWgChunk < s_end) {
-                    ca.load(P.dz1 + nb + 128 * half, kMlpHid, s + kWgChunk, s_end, tid);
-                    cb.load(P.xs, kMlpInPad, s + kWgChunk, s_end, tid);
-                }
-    #pragma unroll
-                for (int ks = 0; ks < kWgChunk / 16; ++ks) {
-                    const bf16x8 fa = wg_frag32(ta, kTrHalf, 16 * ks, 32 * rb, lane);
-                    if (cg == 0) {
-                        bf16x8 fb[3];
-    #pragma unroll
-                        for (int b = 0; b < 3; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * b, lane);
-    #pragma unroll
-                        for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
-                    } else {
-                        bf16x8 fb[2];
-    #pragma unroll
-                        for (int b = 0; b < 2; ++b) fb[b] = wg_frag32(tb, kTrX, 16 * ks, 32 * (3 + b), lane);
-    #pragma unroll
-                        for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[b], acc[b], 0, 0, 0);
-                    }
-                }
-            }
-            {
-                const int row0 = 128 * half + 32 * rb;
-                if (cg == 0) {
-    #pragma unroll
-                    for (int b = 0; b < 3; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * b, kMlpInPad, acc[b], lane);
-                } else {
-    #pragma unroll
-                    for (int b = 0; b < 2; ++b) wg_store_block(slab + kGW1, kMlpInPad, row0, 32 * (3 + b), kMlpInPad, acc[b], lane);
-                    // column 144 of the product = db1: lane c == 16 of column block 4
-                    if ((lane & 31) == 16) {
-                        const int hh = lane >> 5;
-    #pragma unroll
-                        for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[1][i];
-                    }
-                }
-            }
-        }
-        if (!PNR_WG_GLDS) {   // the fused kernel's per-tile layer-3 products of this slice, added in tile order: each of the two roles takes half of the
-            // elements, a thread a quad of them — the 16 tiles' 16-byte pieces requested together (one round trip instead of the
-            // 2 x 4 of an element at a time, eight tiles in flight).  (The glds roles each add a QUARTER, while their first chunk travels.)
-            static_assert(kW3PartFloats % 16 == 0, "quarters of whole quads");
-            const long long t0 = s_begin / kWgChunk, t1 = (s_end + kWgChunk - 1) / kWgChunk;
-            const size_t stride = (size_t)P.n_nets * kW3PartFloats;
-            for (int q = half * (kW3PartFloats / 8) + tid; q < (half + 1) * (kW3PartFloats / 8); q += kWgThreads) {
-                const float* pp = P.w3part + ((size_t)t0 * P.n_nets + blockIdx.z) * kW3PartFloats + 4 * q;
-                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-                long long t = t0;
-                for (; t + 16 <= t1; t += 16) {
-                    f32x4 x[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) x[j] = *reinterpret_cast<const f32x4*>(pp + (size_t)(t - t0 + j) * stride);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) sum += x[j];
-                }
-                for (; t < t1; ++t) sum += *reinterpret_cast<const f32x4*>(pp + (size_t)(t - t0) * stride);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = 4 * q + j;
-                    slab[e < kMlpHead * kMlpHid ? kGW3 + e : (e < kMlpHead * kMlpHid + kMlpHid ? kGB2 + (e - kMlpHead * kMlpHid) : kGB3 + (e - kMlpHead * kMlpHid - kMlpHid))] = sum[j];
-                }
-            }
-        }
-        if (PNR_WG_GLDS) flush_stamps(); else { WG_STAMP(22); }
+        wgrad_dw1_glds<NS>(P, lds_raw, half, nb, s_begin, s_end, slab, tid, my_stamps);
+        flush_stamps();
     } else if (part == 2) {
         // dW1 = dZ1^T . X (144 columns) and db1 = dZ1^T . 1 (the tile's column 144 is all ones); wave w: rows 32w..
         __bf16* ta = lds;                        // dZ1 chunk [64][256]

@@ -7,7 +7,7 @@
 // arithmetic in the same order), draws the action in the policy head's epilogue, steps its 64 envs (the body of
 // step_kernel's loop: pnr_device.h), and makes the next input tile from the observation while it is still in LDS.  Nothing
 // crosses a launch boundary inside the rollout, the env state stays on the CU, and each wave keeps its blocks of BOTH nets'
-// W2 in registers for all T steps (the weight-stationary form of mlp_train_kernel: with one workgroup per CU there is no
+// W2 in registers for all T steps (weight-stationary: with one workgroup per CU there is no
 // second workgroup to hide the L2 latency of a weight stream behind).  Outputs are those of the two-launch form, bit for bit
 // (tests/test_gpu_ppo.py::test_resident_rollout_equals_the_two_launch_sampler).
 // Kinematic mode, env-major layouts (pnr_env_rollout_params checks); grid = ceil(n / 64) workgroups of 512 threads.
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void ppo_rollout_kernel(const Rollo
 
     for (int t = 0; t < S.T; ++t) {
         // the thread id as the loop body sees it: opaque, so that per-thread global addresses are formed where they are used
-        // instead of living in registers around the loop (mlp_train_kernel)
+        // instead of living in registers around the loop
         int tv = tid;
         asm volatile("" : "+v"(tv));
         const long long tn = (long long)t * n;

@@ -152,6 +152,30 @@ def test_missing_library_raises(monkeypatch, tmp_path):
         _lib.load_library()
 
 
+def test_library_built_from_other_sources_is_refused(tmp_path):
+    """The build's identity is baked into the binary (content fingerprints per translation unit, -DPNR_UNIT_FINGERPRINT), not
+    read off file times: a copy of the package whose source was touched after the build must refuse to load its library."""
+    import shutil
+    import subprocess
+    import sys
+    from pioneer_amd import _lib
+    assert not _lib._stale(), "the in-tree library must carry the fingerprints of the in-tree sources"
+    assert _lib.load_library().pnr_build_fingerprint().decode() == _lib.tree_fingerprint()
+    assert _lib.embedded_fingerprints(_lib.LIB_PATH) == {_lib.UNIT_TAGS[u]: _lib.unit_fingerprint(u) for u in _lib.UNITS}
+    root = tmp_path / "copy"
+    shutil.copytree(os.path.join(ROOT, "pioneer_amd"), root / "pioneer_amd", ignore=shutil.ignore_patterns("*.o", "__pycache__", "libpioneer_amd_*.so"))
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    probe = "from pioneer_amd import _lib; _lib.load_library(); print('loaded', _lib._stale())"
+    env = {k: v for k, v in os.environ.items() if k != "PNR_LIB_PATH"}
+    r = subprocess.run([sys.executable, "-c", probe], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "loaded False" in r.stdout, r.stderr[-2000:]
+    src = root / "pioneer_amd" / "csrc" / "pnr_device.h"
+    src.write_text(src.read_text() + "\n// touched after the build\n")
+    os.utime(src, (1, 1))                                     # .. and older than the library by its file time
+    r = subprocess.run([sys.executable, "-c", probe], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "was built from other sources" in r.stderr, r.stdout + r.stderr[-2000:]
+
+
 def test_spaces_and_helpers():
     from pioneer_amd.spaces import Box
     from pioneer_amd.env import arr2str

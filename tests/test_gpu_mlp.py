@@ -280,10 +280,7 @@ def test_adam_refuses_a_gradient_that_is_not_16_byte_aligned():
 def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
     """pnr_mlp_gather + train_step(xs_in=...) against train_step(obs, idx, filt): the same filter arithmetic and rounding,
     the same record rows, so gradients, loss means and updated weights are bit-identical — on a minibatch that is a slice
-    of a longer gathered epoch (pointer offsets into the gathered arrays).  In the PNR_MLP_STATIONARY=1 variant
-    (test_alternative_forms_of_the_fused_kernel_are_bit_identical runs this test on it) the two calls also run two different
-    kernels: mlp_forward_kernel<true> (one workgroup per tile, weights streamed) and mlp_train_kernel (one workgroup per CU
-    walking its tiles — one, a partial last one, or up to three of them at these sizes — with its weights in registers)."""
+    of a longer gathered epoch (pointer offsets into the gathered arrays)."""
     import copy
     from pioneer_amd.mlp import HipMLP
     R, lr = 20000, 1e-3
@@ -323,27 +320,6 @@ def test_pre_gathered_epoch_equals_the_in_kernel_gather(B):
         mlp.adam(flat, 1.0, lr); mlp_g.adam(flat_g, 1.0, lr)
     for a, b in zip(mlp.params, mlp_g.params):
         assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("switch", ["-DPNR_MLP_STATIONARY=1", "-DPNR_MLP_FAT=1"])
-def test_alternative_forms_of_the_fused_kernel_are_bit_identical(tmp_path, switch):
-    """The measured alternatives of the fused learner kernel that stay in the tree behind a build switch — mlp_train_kernel
-    (-DPNR_MLP_STATIONARY=1: weight-stationary, half-tile-pipelined; r03f: 58 us against 51) and mlp_fused4_kernel (-DPNR_MLP_FAT=1: four
-    64-row waves per tile, three tiles per CU; r04: 64.9 us against 49.8) — produce the same bits as mlp_forward_kernel<true>: the
-    learner translation unit is rebuilt with the switch and the comparison above, whose pre-gathered calls then run the
-    alternative, is run on that library in a child process."""
-    import os
-    import subprocess
-    import sys
-    from pioneer_amd import _lib
-    out = str(tmp_path / "libpioneer_amd_variant.so")
-    _lib.build_library(units=("pnr_learn.hip",), extra_flags=[switch], out_path=out)
-    env = dict(os.environ, PNR_LIB_PATH=out)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_mlp.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "pre_gathered or graph_replay", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "4 passed" in r.stdout, r.stdout[-1000:]
 
 
 # ---- float32-accurate operands (r04): every MFMA operand as 2 / 3 bf16 planes (include/pioneer_amd.h, pnr_mlp_pack) -----------------

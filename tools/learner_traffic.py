@@ -15,7 +15,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pioneer_amd import _lib  # noqa: E402
 
-ROLES = {"mlp_forward_kernelILb1": "fused", "mlp_train_kernel": "fused", "mlp_wgrad_kernel": "wgrad", "mlp_adam_kernel": "adam"}      # (mangled-name substrings)
+ROLES = {"mlp_forward_kernelILb1": "fused", "mlp_wgrad_kernel": "wgrad", "mlp_adam_kernel": "adam"}      # (mangled-name substrings)
 
 
 def main():
