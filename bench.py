@@ -727,7 +727,7 @@ def run_rank(args):
         if ppo_f32:
             out["ppo_loop_f32"] = ppo_f32
         if ppo_x2:
-            out["ppo_loop_bf16x2"] = ppo_x2
+            out["ppo_loop_bf16x3"] = ppo_x2
         if ppo_large:
             out["ppo_loop_large_minibatch"] = ppo_large
         if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
@@ -766,7 +766,7 @@ def run_rank(args):
                 ppo_f32 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "f32")
                 # two planes: 16 significant bits per operand — heads within 8e-6, gradients within 1.4e-5 of float32
                 # (profiles/r04_f_accuracy_by_precision.jsonl), between the two in speed
-                ppo_x2 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "bf16x2")
+                ppo_x2 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "bf16x3")
             if args.ppo_large_minibatch > 0 and args.ppo_large_minibatch != args.ppo_minibatch:
                 ppo_large = ppo_leg(args.ppo_iters, args.ppo_large_minibatch)
         except Exception as exc:

@@ -49,9 +49,9 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("--iterations", type=int, default=1000)
     tr.add_argument("--envs-per-worker", type=int, default=4096)
     tr.add_argument("--mode", choices=["kinematic", "dynamic"], default="kinematic")
-    tr.add_argument("--precision", choices=["bf16", "bf16x2", "f32", "torch"], default="bf16",
+    tr.add_argument("--precision", choices=["bf16", "f32", "bf16x3", "torch"], default="bf16",
                     help="the learner's arithmetic: bf16 MFMA operands (default), float32-accurate products on the same kernels "
-                         "('f32': three bf16 planes per operand; 'bf16x2': two), or the float32 torch formulation — the reference's "
+                         "('f32': two scaled fp16 planes per operand; 'bf16x3': three bf16 planes), or the float32 torch formulation — the reference's "
                          "learner is float32 torch (pioneer_knm_train.py:47)")
     tr.add_argument("--restore", default=None, metavar="CHECKPOINT", help="start every trial from this PPOTrainer.save() file")
     tr.add_argument("--trial-parallel", action="store_true",

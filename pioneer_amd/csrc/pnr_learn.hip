@@ -130,6 +130,7 @@ int pnr_mlp_forward(int64_t batch, const float* obs, const int64_t* idx, const f
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: the four filter vectors come together or not at all");
     if ((h1 == nullptr) != (h2 == nullptr)) return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_forward: h1 and h2 come together");
     MlpFwdParams P = {};
+    P.gscale = 1.f;
     P.obs = obs; P.idx = reinterpret_cast<const long long*>(idx); P.f_loc = f_loc; P.f_inv = f_inv; P.f_lo = f_lo; P.f_hi = f_hi;
     P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
     P.xs = static_cast<__bf16*>(xs); P.h1 = static_cast<__bf16*>(h1); P.h2 = static_cast<__bf16*>(h2);
@@ -238,6 +239,7 @@ int pnr_mlp_act(int64_t batch, const float* obs, const float* f_loc, const float
     if (a_max && (!env_actions || env_actions == actions))
         return fail(nullptr, PNR_ERR_INVALID, "pnr_mlp_act: clipping (a_max) needs its own env_actions buffer");
     MlpFwdParams P = {};
+    P.gscale = 1.f;
     P.obs = obs; P.f_loc = f_loc; P.f_inv = f_inv; P.f_lo = f_lo; P.f_hi = f_hi;
     P.wpack = static_cast<const __bf16*>(wpack); P.bias = bias; P.head = head;
     P.B = batch; P.first_net = 0; P.n_nets = kMlpNets;
@@ -298,7 +300,8 @@ int pnr_mlp_backward(int64_t batch, const float* g_head, const void* wpack, cons
     Bp.g_head = g_head; Bp.wpack = static_cast<const __bf16*>(wpack); Bp.h1 = static_cast<const __bf16*>(h1);
     Bp.h2 = static_cast<const __bf16*>(h2); Bp.dz1 = static_cast<__bf16*>(dz1); Bp.dz2 = static_cast<__bf16*>(dz2); Bp.B = batch;
     hipLaunchKernelGGL(mlp_backward_data_kernel, dim3((unsigned)((batch + kMlpBM - 1) / kMlpBM), kMlpNets), dim3(kMlpThreads), 0, st, Bp);
-    MlpWgradParams Wp;
+    MlpWgradParams Wp = {};
+    Wp.gscale = 1.f;
     Wp.g_head = g_head; Wp.xs = static_cast<const __bf16*>(xs); Wp.h1 = Bp.h1; Wp.h2 = Bp.h2; Wp.dz1 = Bp.dz1; Wp.dz2 = Bp.dz2;
     Wp.slabs = slabs; Wp.B = batch; Wp.slice_rows = rows; Wp.first_net = 0; Wp.w3part = nullptr; Wp.n_nets = kMlpNets; Wp.stamps = nullptr;
     Wp.act_plane = 0; Wp.xs_plane = 0;
@@ -452,6 +455,7 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     F.dz1 = static_cast<__bf16*>(s->dz1); F.dz2 = static_cast<__bf16*>(s->dz2);
     F.act_plane = (size_t)kMlpNets * (size_t)B * kMlpHid;            // planes of h1 / dz1 / dz2: [planes][2][B][256]
     F.xs_plane = s->xs_in_plane > 0 ? (size_t)s->xs_in_plane : (size_t)B * kMlpInPad;
+    F.gscale = mlp_grad_scale(planes, B);
     // layer 3's weight gradients per tile from the fused kernel (then H2 never leaves the CU) when the caller gave the scratch for it
     if (s->w3_partials) {
         if (s->w3_partial_floats < (long long)tiles.x * nets * kW3PartFloats)
@@ -470,14 +474,15 @@ int pnr_mlp_train_step(const pnr_mlp_step* s, void* stream)
     if (s->flat_grad)       // no Adam launch here (the caller all-reduces first): the loss means get a small launch of their own
         hipLaunchKernelGGL(ppo_loss_finish_split_kernel, dim3(1), dim3(256), 0, st, s->partials, prow, B, s->means, (float*)nullptr,
                            s->kl_coeff, s->entropy_coeff, s->vf_loss_coeff);
-    MlpWgradParams Wp;
+    MlpWgradParams Wp = {};
+    Wp.gscale = 1.f;
     Wp.g_head = s->g_head; Wp.xs = F.xs_in ? F.xs_in : F.xs; Wp.h1 = F.h1; Wp.h2 = F.h2; Wp.dz1 = F.dz1; Wp.dz2 = F.dz2;
     Wp.slabs = s->slabs; Wp.B = B; Wp.slice_rows = rows; Wp.first_net = s->first_net; Wp.w3part = F.w3part; Wp.n_nets = nets;
     Wp.stamps = nullptr;
 #if PNR_MLP_STAMPS
     Wp.stamps = g_wg_stamps;
 #endif
-    Wp.act_plane = F.act_plane; Wp.xs_plane = F.xs_plane;
+    Wp.act_plane = F.act_plane; Wp.xs_plane = F.xs_plane; Wp.gscale = F.gscale;
     const dim3 wgrid((unsigned)slices, kWgParts, nets);
     if (planes == 1) hipLaunchKernelGGL(mlp_wgrad_kernel<1>, wgrid, dim3(kWgThreads), 0, st, Wp);
     else if (planes == 2) hipLaunchKernelGGL(mlp_wgrad_kernel<2>, wgrid, dim3(kWgThreads), 0, st, Wp);

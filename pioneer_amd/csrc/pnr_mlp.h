@@ -147,38 +147,6 @@ struct MlpNetParams {             // float32 master parameters of one net (torch
     int n3;                             // 12 (policy) or 1 (value)
 };
 
-struct MlpPackParams { MlpNetParams net[kMlpNets]; __bf16* wpack; float* bias; int planes; };   // wpack: [planes][2][kPackElems]
-
-// One thread per packed element; the transposes and the zero padding happen here, once per update.
-__global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpPackParams P)
-{
-    const int net = blockIdx.y;
-    const MlpNetParams& N = P.net[net];
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    __bf16* wp = P.wpack + (size_t)net * kPackElems;
-    if (e < kPackElems) {
-        // e walks the SOURCE matrices in row-major order; the destination is the fragment-native position
-        float v; int dst;
-        if (e < kOffW2) { const int o = e / kMlpInPad, k = e % kMlpInPad; v = k < kMlpIn ? N.w1[o * kMlpIn + k] : 0.f; dst = kOffW1 + frag32_off(o, k, kMlpInPad / 16); }
-        else if (e < kOffW3) { const int r = e - kOffW2, o = r / kMlpHid, i = r % kMlpHid; v = N.w2[r]; dst = kOffW2 + frag32_off(o, i, kMlpHid / 16); }
-        else if (e < kOffW2T) { const int r = (e - kOffW3) / kMlpHid, f = (e - kOffW3) % kMlpHid; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3 + frag16_off(r, f); }
-        else if (e < kOffW3T) { const int i = (e - kOffW2T) / kMlpHid, o = (e - kOffW2T) % kMlpHid; v = N.w2[o * kMlpHid + i]; dst = kOffW2T + frag32_off(i, o, kMlpHid / 16); }
-        else { const int f = (e - kOffW3T) / kMlpHead, r = (e - kOffW3T) % kMlpHead; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3T + frag32_off(f, r, 1); }
-        for (int pl = 0; pl < P.planes; ++pl) {          // plane pl carries what planes 0 .. pl - 1 left of the value
-            const __bf16 b = (__bf16)v;
-            wp[pl * kWPlane + dst] = b;
-            v -= (float)b;
-        }
-    } else if (e < kPackElems + kBiasElems) {
-        const int b = e - kPackElems;
-        float v;
-        if (b < kMlpHid) v = N.b1[b];
-        else if (b < 2 * kMlpHid) v = N.b2[b - kMlpHid];
-        else v = (b - 2 * kMlpHid) < N.n3 ? N.b3[b - 2 * kMlpHid] : 0.f;
-        P.bias[net * kBiasElems + b] = v;
-    }
-}
-
 // tanh through one exp2 and one reciprocal: 1 - 2 / (e^{2x} + 1); saturates correctly at +-inf.  Absolute error
 // ~1e-7, far below the bf16 rounding of the stored activation.
 __device__ __forceinline__ float tanh_fast(float x)
@@ -213,25 +181,94 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 // Every tensor that is an MFMA operand exists as NS planes of the bf16 layout (packed weights, input rows, the LDS tiles, the saved
 // activations and gradients); biases, heads, the loss, slabs, Adam and the master weights are float32 as before.  NS = 1 is the
 // bf16 path, instruction for instruction what it was.
-template <int NS>
-__device__ __forceinline__ void split_quad(const float (&v)[4], bf16x4_t (&pk)[NS])
+// ---- r05: NS = 2 is TWO FP16 PLANES, power-of-two scaled — the float32-accurate path ("f32").  An fp16 number carries 11
+// significant bits, so two planes carry 22 of float32's 24 and the three products (0,0), (0,1), (1,0) leave an operand error of
+// 2^-22: measured against float64 the heads are at 2.4e-7 and the weight gradients at 1.5-3.4e-7 relative, BELOW what a float32
+// GEMM's own accumulation leaves (torch float32: 4.3e-7 / 4.4-6.7e-7; tools/split_accuracy.py) — at HALF the
+// MFMAs and two thirds of the bytes of the three-bf16-plane form (NS = 3, kept: exact 24-bit split, no range caveat).  fp16's
+// exponent range is the price: every operand tensor is stored multiplied by a power of two (exact; the accumulators are divided
+// by the product of the two scales, also exact) so that residual planes stay out of the subnormals, and is clamped to +-65504:
+//   weights x 2^8 (|w| < 255), activations tanh(.) x 2^8, net inputs x 2^4 (|x| < 4094: the filter clamps to +-10; raw obs <= 126),
+//   gradients dZ, G x gscale = 4 * 2^ceil(log2 B) (per-sample |d loss / d z| < 16 384 before the 1 / B; larger ones saturate —
+//   a float32 learner would be taking a step of that size, i.e. has already diverged).
+// Buffers keep their __bf16 element type (16-bit payloads); Fmt<NS> says what the bits mean.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NS> struct Fmt {
+    static constexpr bool kHalf = NS == 2;
+    static constexpr float kSW = kHalf ? 256.f : 1.f;      // weights
+    static constexpr float kSH = kHalf ? 256.f : 1.f;      // activations
+    static constexpr float kSX = kHalf ? 16.f : 1.f;       // net inputs
+};
+constexpr float kHalfMax = 65504.f;
+__host__ __device__ inline float mlp_grad_scale(int planes, long long B)      // gscale of a batch of B samples (1 unless planes == 2)
 {
-    float r[4] = {v[0], v[1], v[2], v[3]};
+    if (planes != 2) return 1.f;
+    float g = 4.f;
+    for (long long n = 1; n < B; n <<= 1) g *= 2.f;
+    return g;
+}
+__device__ __forceinline__ __bf16 half_bits(float v) { return __builtin_bit_cast(__bf16, (_Float16)v); }
+__device__ __forceinline__ float half_value(__bf16 b) { return (float)__builtin_bit_cast(_Float16, b); }
+// v * scale as NS planes: bf16 planes p0 = bf16(x), p1 = bf16(x - p0), .. (scale must be 1); fp16 planes of clamp(v * scale)
+template <int NS>
+__device__ __forceinline__ void split_quad(const float (&v)[4], bf16x4_t (&pk)[NS], float scale = 1.f)
+{
+    if constexpr (Fmt<NS>::kHalf) {
+        float r[4];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        pk[s] = (bf16x4_t){(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
-        if (s + 1 < NS) {
+        for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_fmed3f(v[j] * scale, -kHalfMax, kHalfMax);
+        pk[0] = (bf16x4_t){half_bits(r[0]), half_bits(r[1]), half_bits(r[2]), half_bits(r[3])};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] -= (float)pk[s][j];
+        for (int j = 0; j < 4; ++j) r[j] -= half_value(pk[0][j]);
+        pk[1] = (bf16x4_t){half_bits(r[0]), half_bits(r[1]), half_bits(r[2]), half_bits(r[3])};
+    } else {
+        float r[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            pk[s] = (bf16x4_t){(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+            if (s + 1 < NS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] -= (float)pk[s][j];
+            }
         }
     }
 }
 template <int NS>
-__device__ __forceinline__ void split_scalar(float v, __bf16 (&p)[NS])
+__device__ __forceinline__ void split_scalar(float v, __bf16 (&p)[NS], float scale = 1.f)
 {
-    float r = v;
+    if constexpr (Fmt<NS>::kHalf) {
+        float r = __builtin_amdgcn_fmed3f(v * scale, -kHalfMax, kHalfMax);
+        p[0] = half_bits(r); r -= half_value(p[0]); p[1] = half_bits(r);
+    } else {
+        float r = v;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { p[s] = (__bf16)r; r -= (float)p[s]; }
+        for (int s = 0; s < NS; ++s) { p[s] = (__bf16)r; r -= (float)p[s]; }
+    }
+}
+// the value NS planes add up to (the float32 original for bf16 planes; its 22-bit neighbour / scale for fp16 planes)
+template <int NS>
+__device__ __forceinline__ f32x4 planes_value(const bf16x4_t (&pk)[NS], float inv_scale = 1.f)
+{
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = NS - 1; s >= 0; --s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] += Fmt<NS>::kHalf ? half_value(pk[s][j]) : (float)pk[s][j];
+    if constexpr (Fmt<NS>::kHalf) x *= inv_scale;
+    return x;
+}
+// the MFMAs on 16-bit payloads: bf16, or fp16 (NS == 2)
+template <bool HALF>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    if constexpr (HALF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool HALF>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c)
+{
+    if constexpr (HALF) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 // the plane pairs of a product in the order they are accumulated: the large term first (it may carry the bias as its C operand)
 template <int NS> struct SplitPairs;
@@ -239,6 +276,45 @@ template <> struct SplitPairs<1> { static constexpr int n = 1; static constexpr 
 template <> struct SplitPairs<2> { static constexpr int n = 3; static constexpr int a[3] = {0, 0, 1}, b[3] = {0, 1, 0}; };
 template <> struct SplitPairs<3> { static constexpr int n = 6; static constexpr int a[6] = {0, 0, 1, 0, 2, 1}, b[6] = {0, 1, 0, 2, 0, 1}; };
 constexpr int kMlpMaxPlanes = 3;
+
+struct MlpPackParams { MlpNetParams net[kMlpNets]; __bf16* wpack; float* bias; int planes; };   // wpack: [planes][2][kPackElems]
+
+// One thread per packed element; the transposes and the zero padding happen here, once per update.
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpPackParams P)
+{
+    const int net = blockIdx.y;
+    const MlpNetParams& N = P.net[net];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    __bf16* wp = P.wpack + (size_t)net * kPackElems;
+    if (e < kPackElems) {
+        // e walks the SOURCE matrices in row-major order; the destination is the fragment-native position
+        float v; int dst;
+        if (e < kOffW2) { const int o = e / kMlpInPad, k = e % kMlpInPad; v = k < kMlpIn ? N.w1[o * kMlpIn + k] : 0.f; dst = kOffW1 + frag32_off(o, k, kMlpInPad / 16); }
+        else if (e < kOffW3) { const int r = e - kOffW2, o = r / kMlpHid, i = r % kMlpHid; v = N.w2[r]; dst = kOffW2 + frag32_off(o, i, kMlpHid / 16); }
+        else if (e < kOffW2T) { const int r = (e - kOffW3) / kMlpHid, f = (e - kOffW3) % kMlpHid; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3 + frag16_off(r, f); }
+        else if (e < kOffW3T) { const int i = (e - kOffW2T) / kMlpHid, o = (e - kOffW2T) % kMlpHid; v = N.w2[o * kMlpHid + i]; dst = kOffW2T + frag32_off(i, o, kMlpHid / 16); }
+        else { const int f = (e - kOffW3T) / kMlpHead, r = (e - kOffW3T) % kMlpHead; v = r < N.n3 ? N.w3[r * kMlpHid + f] : 0.f; dst = kOffW3T + frag32_off(f, r, 1); }
+        if (P.planes == 2) {                             // two fp16 planes of the weight x 2^8 (Fmt<2>)
+            __bf16 b[2];
+            split_scalar<2>(v, b, Fmt<2>::kSW);
+            wp[dst] = b[0]; wp[kWPlane + dst] = b[1];
+        } else {
+            for (int pl = 0; pl < P.planes; ++pl) {      // plane pl carries what planes 0 .. pl - 1 left of the value
+                const __bf16 b = (__bf16)v;
+                wp[pl * kWPlane + dst] = b;
+                v -= (float)b;
+            }
+        }
+    } else if (e < kPackElems + kBiasElems) {
+        const int b = e - kPackElems;
+        float v;
+        if (b < kMlpHid) v = N.b1[b];
+        else if (b < 2 * kMlpHid) v = N.b2[b - kMlpHid];
+        else v = (b - 2 * kMlpHid) < N.n3 ? N.b3[b - 2 * kMlpHid] : 0.f;
+        P.bias[net * kBiasElems + b] = v;
+    }
+}
+
 // tanh of accumulator quad q (four consecutive features of one sample), rounded to bf16
 template <class ACC>
 __device__ __forceinline__ bf16x4_t tanh_quad(const ACC& acc, int q)
@@ -454,6 +530,7 @@ struct MlpFwdParams {
     float* w3part;             // [tiles * nets][kW3PartFloats] layer 3's weight-gradient partials per tile (then h2 may be null), or null
     size_t act_plane;          // NS > 1: elements between two planes of h1 / h2 / dz1 / dz2 ([NS][2][B][256]: 2 B 256)
     size_t xs_plane;           // NS > 1: elements between two planes of xs_in
+    float gscale;              // NS == 2: the power of two the gradient planes (G, dZ2, dZ1) are stored multiplied by (mlp_grad_scale); else 1
     unsigned long long* stamps; // PNR_MLP_STAMPS builds only: [workgroups][4 waves][kMlpStampSlots] cycle stamps, or null
 };
 
@@ -526,8 +603,8 @@ struct MlpGemm1 {
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
 #pragma unroll
                 for (int cb = 0; cb < kMlpCB; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks % D][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb],
-                                                                      (ks == 0 && pi == 0 && init) ? *init : acc[cb], 0, 0, 0);
+                    acc[cb] = mfma32<Fmt<NS>::kHalf>(a[ks % D][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb],
+                                                     (ks == 0 && pi == 0 && init) ? *init : acc[cb]);
         }
     }
 };
@@ -580,11 +657,12 @@ __device__ __forceinline__ bf16x8 wg_frag16(const __bf16* tile, int tstride, int
 // weight-gradient kernel's third role just adds a slice's 16 partial rows in tile order.  Both forms define the slice sum the same way
 // (per 64-sample tile a product chained over its two 32-sample k-steps from zero, the tiles added in order), so they agree bit for bit.
 constexpr int kW3PartFloats = kMlpHead * kMlpHid + kMlpHid + kMlpHead;
+template <bool HALF = false>
 __device__ __forceinline__ bf16x8 bf16x8_ones()
 {
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)1.0f;
+    for (int j = 0; j < 8; ++j) o[j] = HALF ? half_bits(1.0f) : (__bf16)1.0f;
     return o;
 }
 // dW3 (this wave's feature columns 32 w ..) and db3 (wave 0) of one 64-sample tile: G tile [64][16] bf16, H2 tile [64][256] bf16
@@ -593,7 +671,7 @@ template <int NS = 1>
 __device__ __forceinline__ void mlp_tile_w3_products(const __bf16* gtile, int gstride, const __bf16* htile, int hstride, int lane, int w,
                                                      f32x4 (&aw3)[2], f32x4& ab3, int gplane = 0, int hplane = 0)
 {
-    const bf16x8 ones = bf16x8_ones();
+    const bf16x8 ones = bf16x8_ones<Fmt<NS>::kHalf>();
     aw3[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; aw3[1] = aw3[0]; ab3 = aw3[0];
 #pragma unroll
     for (int ks = 0; ks < kMlpBM / 32; ++ks) {
@@ -602,7 +680,7 @@ __device__ __forceinline__ void mlp_tile_w3_products(const __bf16* gtile, int gs
         for (int s = 0; s < NS; ++s) fg[s] = wg_frag16(gtile + s * gplane, gstride, 32 * ks, 0, lane);            // A: rows = head entries
         if (w == 0) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) ab3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[s], ones, ab3, 0, 0, 0);
+            for (int s = 0; s < NS; ++s) ab3 = mfma16<Fmt<NS>::kHalf>(fg[s], ones, ab3);
         }
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -611,7 +689,7 @@ __device__ __forceinline__ void mlp_tile_w3_products(const __bf16* gtile, int gs
             for (int s = 0; s < NS; ++s) fh[s] = wg_frag16(htile + s * hplane, hstride, 32 * ks, 32 * w + 16 * b, lane);
 #pragma unroll
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
-                aw3[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[SplitPairs<NS>::a[pi]], fh[SplitPairs<NS>::b[pi]], aw3[b], 0, 0, 0);
+                aw3[b] = mfma16<Fmt<NS>::kHalf>(fg[SplitPairs<NS>::a[pi]], fh[SplitPairs<NS>::b[pi]], aw3[b]);
         }
     }
 }
@@ -619,7 +697,7 @@ __device__ __forceinline__ void mlp_tile_w3_products(const __bf16* gtile, int gs
 template <int NS = 1>
 __device__ __forceinline__ void mlp_tile_b2_products(const __bf16* ztile, int zstride, int lane, int w, f32x4 (&ab2)[2], int zplane = 0)
 {
-    const bf16x8 ones = bf16x8_ones();
+    const bf16x8 ones = bf16x8_ones<Fmt<NS>::kHalf>();
     ab2[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab2[1] = ab2[0];
 #pragma unroll
     for (int ks = 0; ks < kMlpBM / 32; ++ks)
@@ -628,7 +706,7 @@ __device__ __forceinline__ void mlp_tile_b2_products(const __bf16* ztile, int zs
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const bf16x8 fz = wg_frag16(ztile + s * zplane, zstride, 32 * ks, 32 * w + 16 * b, lane);
-                ab2[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fz, ab2[b], 0, 0, 0);
+                ab2[b] = mfma16<Fmt<NS>::kHalf>(ones, fz, ab2[b]);
             }
 }
 
@@ -710,7 +788,7 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
         gt[sl * kGS + e1] = (__bf16)g1;
     } else {                              // the gradient rows as NS planes (plane s of the tile: + s * kTilePlane)
         __bf16 p0[NS], p1[NS];
-        split_scalar<NS>(g0, p0); split_scalar<NS>(g1, p1);
+        split_scalar<NS>(g0, p0, P.gscale); split_scalar<NS>(g1, p1, P.gscale);
 #pragma unroll
         for (int s = 0; s < NS; ++s) { gt[s * kTilePlane + sl * kGS + e0] = p0[s]; gt[s * kTilePlane + sl * kGS + e1] = p1[s]; }
     }
@@ -760,14 +838,17 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             for (int k = 0; k < 4; ++k) q[r][k] = *reinterpret_cast<const f32x4*>(b + 32 * rowblk(r) + 8 * k + 4 * h);
     };
     // .. as ONE 16-register value: the first MFMA of each column block reads it as its C operand (MlpGemm1::run's `init`)
-    const auto bias16 = [&](const f32x4 (&q)[NRB][4], int r) {
+    // (fp16 planes: times the product's scale — the accumulators hold scale * (W . x + b) until the epilogue divides, both exact)
+    const auto bias16 = [&](const f32x4 (&q)[NRB][4], int r, float scale) {
         f32x16 b;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[4 * k + j] = q[r][k][j];
+            for (int j = 0; j < 4; ++j) b[4 * k + j] = Fmt<NS>::kHalf ? q[r][k][j] * scale : q[r][k][j];
         return b;
     };
+    typedef Fmt<NS> F;
+    constexpr float kS1 = F::kSW * F::kSX, kS2 = F::kSW * F::kSH;     // scale of layer 1's / layer 2's and the head's accumulators
     const auto bias_init = [&](f32x16 (&acc)[kMlpCB], const f32x16 (&b)[NRB]) {       // (timing-only builds that skip a product)
 #pragma unroll
         for (int cb = 0; cb < kMlpCB; ++cb) acc[cb] = b[0];
@@ -870,13 +951,12 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             }
             // 18 bf16 = 36 bytes per thread, 4-byte aligned in the tile: nine dword stores (per plane: the residual goes on)
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
             for (int j = 0; j < CPT; j += 2) {
                 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                bf16x2 pk = {(__bf16)x[j], (__bf16)x[j + 1]};
-                *reinterpret_cast<bf16x2*>(xt + s * kTilePlane + row * kXS + CPT * part + j) = pk;
-                if (s + 1 < NS) { x[j] -= (float)pk[0]; x[j + 1] -= (float)pk[1]; }
+                __bf16 p0[NS], p1[NS];
+                split_scalar<NS>(x[j], p0, F::kSX); split_scalar<NS>(x[j + 1], p1, F::kSX);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x2*>(xt + s * kTilePlane + row * kXS + CPT * part + j) = (bf16x2){p0[s], p1[s]};
             }
         }
         }
@@ -899,7 +979,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     // LDS round trip (3 500 of a tile's 44 000 cycles in the phase stamps)
     bf16x4 h1keep[(FUSED && NS == 1) ? kMlpCB * 4 : 1];
     f32x4 h1keep_f[(FUSED && NS > 1) ? kMlpCB * 4 : 1];        // NS > 1: the float32 values themselves (what the planes add up to)
-    const auto epilogue = [&](bool keep) {
+    const auto epilogue = [&](bool keep, [[maybe_unused]] float inv_scale) {
 #pragma unroll
         for (int cb = 0; cb < kMlpCB; ++cb)
 #pragma unroll
@@ -915,10 +995,12 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                 *reinterpret_cast<bf16x4*>(ht + (32 * colblk(cb) + c) * kHS + 32 * rowblk(cb) + 8 * q + 4 * h) = pk;
                 if constexpr (FUSED) { if (keep) h1keep[4 * cb + q] = pk; }
                 } else {
-                    const f32x2 lo = tanh_fast2((f32x2){acc[cb][4 * q], acc[cb][4 * q + 1]}), hi = tanh_fast2((f32x2){acc[cb][4 * q + 2], acc[cb][4 * q + 3]});
+                    f32x2 z0 = {acc[cb][4 * q], acc[cb][4 * q + 1]}, z1 = {acc[cb][4 * q + 2], acc[cb][4 * q + 3]};
+                    if constexpr (F::kHalf) { z0 *= inv_scale; z1 *= inv_scale; }        // exact: a power of two
+                    const f32x2 lo = tanh_fast2(z0), hi = tanh_fast2(z1);
                     const float t[4] = {lo[0], lo[1], hi[0], hi[1]};
                     bf16x4_t pk[NS];
-                    split_quad<NS>(t, pk);
+                    split_quad<NS>(t, pk, F::kSH);
 #pragma unroll
                     for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * kTilePlane + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
                     if constexpr (FUSED) { if (keep) h1keep_f[4 * cb + q] = (f32x4){t[0], t[1], t[2], t[3]}; }
@@ -936,12 +1018,12 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     {
         f32x16 b16[NRB];
 #pragma unroll
-        for (int r = 0; r < NRB; ++r) b16[r] = bias16(bq1, r);
+        for (int r = 0; r < NRB; ++r) b16[r] = bias16(bq1, r, kS1);
         if (PNR_MLP_DIAG & 8) bias_init(acc, b16);
         else g1.run(xt, acc, lane, [] {}, &b16[0]);
     }
     MLP_STAMP(2);                         // layer-1 product issued
-    if (!(PNR_MLP_DIAG & 32)) epilogue(true);
+    if (!(PNR_MLP_DIAG & 32)) epilogue(true, 1.f / kS1);
     MLP_STAMP(3);                         // layer-1 epilogue
     // layer 2's bias and first weight fragments are requested ahead of the barrier (and of the tile store behind it)
     f32x4 bq2[NRB][4];
@@ -958,7 +1040,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     // HBM from INSIDE the product, behind its last weight-fragment load, and the tile's record is requested there too
     f32x16 b16_2[NRB];
 #pragma unroll
-    for (int r = 0; r < NRB; ++r) b16_2[r] = bias16(bq2, r);
+    for (int r = 0; r < NRB; ++r) b16_2[r] = bias16(bq2, r, kS2);
     if (PNR_MLP_DIAG & 4) bias_init(acc, b16_2);
     MlpRecordTile<kFwdThreads> rect;
     const bool rec_early = FUSED && !P.idx && !(PNR_MLP_DIAG & 256);
@@ -981,7 +1063,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     MLP_STAMP(6);                         // layer-2 product issued
     mlp_barrier();
     MLP_STAMP(7);
-    if (!(PNR_MLP_DIAG & 32)) epilogue(false);
+    if (!(PNR_MLP_DIAG & 32)) epilogue(false, 1.f / kS2);
     MLP_STAMP(8);                         // layer-2 epilogue
     mlp_barrier();
     MLP_STAMP(9);
@@ -992,6 +1074,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     if (!(PNR_MLP_DIAG & 16) && w < 4) {
         const int r16 = lane & 15, g = lane >> 4;
         f32x4 a3 = *reinterpret_cast<const f32x4*>(bias + 2 * kMlpHid + 4 * g);    // rows 4g .. 4g+3: the accumulators' start
+        if constexpr (F::kHalf) a3 *= kS2;
         const __bf16* w3 = wp + kOffW3 + lane * 8;                    // fragment-native: block ks at ks * 512
         bf16x8 w3f[kMlpHid / 32][NS];
 #pragma unroll
@@ -1007,8 +1090,9 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const bf16x8*>(ht + s * kTilePlane + (16 * w + r16) * kHS + 32 * ks + 8 * g);
 #pragma unroll
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
-                a3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[ks][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]], a3, 0, 0, 0);
+                a3 = mfma16<F::kHalf>(w3f[ks][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]], a3);
         }
+        if constexpr (F::kHalf) a3 *= 1.f / kS2;
         {
             const long long b = row0 + 16 * w + r16;                  // column = sample, rows 4g .. 4g+3 = head entries
             const f32x4 hq = a3;
@@ -1092,9 +1176,9 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         const auto dtanh_split = [&](int cb, int q, const f32x4& hf) {
             float d[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = acc[cb][4 * q + j] * __builtin_fmaf(-hf[j], hf[j], 1.0f);
+            for (int j = 0; j < 4; ++j) d[j] = (F::kHalf ? acc[cb][4 * q + j] * (1.f / F::kSW) : acc[cb][4 * q + j]) * __builtin_fmaf(-hf[j], hf[j], 1.0f);
             bf16x4_t pk[NS];
-            split_quad<NS>(d, pk);
+            split_quad<NS>(d, pk);               // (fp16 planes: d is the gradient times gscale already; the split clamps)
 #pragma unroll
             for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * kTilePlane + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
         };
@@ -1108,14 +1192,10 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                     const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at);
                     *reinterpret_cast<bf16x4*>(at) = dtanh_quad(acc[cb], q, hv);
                     } else {
-                        f32x4 hf = {0.f, 0.f, 0.f, 0.f};
+                        bf16x4_t hv[NS];                                          // the planes add up to the activation (bf16 planes: exactly)
 #pragma unroll
-                        for (int s = NS - 1; s >= 0; --s) {                       // the planes add up to the float32 activation exactly
-                            const bf16x4 hv = *reinterpret_cast<const bf16x4*>(at + s * kTilePlane);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) hf[j] += (float)hv[j];
-                        }
-                        dtanh_split(cb, q, hf);
+                        for (int s = 0; s < NS; ++s) hv[s] = *reinterpret_cast<const bf16x4*>(at + s * kTilePlane);
+                        dtanh_split(cb, q, planes_value<NS>(hv, 1.f / F::kSH));
                     }
                 }
         };
@@ -1128,6 +1208,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         // ---- layer 3's weight-gradient partials of this tile (dW3 = G^T . H2, db3 = G^T . 1), while H2 is still in the tile: this wave's
         // 32 feature columns are the ones only it overwrites below
         float* w3p = P.w3part ? P.w3part + ((size_t)blockIdx.x * P.n_nets + yi) * kW3PartFloats : nullptr;
+        [[maybe_unused]] const float inv_g = 1.f / P.gscale;       // (a power of two: exact)
         if (w3p) {
             f32x4 aw3[2], ab3;
             mlp_tile_w3_products<NS>(gt, kGS, ht, kHS, lane, w, aw3, ab3, kTilePlane, kTilePlane);
@@ -1135,10 +1216,10 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w3p[(4 * g + j) * kMlpHid + 32 * w + 16 * b + c16] = aw3[b][j];
+                for (int j = 0; j < 4; ++j) w3p[(4 * g + j) * kMlpHid + 32 * w + 16 * b + c16] = F::kHalf ? aw3[b][j] * (inv_g * (1.f / F::kSH)) : aw3[b][j];
             if (w == 0 && c16 == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w3p[kMlpHead * kMlpHid + kMlpHid + 4 * g + j] = ab3[j];     // every column of G^T . 1 is db3
+                for (int j = 0; j < 4; ++j) w3p[kMlpHead * kMlpHid + kMlpHid + 4 * g + j] = F::kHalf ? ab3[j] * inv_g : ab3[j];     // every column of G^T . 1 is db3
             }
         }
         // ---- dH2^T = W3^T . G^T (one k-step of 16; the padded head rows are zero), dZ2 in place over H2
@@ -1153,7 +1234,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
 #pragma unroll
                 for (int cb = 0; cb < kMlpCB; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3t[SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb], acc[cb], 0, 0, 0);
+                    acc[cb] = mfma32<F::kHalf>(w3t[SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]][cb], acc[cb]);
         }
         bwd_epilogue();
         const auto b2_products = [&] {                             // db2 = 1^T . dZ2 of this wave's columns 32 w .., now that they hold dZ2
@@ -1162,7 +1243,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                 mlp_tile_b2_products<NS>(ht, kHS, lane, w, ab2, kTilePlane);
                 if ((lane >> 4) == 0) {
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * w + 16 * b + (lane & 15)] = ab2[b][0];
+                    for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * w + 16 * b + (lane & 15)] = F::kHalf ? ab2[b][0] * inv_g : ab2[b][0];
                 }
             }
         };
@@ -1309,14 +1390,24 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGather
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[k] = fminf(fmaxf((x[k] - loc[k]) * inv[k], lo[k]), hi[k]);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (col + k >= kMlpIn) x[k] = 0.f;
+        if (P.planes == 2) {                             // two fp16 planes of the input x 2^4 (Fmt<2>)
+            const float xv[4] = {x[0], x[1], x[2], x[3]};
+            bf16x4_t hp[2];
+            split_quad<2>(xv, hp, Fmt<2>::kSX);
+            *reinterpret_cast<bf16x4*>(P.xs_out + b * kMlpInPad + col) = hp[0];
+            *reinterpret_cast<bf16x4*>(P.xs_out + ((size_t)P.B + b) * kMlpInPad + col) = hp[1];
+        } else {
         bf16x4 pk;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pk[k] = (__bf16)((col + k < kMlpIn) ? x[k] : 0.f);
+        for (int k = 0; k < 4; ++k) pk[k] = (__bf16)x[k];
         *reinterpret_cast<bf16x4*>(P.xs_out + b * kMlpInPad + col) = pk;
         for (int pl = 1; pl < P.planes; ++pl) {          // the residual planes of the split float32 input
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { x[k] = (col + k < kMlpIn) ? x[k] - (float)pk[k] : 0.f; pk[k] = (__bf16)x[k]; }
+            for (int k = 0; k < 4; ++k) { x[k] = x[k] - (float)pk[k]; pk[k] = (__bf16)x[k]; }
             *reinterpret_cast<bf16x4*>(P.xs_out + ((size_t)pl * P.B + b) * kMlpInPad + col) = pk;
+        }
         }
     }
     }
@@ -1455,6 +1546,7 @@ struct MlpWgradParams {
     unsigned long long* stamps; // PNR_MLP_STAMPS builds only (tools/wgrad_stamps.py): [nets][roles][slices][8 waves][kMlpStampSlots], or null
     size_t act_plane;          // NS > 1: elements between two planes of h1 / dz1 / dz2
     size_t xs_plane;           // .. and of xs
+    float gscale;              // NS == 2: what the gradient planes are stored multiplied by (MlpFwdParams::gscale); else 1
 };
 #if PNR_MLP_STAMPS
 #define WG_STAMP(i) do { if (P.stamps && lane == 0) { unsigned long long* sp_ = P.stamps + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + w) * kMlpStampSlots; \
@@ -1707,11 +1799,13 @@ __device__ __forceinline__ void wg_ring_loop(long long s_begin, long long s_end,
 // A wave's 32x32 accumulator block to a row-major float32 matrix through a wave-private LDS tile: 16-byte stores, eight lanes per
 // 128-byte row segment (wg_store_block's one dword per lane cost ~96 cycles of issue per instruction: 6 000 cycles per dW2 wave).
 constexpr int kWgTrS = 36;                                       // floats per row of the transposing tile (144 B: 16-byte aligned)
-__device__ __forceinline__ void wg_store_block_lds(float* scratch, float* __restrict__ m, int ld, int row0, int col0, int ncols, const f32x16& a, int lane)
+// (unscale: the power of two the accumulators are multiplied by on their way out — fp16 planes; 1 otherwise)
+__device__ __forceinline__ void wg_store_block_lds(float* scratch, float* __restrict__ m, int ld, int row0, int col0, int ncols, const f32x16& a, int lane,
+                                                   float unscale = 1.f)
 {
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) scratch[((i & 3) + 8 * (i >> 2) + 4 * h) * kWgTrS + c] = a[i];
+    for (int i = 0; i < 16; ++i) scratch[((i & 3) + 8 * (i >> 2) + 4 * h) * kWgTrS + c] = a[i] * unscale;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private tile: the wave's own DS operations complete in order
     const int r = lane >> 3, q = lane & 7;
 #pragma unroll
@@ -1856,7 +1950,7 @@ __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ri
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][a], fb[ks & 1][b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = mfma32<false>(fa[ks & 1][a], fb[ks & 1][b], acc[a][b]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = ks; k < MAXP; k += G::KS) piece(k);
@@ -1879,7 +1973,7 @@ __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ri
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SplitPairs<NS>::a[pi]][a], fb[SplitPairs<NS>::b[pi]][b], acc[a][b], 0, 0, 0);
+                            acc[a][b] = mfma32<Fmt<NS>::kHalf>(fa[SplitPairs<NS>::a[pi]][a], fb[SplitPairs<NS>::b[pi]][b], acc[a][b]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = ks; k < MAXP; k += G::KS) piece(k);
@@ -1897,7 +1991,8 @@ __device__ __forceinline__ void wgrad_dw2_glds(const MlpWgradParams& P, char* ri
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-            wg_store_block_lds(scratch, slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane);
+            wg_store_block_lds(scratch, slab + kGW2, kMlpHid, 64 * wo + 32 * a, 128 * part + 64 * wi + 32 * b, kMlpHid, acc[a][b], lane,
+                               Fmt<NS>::kHalf ? 1.f / (P.gscale * Fmt<NS>::kSH) : 1.f);
     if (P.w3part) w3.finish(slab);                               // (behind the accumulators' stores: its loads have had that long to arrive)
 }
 
@@ -1957,7 +2052,7 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
             }
         }
     };
-    const bf16x8 ones = bf16x8_ones();
+    const bf16x8 ones = bf16x8_ones<Fmt<NS>::kHalf>();
     const auto multiply = [&](int stage, auto&& piece) {
         const char* ta = ring + stage * G::kStage1;
         const char* tb = ta + CH * 256;
@@ -1975,7 +2070,7 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
 #pragma unroll
                 for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SplitPairs<NS>::a[pi]], fb[SplitPairs<NS>::b[pi]][b], acc[b], 0, 0, 0);
+                    for (int b = 0; b < 3; ++b) acc[b] = mfma32<Fmt<NS>::kHalf>(fa[SplitPairs<NS>::a[pi]], fb[SplitPairs<NS>::b[pi]][b], acc[b]);
             } else {
                 bf16x8 fb[NS][2];
 #pragma unroll
@@ -1985,10 +2080,10 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
 #pragma unroll
                 for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SplitPairs<NS>::a[pi]], fb[SplitPairs<NS>::b[pi]][b], acc[b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b) acc[b] = mfma32<Fmt<NS>::kHalf>(fa[SplitPairs<NS>::a[pi]], fb[SplitPairs<NS>::b[pi]][b], acc[b]);
 #pragma unroll
                 for (int pl = 0; pl < NS; ++pl)
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pl], ones, acc[2], 0, 0, 0);      // every column: db1 of this wave's rows
+                    acc[2] = mfma32<Fmt<NS>::kHalf>(fa[pl], ones, acc[2]);      // every column: db1 of this wave's rows
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2003,16 +2098,17 @@ __device__ __forceinline__ void wgrad_dw1_glds(const MlpWgradParams& P, char* ri
     mlp_barrier();
     float* scratch = reinterpret_cast<float*>(ring) + w * (32 * kWgTrS);
     const int row0 = 128 * half + 32 * rb;
+    const float inv_g = 1.f / P.gscale, un1 = Fmt<NS>::kHalf ? inv_g * (1.f / Fmt<NS>::kSX) : 1.f;      // (powers of two: exact)
     if (cg == 0) {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) wg_store_block_lds(scratch, slab + kGW1, kMlpInPad, row0, 32 * b, kMlpInPad, acc[b], lane);
+        for (int b = 0; b < 3; ++b) wg_store_block_lds(scratch, slab + kGW1, kMlpInPad, row0, 32 * b, kMlpInPad, acc[b], lane, un1);
     } else {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) wg_store_block_lds(scratch, slab + kGW1, kMlpInPad, row0, 32 * (3 + b), kMlpInPad, acc[b], lane);
+        for (int b = 0; b < 2; ++b) wg_store_block_lds(scratch, slab + kGW1, kMlpInPad, row0, 32 * (3 + b), kMlpInPad, acc[b], lane, un1);
         if ((lane & 31) == 0) {
             const int hh = lane >> 5;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = acc[2][i];
+            for (int i = 0; i < 16; ++i) slab[kGB1 + row0 + (i & 3) + 8 * (i >> 2) + 4 * hh] = Fmt<NS>::kHalf ? acc[2][i] * inv_g : acc[2][i];
         }
     }
     w3.finish(slab);
@@ -2340,10 +2436,15 @@ __global__ __launch_bounds__(256) void mlp_adam_kernel(const MlpAdamParams P)
     if (valid > 0) { *reinterpret_cast<f32x4*>(P.m + si) = mo; *reinterpret_cast<f32x4*>(P.v + si) = vo; }
     __bf16* wp = P.wpack + (size_t)net * kPackElems;
     float r[kAdamVec] = {pv[0], pv[1], pv[2], pv[3]};
+    bf16x4_t hp[2];
+    if (P.planes == 2) split_quad<2>(r, hp, Fmt<2>::kSW);          // two fp16 planes of the weight x 2^8 (Fmt<2>)
     for (int pl = 0; pl < P.planes; ++pl) {
         bf16x4 b;
+        if (P.planes == 2) b = hp[pl];
+        else {
 #pragma unroll
-        for (int j = 0; j < kAdamVec; ++j) { b[j] = (__bf16)r[j]; r[j] -= (float)b[j]; }
+            for (int j = 0; j < kAdamVec; ++j) { b[j] = (__bf16)r[j]; r[j] -= (float)b[j]; }
+        }
         __bf16* w = wp + (size_t)pl * kWPlane;
         if (wp0 >= 0) *reinterpret_cast<bf16x4*>(w + wp0) = b;
 #pragma unroll

@@ -52,7 +52,7 @@ def train(results_dir: str,
     independently (pioneer_knm_train.py:43-44; cli.py:15 defaults to 128 of them): rank r trains trials r, r + world, ... on
     its own GPU with ``num_workers x envs_per_worker`` envs each and NO traffic between the GPUs until the result rows are
     gathered at the end.  ``restore``: a PPOTrainer.save() checkpoint every trial starts from (Tune's restore=...).
-    ``hip_kernels``: the learner's arithmetic when no ``ppo_config`` is given — True / "bf16" (default), "f32" / "bf16x2" (float32-
+    ``hip_kernels``: the learner's arithmetic when no ``ppo_config`` is given — True / "bf16" (default), "f32" / "bf16x3" (float32-
     accurate split operands on the same kernels) or False (the float32 torch formulation); PPOConfig.hip_kernels."""
     # the engine's own options: as given, or — dynamics mode — the inertia-scaled motor (omega = 20 rad/s, zeta = 1 on every
     # joint: with plain torque gains PPO does not learn the task, DESIGN.md section 6); TimeLimit(500) and auto-reset as

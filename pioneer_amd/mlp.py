@@ -1,7 +1,8 @@
 """The PPO driver's two MLPs on the hand-written bf16 MFMA kernels of csrc/pnr_mlp.h (C ABI: pnr_mlp_*).
 
-``planes`` selects the operands' precision (include/pioneer_amd.h, pnr_mlp_pack): 1 = bf16 (the fast path), 2 / 3 = every float32
-operand as the sum of 2 / 3 bf16 planes (3: the accuracy of a float32 GEMM — what the reference's torch learner computes in).
+``planes`` selects the operands' precision (include/pioneer_amd.h, pnr_mlp_pack): 1 = bf16 (reduced precision), 2 = every float32
+operand as two power-of-two-scaled fp16 planes (22 significant bits: the accuracy of a float32 GEMM — what the reference's torch
+learner computes in — at three MFMAs per product), 3 = three bf16 planes (24 bits, six MFMAs per product).
 
 ``HipMLP`` owns the packed bf16 weights and the activation / gradient workspaces for one ``ActorCritic`` and exposes
 
@@ -31,7 +32,9 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-PLANES = {True: 1, "bf16": 1, "bf16x2": 2, "f32": 3}      # PPOConfig.hip_kernels -> bf16 planes per operand
+# PPOConfig.hip_kernels -> 16-bit planes per MFMA operand: 1 = bf16 (reduced precision); 2 = two scaled fp16 planes (float32-class:
+# 22 significant bits, three MFMAs per product — "f32"); 3 = three bf16 planes (24 bits, six MFMAs per product — "bf16x3")
+PLANES = {True: 1, "bf16": 1, "f32": 2, "bf16x3": 3}
 
 
 class HipMLP:

@@ -56,9 +56,10 @@ class PPOConfig:
     filter_clip: float = 10.0
     seed: int = 0
     # engine option (no reference counterpart): on a HIP device, run the reference-shaped nets, the loss, Adam, GAE and the
-    # shuffle on the hand-written kernels.  True / "bf16": bf16 MFMA operands (the fast path); "f32": every operand as three bf16
-    # planes = float32-accurate products on the same kernels (the reference's learner is float32 torch, pioneer_knm_train.py:47),
-    # "bf16x2": two planes (16 significant bits); False = the float32 torch formulation
+    # shuffle on the hand-written kernels.  "f32": every operand as two scaled fp16 planes = float32-accurate products (22 significant
+    # bits, measured at torch float32's own distance from float64) — the reference's learner is float32 torch,
+    # pioneer_knm_train.py:47; True / "bf16": bf16 MFMA operands (8 significant bits: the reduced-precision fast variant);
+    # "bf16x3": three bf16 planes (24 bits, twice the MFMAs of "f32"); False = the float32 torch formulation
     hip_kernels: object = True
 
     @classmethod
@@ -73,11 +74,11 @@ class PPOConfig:
         """bf16 planes per MFMA operand of the hand-written kernels (pioneer_amd.mlp.PLANES)."""
         from .mlp import PLANES
         if self.hip_kernels not in PLANES:
-            raise AssertionError(f"hip_kernels must be one of True, 'bf16', 'bf16x2', 'f32' or False, got {self.hip_kernels!r}")
+            raise AssertionError(f"hip_kernels must be one of True, 'bf16', 'f32', 'bf16x3' or False, got {self.hip_kernels!r}")
         return PLANES[self.hip_kernels]
 
     def mlp_dtype(self) -> str:
-        return {1: "bf16", 2: "bf16x2 (two bf16 planes per float32 operand)", 3: "f32 (three bf16 planes per operand: float32-accurate products)"}[self.mlp_planes()]
+        return {1: "bf16", 2: "f32 (two scaled fp16 planes per operand: float32-accurate products)", 3: "bf16x3 (three bf16 planes per operand)"}[self.mlp_planes()]
 
     def wants_hip(self, device) -> bool:
         if self.hip_kernels:

@@ -133,7 +133,7 @@ dist.destroy_process_group()
 
 @pytest.mark.parametrize("precision", ["bf16", "f32"])
 def test_hip_learner_keeps_two_ranks_in_lock_step(tmp_path, precision):
-    """(bf16 operands, and the float32-accurate three-plane form: PPOConfig(hip_kernels="f32").)  Several ranks on the kernels: every update's gradient is all-reduced before Adam, so master weights, Adam's moments and
+    """(bf16 operands, and the float32-accurate split-operand form: PPOConfig(hip_kernels="f32").)  Several ranks on the kernels: every update's gradient is all-reduced before Adam, so master weights, Adam's moments and
     the reported (rank-averaged) losses are identical on both ranks although each rank trains on its own share of the batch —
     and the two-chain form (each net on its own stream with its own all-reduce, what a multi-GPU run uses) leaves exactly the
     weights and moments of the serial one-bucket form."""

@@ -11,7 +11,7 @@ mbs = int(sys.argv[3]) if len(sys.argv) > 3 else 131072        # 32768: the cont
 kp = float(sys.argv[4]) if len(sys.argv) > 4 else 4000.0        # dynamics mode: PD gains of the motor
 kd = float(sys.argv[5]) if len(sys.argv) > 5 else 400.0
 scaled = bool(int(sys.argv[6])) if len(sys.argv) > 6 else False  # gains per unit of each joint's articulated inertia (e.g. 400 40 1)
-# the learner's arithmetic: 1 / bf16 = the HIP kernels with bf16 operands; f32 / bf16x2 = the same kernels with float32-accurate split
+# the learner's arithmetic: 1 / bf16 = the HIP kernels with bf16 operands; f32 / bf16x3 = the same kernels with float32-accurate split
 # operands (PPOConfig.hip_kernels); 0 = the float32 torch learner (autograd, BLAS)
 _prec = sys.argv[7] if len(sys.argv) > 7 else "1"
 bf16 = {"1": True, "0": False}.get(_prec, _prec)
