@@ -23,10 +23,13 @@ JSON line.
 
 Extra legs in the same line, never part of `value`: "fused_rollout" (pnr_rollout, T steps per launch),
 "large_batch" (262 144 envs per launch), "weak_scaling" at N>1 (65 536 envs PER GPU), "dynamics_randomized"
-(BASELINE config[4]), "ppo_loop" (config[2] at N=1: 16 384 envs; config[3] at N>1: 65 536 envs in total,
+(BASELINE config[4]), "ppo_loop_f32" (config[2] at N=1: 16 384 envs; config[3] at N>1: 65 536 envs in total,
 the full rollout+learn loop on SURVEY 8(d)'s contract: T = 32, 4 epochs of 32 768-sample minibatches,
-gradients all-reduced over RCCL), "ppo_loop_large_minibatch" (the same loop with 131 072-sample
-minibatches, a labelled variant), "cpu_baseline" at N=1.
+gradients all-reduced over RCCL — with float32-accurate products, the reference learner's arithmetic: the
+credited PPO figure), "ppo_loop" (the same loop with bf16 operands: a reduced-precision variant),
+"ppo_loop_65536" (N=1: config[3] whole on one GPU, both precisions), "ppo_loop_bf16x3" (N=1),
+"ppo_loop_large_minibatch" (bf16, 131 072-sample minibatches, a labelled variant), "cpu_baseline" at N=1,
+"build" (the binary's baked-in fingerprints next to the tree's and the counter passes').
 """
 import argparse
 import ctypes as C
@@ -50,6 +53,7 @@ HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MIN_SERIES_S = 0.06        # the timed K-step block is repeated back to back until the series is at least this long ...
 MIN_REPEATS = 5            # ... and at least this often; `ms_per_step` = series wall time / (repeats x K)
 MAX_REPEATS = 20000
+DYN_PACKED_FRAC = 361.0 / 977.0                 # v_pk_*_f32 share of the dynamics sub-step loop's VALU instructions (tools/isa_loop_mix.py)
 DYN_COUNTERS = "r04_f_dyn_sq_counters.json"      # tools/dyn_counters_summary.py (VALU instructions per launch of the dynamics kernel)
 
 
@@ -94,7 +98,11 @@ def parse_args(argv=None):
     ap.add_argument("--ppo-large-minibatch", type=int, default=131072,
                     help="also report the loop with this global minibatch size as \"ppo_loop_large_minibatch\" (0 = skip)")
     ap.add_argument("--ppo-f32", type=int, default=1,
-                    help="also report the PPO loop with float32-accurate kernels (PPOConfig(hip_kernels='f32')) as \"ppo_loop_f32\"")
+                    help="N = 1: also report the PPO loop with three bf16 planes per operand as \"ppo_loop_bf16x3\" (\"ppo_loop_f32\", the "
+                         "float32-accurate loop, and \"ppo_loop\", its bf16 reduced-precision variant, are always reported)")
+    ap.add_argument("--ppo-65536", type=int, default=1,
+                    help="N = 1: also report BASELINE config[3] whole on ONE GPU (65 536 envs, T = 32, 32 768-sample minibatches) at both "
+                         "precisions as \"ppo_loop_65536\": the first point of SURVEY 8(d)'s 1/2/4/8 table")
     ap.add_argument("--ppo-timeout", type=float, default=300.0)
     return ap.parse_args(argv)
 
@@ -342,8 +350,19 @@ def run_rank(args):
         instr = cnt["valu_wave_instructions_per_dispatch"] * (envs / 65536.0)
         simds, clock = 256 * 4, 2.4e9
         ach = instr / (avg_launch_ms * 1e-3)
+        # the same instructions as fp32 LANE-OPERATIONS: 64 per wave-instruction, a packed one (v_pk_*_f32: 361 of the sub-step loop's 977
+        # VALU instructions, tools/isa_loop_mix.py) counted twice, against the guide's vector peak of 157.3 TFLOP/s = 78.6 T lane-operations/s
+        # (an FMA lane-operation is two flops)
+        lane_ops = instr * 64.0 * (1.0 + DYN_PACKED_FRAC)
+        lane = {"achieved": lane_ops / (avg_launch_ms * 1e-3) / 1e12, "peak": 157.3 / 2, "unit": "T fp32 lane-operations/s",
+                "frac": lane_ops / (avg_launch_ms * 1e-3) / (157.3e12 / 2), "packed_instruction_fraction": DYN_PACKED_FRAC,
+                "note": "packed instructions counted twice.  Reconciles the issue model above with the occupancy A/B (DESIGN_HISTORY r03: 1.75 / 1.73 / "
+                        "1.60 us per 65 536 env-sub-steps at 1 / 2 / 4 waves per SIMD — a second wave buys 1 %): a packed fp32 instruction takes "
+                        "one issue slot but two passes of the SIMD's fp32 lanes, so for this stream (37 % packed) the unit that fills is the lanes of "
+                        "the SIMD, not one wave's issue port — ONE wave per SIMD already keeps them this busy, and more waves can only share them; "
+                        "the 2-cycle issue peak is reached by unpacked streams at eight waves (profiles/r03_a_valu_issue_probe.jsonl)"}
         return {"bound": "valu", "achieved": ach / 1e9, "peak": simds * clock / 2 / 1e9, "unit": "G wave-instructions/s",
-                "frac": ach / (simds * clock / 2), "frac_of_single_wave_issue": cnt["frac_of_single_wave_issue"],
+                "frac": ach / (simds * clock / 2), "frac_of_single_wave_issue": cnt["frac_of_single_wave_issue"], "fp32_lanes": lane,
                 "source": "VALU wave-instructions per 65 536-env launch from " + src + "; duration = this run's HIP events; peak = one "
                           "wave64 VALU instruction per 2 cycles per SIMD at 2.4 GHz; one wave per SIMD can issue one per 4"}
 
@@ -594,11 +613,18 @@ def run_rank(args):
                         f"{args.weak_envs} envs PER GPU on {world} ranks (weak scaling; not the metric's configuration)")
         weak["total_envs"] = args.weak_envs * world
 
-    def ppo_leg(iters, global_mbs, precision=True):
+    PRECISION_LABEL = {
+        "f32": "float32-accurate products (two scaled fp16 planes per operand, 22 significant bits: measured at torch float32's own distance "
+               "from float64) — the arithmetic of the reference's learner (float32 torch, pioneer_knm_train.py:47): the credited figure",
+        True: "REDUCED-PRECISION VARIANT: bf16 MFMA operands (8 significant bits; gradients ~9e-3 relative from float32)",
+        "bf16x3": "float32-accurate products as three bf16 planes per operand (24 bits, six MFMAs per product: r04's form)"}
+
+    def ppo_leg(iters, global_mbs, precision=True, total=None):
         """BASELINE config[2] at N=1 (16 384 envs, full rollout + learn loop) and config[3] at N>1
         (65 536 envs in total sharded over the ranks, gradients all-reduced over RCCL/xGMI)."""
         from pioneer_amd.ppo import PPOConfig, PPOTrainer
-        total = args.ppo_envs if args.ppo_envs > 0 else (16384 if world == 1 else 65536)
+        if total is None:
+            total = args.ppo_envs if args.ppo_envs > 0 else (16384 if world == 1 else 65536)
         start, cnt = pdist.shard_range(total, world, rank)
         penv = PioneerVectorEnv(cnt, device=dev, seed=0, env_id_offset=start,
                                 engine_config=EngineConfig(max_episode_steps=500, auto_reset=True, mode=args.mode))
@@ -633,7 +659,7 @@ def run_rank(args):
         mac_per_sample_net = 106496 + 69632 + 110592           # forward, backward-data, weight gradients (csrc/pnr_mlp.h)
         flops = 2.0 * mac_per_sample_net * mbs * 2             # per update on this rank, both nets: the model's flops ..
         mfma_flops = flops * {0: 0, 1: 1, 2: 3, 3: 6}[planes]  # .. and what the matrix cores execute for them (plane pairs)
-        roof = {"bound": "hbm + latency (arithmetic intensity ~110 flop/B against a ridge of ~310)", "us_per_update": us_per_update,
+        roof = {"bound": None, "us_per_update": us_per_update,
                 "minibatch_per_rank": mbs, "flops_per_update": flops, "mfma_flops_per_update": mfma_flops,
                 "achieved_TFLOPs": flops / (us_per_update * 1e-6) / 1e12, "mfma_peak_TFLOPs": 2500.0,
                 "mfma_frac": mfma_flops / (us_per_update * 1e-6) / 2.5e15,
@@ -658,7 +684,17 @@ def run_rank(args):
         except Exception as exc:
             roof["bytes_per_update"] = None
             roof["bytes_source"] = f"profiles/{LEARNER_TRAFFIC}: {type(exc).__name__}"
-        return {"value": steps / tp, "roofline": roof if hip_learner else None, "unit": "env-steps/s", "total_envs": total, "envs_per_gpu": cnt, "rollout_T": 32,
+        # which roofline the update's arithmetic intensity puts it under (MFMA flops per counter byte against the ridge 2.5 PF / 8 TB/s)
+        if roof.get("bytes_per_update"):
+            inten = mfma_flops / roof["bytes_per_update"]
+            roof["intensity_mfma_flop_per_byte"] = inten
+            roof["bound"] = ("mfma" if inten > 2.5e15 / (HBM_PEAK_GBPS * 1e9) else "hbm")
+            roof["bound_note"] = (f"{inten:.0f} MFMA flop per byte against a ridge of {2.5e15 / (HBM_PEAK_GBPS * 1e9):.0f}; neither roofline is approached "
+                                  "(mfma_frac, hbm_frac): the kernels are bound by the dependent chain of a tile's phases, DESIGN.md section 3c")
+        else:                                                   # no usable counter pass for this leg: no byte figure is quoted at all
+            roof.pop("bytes_per_update", None)
+            roof["bound"] = "mfma + latency (bytes not quoted: " + roof.get("bytes_source", "no counter pass") + ")"
+        return {"value": steps / tp, "precision": PRECISION_LABEL.get(precision, str(precision)), "roofline": roof if hip_learner else None, "unit": "env-steps/s", "total_envs": total, "envs_per_gpu": cnt, "rollout_T": 32,
                 "num_sgd_iter": 4, "sgd_minibatch_size": mbs * world, "sgd_minibatch_size_per_rank": mbs,
                 "sgd_updates_per_iter": 4 * ((32 * cnt) // mbs), "mlp_dtype": pcfg.mlp_dtype(),
                 "hip_graph": graphed, "iters": iters, "losses_finite": finite,
@@ -670,7 +706,8 @@ def run_rank(args):
                 "sample_time_s": sum(r["sample_time_s"] for r in rs), "learn_time_s": sum(r["learn_time_s"] for r in rs),
                 "note": "full loop: policy MLP 137-256-256 fwd per step, GAE, 4 SGD epochs, obs filter, grad all-reduce"}
 
-    def emit(ppo_loop, ppo_large, ppo_f32=None, ppo_x2=None):
+    def emit(ppo):
+        """ppo: the PPO legs that have a result so far (key -> dict; an error dict for the one that failed or was cut off)."""
         if rank != 0:
             return
         launches = K // T
@@ -722,71 +759,78 @@ def run_rank(args):
             out["dynamics_randomized"] = dynamic
         if weak:
             out["weak_scaling"] = weak
-        if ppo_loop:
-            out["ppo_loop"] = ppo_loop
-        if ppo_f32:
-            out["ppo_loop_f32"] = ppo_f32
-        if ppo_x2:
-            out["ppo_loop_bf16x3"] = ppo_x2
-        if ppo_large:
-            out["ppo_loop_large_minibatch"] = ppo_large
+        for key, res in ppo.items():
+            if "." in key:                                    # "ppo_loop_65536.f32" -> out["ppo_loop_65536"]["f32"]
+                top, sub = key.split(".", 1)
+                out.setdefault(top, {"note": "BASELINE config[3] whole on ONE GPU: 65 536 envs, T = 32, four epochs of 32 768-sample minibatches — "
+                                             "the N = 1 point of SURVEY 8(d)'s 1/2/4/8 table (at N > 1 `ppo_loop_f32` / `ppo_loop` are this workload sharded)"})[sub] = res
+            else:
+                out[key] = res
+        lib = _lib.load_library()
+        built, tree = lib.pnr_build_fingerprint().decode(), _lib.tree_fingerprint()
+        out["build"] = {"binary": built, "tree": tree, "binary_is_this_tree": built == tree,
+                        "env_kernel_sources_sha16": _lib.source_fingerprint(), "learner_kernel_sources_sha16": _lib.source_fingerprint(_lib.LEARNER_KERNEL_SOURCES),
+                        "note": "binary / tree: per translation unit, sha256 over flags + sources + header (pnr_build_fingerprint, baked in at compile time; the "
+                                "loader refuses a mismatch); the *_sources_sha16 are what the looked-up counter passes (roofline.traffic_source, "
+                                "ppo_loop*.roofline.bytes_source) are checked against"}
         if not args.no_cpu_baseline and world == 1:      # contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    ppo_loop = ppo_large = ppo_f32 = ppo_x2 = None
+    ppo = {}                 # key -> result of the PPO legs that have finished (insertion order = the order in the line)
     rc = 0
     if args.ppo_iters < 0:
-        args.ppo_iters = 10 if args.mode == "kinematic" else 0      # ~90 ms of timed work per PPO leg
+        args.ppo_iters = 10 if args.mode == "kinematic" else 0      # ~150 ms of timed work per PPO leg
     if args.ppo_iters > 0:
-        # the extra leg must never take the main result down: the line is still printed when it fails, but the
-        # process then ends NON-ZERO — exceptions are reported in place (rc 5), and a leg that does not come back
-        # (e.g. ranks out of step in a collective) is cut off by a watchdog that prints the line without it and
-        # ends the process with rc 3
+        # The extra legs must never take the main result down: the line is still printed when one fails, but the process then ends
+        # NON-ZERO — an exception is reported in place of ITS leg (rc 5), and a leg that does not come back (e.g. ranks out of step in
+        # a collective) is cut off by a watchdog that prints the line with every FINISHED leg and the error in place of the one that
+        # was running (rc 3).
         import threading
-        lock, state = threading.Lock(), {"done": False}
+        it, half = args.ppo_iters, max(2, args.ppo_iters // 2)
+        plan = [("ppo_loop_f32", lambda: ppo_leg(it, args.ppo_minibatch, "f32")),          # the credited loop: the reference learner's arithmetic
+                ("ppo_loop", lambda: ppo_leg(it, args.ppo_minibatch, True))]                # its bf16 reduced-precision variant
+        if world == 1 and args.ppo_65536 and not args.ppo_envs:
+            plan += [("ppo_loop_65536.f32", lambda: ppo_leg(max(2, it // 3), args.ppo_minibatch, "f32", total=65536)),
+                     ("ppo_loop_65536.bf16", lambda: ppo_leg(max(2, it // 3), args.ppo_minibatch, True, total=65536))]
+        if world == 1 and args.ppo_f32:
+            plan.append(("ppo_loop_bf16x3", lambda: ppo_leg(half, args.ppo_minibatch, "bf16x3")))
+        if args.ppo_large_minibatch > 0 and args.ppo_large_minibatch != args.ppo_minibatch:
+            plan.append(("ppo_loop_large_minibatch", lambda: ppo_leg(half, args.ppo_large_minibatch, True)))
+        lock, state = threading.Lock(), {"done": False, "leg": None}
 
         def on_timeout():
             with lock:
                 if state["done"]:
                     return
                 state["done"] = True
-                emit({"error": f"ppo leg did not finish within {args.ppo_timeout:.0f} s"}, None)
+                res = dict(ppo)
+                if state["leg"]:
+                    res[state["leg"]] = {"error": f"did not finish: the PPO legs' common budget of {args.ppo_timeout:.0f} s ran out in this leg"}
+                emit(res)
                 sys.stdout.flush()
                 os._exit(3)
         wd = threading.Timer(args.ppo_timeout, on_timeout)
         wd.daemon = True
         wd.start()
-        try:
-            ppo_loop = ppo_leg(args.ppo_iters, args.ppo_minibatch)
-            if args.ppo_f32 and world == 1:       # (N = 1 only: the reference-precision figure of config[2]; the N > 1 leg stays the one form rehearsed there)
-                # the same loop with float32-accurate products on the same kernels (three bf16 planes per operand): the reference's
-                # learner is float32 torch (pioneer_knm_train.py:47), so THIS is the reference-precision figure; `ppo_loop` is the
-                # bf16-operand extra
-                ppo_f32 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "f32")
-                # two planes: 16 significant bits per operand — heads within 8e-6, gradients within 1.4e-5 of float32
-                # (profiles/r04_f_accuracy_by_precision.jsonl), between the two in speed
-                ppo_x2 = ppo_leg(max(2, args.ppo_iters // 2), args.ppo_minibatch, "bf16x3")
-            if args.ppo_large_minibatch > 0 and args.ppo_large_minibatch != args.ppo_minibatch:
-                ppo_large = ppo_leg(args.ppo_iters, args.ppo_large_minibatch)
-        except Exception as exc:
-            err = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-            if ppo_loop is None:
-                ppo_loop = err
-            elif args.ppo_f32 and world == 1 and ppo_f32 is None:
-                ppo_f32 = err
-            elif args.ppo_f32 and world == 1 and ppo_x2 is None:
-                ppo_x2 = err
-            else:
-                ppo_large = err
-            rc = 5
+        for key, fn in plan:
+            with lock:
+                state["leg"] = key
+            try:
+                res = fn()
+            except Exception as exc:
+                res = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                rc = 5
+            with lock:
+                ppo[key] = res
+            if res.get("losses_finite") is False:
+                rc = 5
+            if "error" in res:
+                break                                       # (a failed leg may have left a collective half done: no further legs)
         with lock:
             state["done"] = True
         wd.cancel()
-        for leg in (ppo_loop, ppo_large, ppo_f32, ppo_x2):
-            if leg and leg.get("losses_finite") is False:
-                rc = 5
-    emit(ppo_loop, ppo_large, ppo_f32, ppo_x2)
+    emit(ppo)
 
     if world > 1:
         dist.barrier()

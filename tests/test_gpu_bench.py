@@ -39,8 +39,35 @@ def test_single_gpu_line_has_the_contract_fields():
     assert ("NOT measured in this run" in rf["traffic_source"]) if rf["traffic"] is not None else ("stale" in rf["traffic_source"] or "profiles/" in rf["traffic_source"])
     assert rf["launches_per_step"] == 1 and "single_launch" not in rf
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["value"] > 0
-    p = r["ppo_loop"]
-    assert "error" not in p and p["losses_finite"] and p["sgd_minibatch_size"] == 8192 and p["grad_allreduce"] is None
+    # the PPO legs: the float32-accurate loop leads and is labelled as the credited one, bf16 is labelled the reduced-precision variant
+    keys = list(r)
+    assert keys.index("ppo_loop_f32") < keys.index("ppo_loop")
+    for key, planes_word in (("ppo_loop_f32", "float32-accurate"), ("ppo_loop", "REDUCED-PRECISION")):
+        p = r[key]
+        assert "error" not in p and p["losses_finite"] and p["sgd_minibatch_size"] == 8192 and p["grad_allreduce"] is None
+        assert planes_word in p["precision"]
+        rf = p["roofline"]
+        assert rf["us_per_update"] > 0 and rf["bound"] and ("bytes_per_update" not in rf or rf["bytes_per_update"] > 0)   # filled or dropped, never null
+    assert r["ppo_loop_f32"]["mlp_dtype"].startswith("f32") and r["ppo_loop"]["mlp_dtype"] == "bf16"
+    assert "ppo_loop_65536" not in r               # (--ppo-envs overrides the leg sizes: the anchor is skipped in this small run)
+    b = r["build"]
+    assert b["binary_is_this_tree"] and b["binary"] == b["tree"] and len(b["env_kernel_sources_sha16"]) == 16
+
+
+def test_config3_anchor_and_dynamics_lane_roofline_are_in_the_line():
+    """`ppo_loop_65536` (config[3] whole on one GPU, both precisions, each with its roofline), and the dynamics leg's
+    second roofline figure in fp32 lane-operations."""
+    r, _ = _bench(["--steps", "64", "--warmup", "8", "--large-envs", "0", "--fused-leg", "0", "--split-leg", "0", "--ppo-iters", "3",
+                   "--ppo-f32", "0", "--ppo-large-minibatch", "0", "--no-cpu-baseline"])
+    a = r["ppo_loop_65536"]
+    for prec in ("f32", "bf16"):
+        p = a[prec]
+        assert "error" not in p and p["losses_finite"] and p["total_envs"] == 65536 and p["sgd_minibatch_size"] == 32768 and p["rollout_T"] == 32
+        assert p["sgd_updates_per_iter"] == 4 * 64 and p["roofline"]["us_per_update"] > 0 and p["value"] > 1e6
+    assert a["f32"]["value"] < a["bf16"]["value"]
+    lanes = r["dynamics_randomized"]["roofline"]["fp32_lanes"]
+    assert lanes["unit"].startswith("T fp32 lane-operations") and 0.05 < lanes["frac"] < 1.0 and abs(lanes["peak"] - 78.65) < 0.1
+    assert "second wave" in lanes["note"]
 
 
 def test_two_ranks_self_launched_on_the_metric_configuration():
@@ -50,6 +77,7 @@ def test_two_ranks_self_launched_on_the_metric_configuration():
     assert r["config"]["total_envs"] == 65536 and r["config"]["envs_per_gpu"] == 32768
     assert "cpu_baseline" not in r                 # contract: rank 0 at N=1 only
     assert r["weak_scaling"]["envs_per_gpu"] == 65536 and r["weak_scaling"]["total_envs"] == 131072
+    assert "error" not in r["ppo_loop_f32"] and r["ppo_loop_f32"]["grad_allreduce"]["world_size"] == 2     # the credited loop runs at N > 1 too
     p = r["ppo_loop"]
     assert "error" not in p and p["losses_finite"]
     assert p["total_envs"] == 2048 and p["envs_per_gpu"] == 1024 and p["sgd_minibatch_size_per_rank"] == 4096
