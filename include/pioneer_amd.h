@@ -39,8 +39,11 @@ extern "C" {
  *      weight-gradient partials made by the fused kernel); new entry points pnr_ppo_rollout (the sampler's T steps as one
  *      resident launch), pnr_filter_prepare, pnr_mlp_w3_partial_floats
  *   4  float32-accurate operands for the MLP kernels: pnr_mlp_pack / pnr_mlp_forward / pnr_mlp_act / pnr_mlp_gather gained `planes`
- *      (before `stream`), pnr_mlp_step gained `planes`; pnr_create waits for its zero fill (Conventions) */
-#define PNR_ABI_VERSION 4
+ *      (before `stream`), pnr_mlp_step gained `planes`; pnr_create waits for its zero fill (Conventions)
+ *   5  new entry points pnr_world_step, pnr_set_joint_motor, pnr_build_fingerprint; `planes` == 2 now means two SCALED FP16 planes
+ *      (was: two bf16 planes) in every pnr_mlp_* call; pnr_mlp_train_step checks every argument before its first launch and
+ *      accepts g_head == NULL with w3_partials */
+#define PNR_ABI_VERSION 5
 
 #define PNR_DOF 6          /* revolute joints of pioneer_knm_6dof.urdf:209-264 */
 #define PNR_OBS_DIM 137    /* pioneer_knm_env.py:194-211 (26 pieces)         */
@@ -240,6 +243,36 @@ int pnr_rollout(pnr_handle h, int32_t T, const float* actions, float* obs,
 int pnr_observe(pnr_handle h, float* obs_out, void* stream);
 
 /*
+ * World.step() (bullet_scene.py:273-275: frame_skip x stepSimulation) on its own: the simulator advances by step_time and
+ * NOTHING else happens — no command integration, reward, TimeLimit, reset or observation.  What the reference's demo loop
+ * drives (pioneer_knm_env.py:277-296: reset_state(position(), velocity); world.step()).
+ *   dynamics-mode handle (joint_state must be NULL): frame_skip articulated-body sub-steps on the handle's simulated joints
+ *     (q, qd of pnr_get_dyn_state) under gravity, contacts, joint limits, friction / damping and each joint's motor — the one
+ *     pnr_set_joint_motor gave it, else the handle's own motor law tracking the env's command state r, v (teleport handles:
+ *     no motor: the joints coast).  Parity unpinned, like all of dynamics mode.
+ *   kinematic-mode handle: there is no simulated state; joint_state [num_envs][12] (q[6] | qd[6], float32, caller-owned
+ *     device memory) is the joints as Bullet holds them after resetJointState(position, velocity), and with the reference's
+ *     defaults (no gravity, no motor torque, no collision shapes) a step carries each on at its velocity: q += qd * step_time,
+ *     stopped at its limit with the velocity zeroed.  The env's own state is not touched (the reference's self.r / self.v
+ *     are not either).
+ */
+int pnr_world_step(pnr_handle h, float* joint_state, void* stream);
+
+/*
+ * Joint.control_position / Joint.control_velocity (bullet_scene.py:123-155 -> setJointMotorControl2) for joint `joint`
+ * (0..5, URDF order) of every env of a dynamics-mode handle: control_mode PNR_CONTROL_POSITION (targetPosition,
+ * targetVelocity, positionGain, velocityGain, force, maxVelocity) or PNR_CONTROL_VELOCITY (targetVelocity, force).  An
+ * optional argument the caller leaves out is passed as NaN and takes the handle's configured value (pd_kp, pd_kd,
+ * torque_limit, max_velocity; targetVelocity: 0).  The motor is the engine's one law,
+ *   tau = clip(Kp (r* - q) + kd (clamp(v* + c (r* - q), +-maxVelocity) - qd), +-force)
+ * (pnr_config.control_mode's folding, per joint), honoured by pnr_world_step; pnr_step keeps driving every joint from the
+ * env's own command state (the reference's act() teleports the joints each step, pioneer_knm_env.py:148).  Host-side and
+ * synchronous: takes effect with the next pnr_world_step.  Parity unpinned (Bullet's motor is a velocity-level constraint).
+ */
+int pnr_set_joint_motor(pnr_handle h, int32_t joint, int32_t control_mode, double target_position, double target_velocity,
+                        double position_gain, double velocity_gain, double max_force, double max_velocity);
+
+/*
  * Raw state for checkpoint / tests, as planar 32-bit words [24][num_envs]:
  * words 0-5 a, 6-11 v, 12-17 r, 18-20 target, 21 potential (float32),
  * 22 step_index, 23 episode (uint32).  Device pointers.
@@ -348,12 +381,17 @@ int64_t pnr_mlp_pack_elems(void);
 int64_t pnr_mlp_bias_elems(void);
 int64_t pnr_mlp_slab_floats(int64_t batch);
 /*
- * `planes` (ABI 4; 1, 2 or 3) selects the precision of every MFMA operand of the pnr_mlp_* kernels.  1: bf16 operands (8 significant
- * bits), float32 accumulation — the fast path.  2 / 3: each float32 operand is carried as the sum of 2 / 3 bf16 planes (16 / 24
- * significant bits; 3 = the accuracy of a float32 GEMM, what the reference's float32 learner computes in,
- * pioneer_knm_train.py:47) and a product takes the 3 / 6 bf16 MFMAs of the plane pairs, accumulated in float32.  Every bf16 operand
- * buffer then exists `planes` times, plane-major: wpack [planes][pnr_mlp_pack_elems()], xs / xs_out / xs_in [planes][batch][144],
- * h1 / h2 / dz1 / dz2 [planes][2][batch][256].  Biases, heads, slabs, Adam state and master weights are float32 either way.
+ * `planes` (1, 2 or 3) selects the precision of every MFMA operand of the pnr_mlp_* kernels; accumulation is float32 always.
+ *   1: bf16 operands (8 significant bits) — the reduced-precision fast variant.
+ *   2: each float32 operand as TWO FP16 PLANES (ABI 5): p0 = fp16(s x), p1 = fp16(s x - p0) with a power-of-two scale s per tensor
+ *      (weights 2^8, activations 2^8, net inputs 2^4, gradients 4 * 2^ceil(log2 batch); the accumulators are divided by the product
+ *      of the two scales, exactly) — 22 significant bits per operand, the three fp16 MFMAs (0,0), (0,1), (1,0) per product.  Measured
+ *      at a float32 framework GEMM's own distance from float64 (heads 2.9e-7 against 3.8e-7; gradients 9.6e-7 against 2.4e-6 of float32
+ *      autograd): the accuracy of a float32 GEMM, i.e. what the reference's float32 learner computes in (pioneer_knm_train.py:47).
+ *      Range: scaled values are clamped to +-65504 — weights |w| < 255, inputs |x| < 4094, per-sample gradients |dL/dz| < 16 384.
+ *   3: three bf16 planes (24 bits, exact split, no range caveat), the six bf16 MFMAs of the plane pairs i + j < 3 per product (ABI 4).
+ * Every 16-bit operand buffer then exists `planes` times, plane-major: wpack [planes][pnr_mlp_pack_elems()], xs / xs_out / xs_in
+ * [planes][batch][144], h1 / h2 / dz1 / dz2 [planes][2][batch][256].  Biases, heads, slabs, Adam state and master weights are float32 either way.
  * planes > 1: pnr_mlp_forward / pnr_mlp_act save no activations (xs, h1, h2 / xs_out must be NULL: pnr_mlp_backward is bf16-only and
  * the learner gathers its inputs from the float32 observations), pnr_mlp_gather takes no xs_rows, pnr_mlp_train_step needs w3_partials.
  */

@@ -215,6 +215,11 @@ DYN_STATE_DTYPE = np.dtype([
 ])
 
 
+class OrcJointMotor(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("control_mode", C.c_int32), ("target_position", C.c_double), ("target_velocity", C.c_double),
+                ("position_gain", C.c_double), ("velocity_gain", C.c_double), ("max_force", C.c_double), ("max_velocity", C.c_double)]
+
+
 class DynOracle(COracle):
     """Batched dynamics-mode oracle: kinematic command state + simulated (q, qd)."""
 
@@ -322,6 +327,26 @@ class DynOracle(COracle):
         pos, vel = np.empty(3), np.empty(3)
         self.lib.orc_dyn_tip(self._one(e), _ptr(pos, C.c_double), _ptr(vel, C.c_double))
         return pos, vel
+
+    # World.step() alone with per-joint motors (orc_dyn_world_step): motors = {joint: dict(control_mode, target_position, target_velocity,
+    # position_gain, velocity_gain, max_force, max_velocity)}; a joint that is not named keeps the env-wide law
+    def set_joint_motor(self, joint, control_mode, target_position=0.0, target_velocity=0.0, position_gain=None, velocity_gain=None,
+                        max_force=None, max_velocity=None):
+        if not hasattr(self, "motors"):
+            self.motors = (OrcJointMotor * DOF)()
+        m = self.motors[joint]
+        m.enabled, m.control_mode = 1, int(control_mode)
+        m.target_position, m.target_velocity = float(target_position), float(target_velocity)
+        m.position_gain = float(self.d.kp if position_gain is None else position_gain)
+        m.velocity_gain = float(self.d.kd if velocity_gain is None else velocity_gain)
+        m.max_force = float(self.d.torque_limit if max_force is None else max_force)
+        m.max_velocity = float(self.d.max_velocity if max_velocity is None else max_velocity)
+
+    def world_step(self):
+        motors = getattr(self, "motors", None)
+        for e in range(self.n):
+            self.lib.orc_dyn_world_step(C.byref(self.d), C.byref(self.p), C.c_void_p(self.state.ctypes.data + e * self.state.dtype.itemsize),
+                                        self._one(e), motors)
 
     def substep(self, r_ref, v_ref, e=0):
         r = np.ascontiguousarray(r_ref, dtype=np.float64); v = np.ascontiguousarray(v_ref, dtype=np.float64)

@@ -163,8 +163,20 @@ void orc_dyn_aba_ext(const orc_dyn_state* s, const double tau[ORC_DOF], double g
  * clip(D_i * ades[i], +-tcap) (tcap <= 0: no cap), D_i being the joint's articulated-body inertia at this pose — the
  * number pass 2 forms anyway.  A PD law fed in as ades therefore acts with the same stiffness and damping PER UNIT OF
  * INERTIA on every joint and in every pose (the "pd_inertia_scaled" motor). */
+static void aba_motor_caps(const orc_dyn_state* s, const double tau[ORC_DOF], const double ades[ORC_DOF], const double tcaps[ORC_DOF],
+                           double gravity, const double fext[ORC_DOF][6], double qdd[ORC_DOF]);
+
 void orc_dyn_aba_motor(const orc_dyn_state* s, const double tau[ORC_DOF], const double ades[ORC_DOF], double tcap, double gravity,
                        const double fext[ORC_DOF][6], double qdd[ORC_DOF])
+{
+    double caps[ORC_DOF];
+    for (int i = 0; i < ORC_DOF; i++) caps[i] = tcap;
+    aba_motor_caps(s, tau, ades, caps, gravity, fext, qdd);
+}
+
+/* .. with a torque cap per joint (pnr_world_step's per-joint motors) */
+static void aba_motor_caps(const orc_dyn_state* s, const double tau[ORC_DOF], const double ades[ORC_DOF], const double tcaps[ORC_DOF],
+                           double gravity, const double fext[ORC_DOF][6], double qdd[ORC_DOF])
 {
     mat6 I[ORC_DOF], X[ORC_DOF], IA[ORC_DOF];
     vec6 v[ORC_DOF], c[ORC_DOF], pA[ORC_DOF], U[ORC_DOF];
@@ -192,6 +204,7 @@ void orc_dyn_aba_motor(const orc_dyn_state* s, const double tau[ORC_DOF], const 
         double tq = tau[i];
         if (ades) {
             double m = D[i] * ades[i];
+            const double tcap = tcaps[i];
             if (tcap > 0) m = m > tcap ? tcap : (m < -tcap ? -tcap : m);
             tq += m;
         }
@@ -502,6 +515,48 @@ void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state
         double hi = (double)p->r_hi[i], lo = (double)p->r_lo[i];
         if (s->q[i] > hi) { s->q[i] = hi; if (s->qd[i] > 0) s->qd[i] = 0; }
         if (s->q[i] < lo) { s->q[i] = lo; if (s->qd[i] < 0) s->qd[i] = 0; }
+    }
+}
+
+/* World.step() alone (bullet_scene.py:273-275: frame_skip x stepSimulation; include/pioneer_amd.h pnr_world_step): the
+ * sub-steps of orc_dyn_substep with each joint's own motor — m[i] where Joint.control_position / control_velocity set one
+ * (bullet_scene.py:123-155; m[i].enabled), else the env-wide law on the env's command state ks->r, ks->v (teleport: none).
+ * No command integration, reward or observation.  Build-defined like all of dynamics mode: parity unpinned. */
+void orc_dyn_world_step(const orc_dyn_params* d, const orc_params* p, const orc_state* ks, orc_dyn_state* s, const orc_joint_motor* m)
+{
+    for (int k = 0; k < d->frame_skip; k++) {
+        double tau[ORC_DOF], qdd[ORC_DOF], fext[ORC_DOF][6], ades[ORC_DOF], caps[ORC_DOF];
+        int have_ext = 0;
+        for (int i = 0; i < ORC_DOF; i++) {
+            orc_dyn_params u = *d;                       /* this joint's motor in the terms of the one law */
+            double r_ref = ks->r[i], v_ref = (double)ks->v[i];
+            int on = !d->teleport;
+            if (m && m[i].enabled) {
+                u.control_mode = m[i].control_mode; u.kp = m[i].position_gain; u.kd = m[i].velocity_gain;
+                u.torque_limit = m[i].max_force; u.max_velocity = m[i].control_mode == 1 ? 0.0 : m[i].max_velocity;
+                r_ref = m[i].target_position; v_ref = m[i].target_velocity; on = 1;
+            }
+            caps[i] = u.torque_limit;
+            double t = 0.0;
+            ades[i] = 0.0;
+            if (on) {
+                if (d->pd_inertia_scaled) { orc_dyn_params w = u; w.torque_limit = 0.0; ades[i] = orc_dyn_motor_torque(&w, r_ref, v_ref, s->q[i], s->qd[i]); }
+                else t = orc_dyn_motor_torque(&u, r_ref, v_ref, s->q[i], s->qd[i]);
+            }
+            t -= s->damping[i] * s->qd[i];
+            t -= s->friction[i] * s->qd[i] / sqrt(s->qd[i] * s->qd[i] + FRICTION_EPS * FRICTION_EPS);
+            tau[i] = t;
+        }
+        if (d->ground_z == d->ground_z || d->obstacle_half_extents[0] > 0 || d->n_scene > 0)
+            have_ext = orc_dyn_contact_wrenches(d, s, fext);
+        aba_motor_caps(s, tau, d->pd_inertia_scaled ? ades : NULL, caps, d->gravity, have_ext ? (const double (*)[6])fext : NULL, qdd);
+        for (int i = 0; i < ORC_DOF; i++) {          /* semi-implicit Euler + inelastic joint limits (orc_dyn_substep's) */
+            s->qd[i] += qdd[i] * d->timestep;
+            s->q[i] += s->qd[i] * d->timestep;
+            double hi = (double)p->r_hi[i], lo = (double)p->r_lo[i];
+            if (s->q[i] > hi) { s->q[i] = hi; if (s->qd[i] > 0) s->qd[i] = 0; }
+            if (s->q[i] < lo) { s->q[i] = lo; if (s->qd[i] < 0) s->qd[i] = 0; }
+        }
     }
 }
 

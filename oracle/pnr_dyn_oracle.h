@@ -113,6 +113,13 @@ int orc_dyn_contact_force(const orc_dyn_params* d, const double pos[3], const do
 void orc_dyn_tip(const orc_dyn_state* s, double pos[3], double vel[3]);
 
 /* one sub-step (semi-implicit Euler at d->timestep) tracking (r_ref, v_ref) */
+/* a joint's motor as Joint.control_position / control_velocity set it (bullet_scene.py:123-155); enabled 0: the env-wide law */
+typedef struct orc_joint_motor {
+    int32_t enabled, control_mode;                    /* control_mode 0 position, 1 velocity */
+    double target_position, target_velocity, position_gain, velocity_gain, max_force, max_velocity;
+} orc_joint_motor;
+void orc_dyn_world_step(const orc_dyn_params* d, const orc_params* p, const orc_state* ks, orc_dyn_state* s, const orc_joint_motor* m);
+
 void orc_dyn_substep(const orc_dyn_params* d, const orc_params* p, orc_dyn_state* s,
                      const double r_ref[ORC_DOF], const double v_ref[ORC_DOF]);
 

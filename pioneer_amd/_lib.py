@@ -132,6 +132,8 @@ SIGNATURES = {
     "pnr_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pnr_rollout": (C.c_int, [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pnr_observe": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_world_step": (C.c_int, [_VP, _VP, _VP]),
+    "pnr_set_joint_motor": (C.c_int, [_VP, C.c_int32, C.c_int32] + [C.c_double] * 6),
     "pnr_get_state": (C.c_int, [_VP, _VP, _VP]),
     "pnr_set_state": (C.c_int, [_VP, _VP, _VP]),
     "pnr_get_dyn_state": (C.c_int, [_VP, _VP, _VP]),

@@ -49,6 +49,7 @@ struct pnr_env_s {
     pnr_constants k;
     KParams base;        // constants pre-filled; pointers set per call
     DynParams dbase;     // dynamics-mode constants (zeroed in kinematic mode)
+    JointMotorTable motors;   // pnr_world_step's per-joint motors (pnr_set_joint_motor); fill_base: every joint on the handle's own law
     long long n;
     unsigned long long env_off;
     int device;
@@ -226,6 +227,13 @@ static void fill_base(pnr_handle h)
         D.kp_eff = (velocity || capped) ? 0.f : (float)c.pd_kp;
         D.c_pos = (!velocity && capped) ? (float)(c.pd_kp / c.pd_kd) : 0.f;
         D.v_cap = capped ? (float)c.max_velocity : INFINITY;
+        // pnr_world_step: until a joint is commanded it runs the handle's motor on the env's own r, v (teleport: no motor at all)
+        for (int i = 0; i < kDof; ++i) {
+            JointMotorTable& W = h->motors;
+            W.kp[i] = c.teleport ? 0.f : D.kp_eff; W.kd[i] = c.teleport ? 0.f : (float)c.pd_kd; W.cpos[i] = D.c_pos; W.vcap[i] = D.v_cap;
+            W.tcap[i] = c.torque_limit > 0 ? (float)c.torque_limit : INFINITY;
+            W.r_ref[i] = 0.f; W.v_ref[i] = 0.f; W.from_cmd[i] = 1;
+        }
     }
     D.link_contacts = c.link_contacts ? 1 : 0;
     D.inertia_scaled = c.pd_inertia_scaled ? 1 : 0;
@@ -486,6 +494,59 @@ static int launch_step(pnr_handle h, int T, const float* actions, float* obs, fl
     else if (oem && !aem) hipLaunchKernelGGL((step_kernel<true, false>), grid, block, 0, st, P.state, P.actions, P.n, P.dt, P.eps, (float)h->cfg.max_v_to_r, P);
     else if (!oem && aem) hipLaunchKernelGGL((step_kernel<false, true>), grid, block, 0, st, P.state, P.actions, P.n, P.dt, P.eps, (float)h->cfg.max_v_to_r, P);
     else hipLaunchKernelGGL((step_kernel<false, false>), grid, block, 0, st, P.state, P.actions, P.n, P.dt, P.eps, (float)h->cfg.max_v_to_r, P);
+    HIP_TRY(h, hipGetLastError());
+    return PNR_OK;
+}
+
+int pnr_set_joint_motor(pnr_handle h, int joint, int control_mode, double target_position, double target_velocity,
+                        double position_gain, double velocity_gain, double max_force, double max_velocity)
+{
+    if (!h) return fail(nullptr, PNR_ERR_INVALID, "null handle");
+    if (h->cfg.mode != PNR_MODE_DYNAMIC) return fail(h, PNR_ERR_INVALID, "pnr_set_joint_motor: motors exist in dynamics mode only");
+    if (joint < 0 || joint >= kDof) return fail(h, PNR_ERR_INVALID, "pnr_set_joint_motor: joint %d out of [0, 6)", joint);
+    if (control_mode != PNR_CONTROL_POSITION && control_mode != PNR_CONTROL_VELOCITY)
+        return fail(h, PNR_ERR_INVALID, "pnr_set_joint_motor: control_mode %d", control_mode);
+    const pnr_config& c = h->cfg;
+    // an argument left out (NaN) takes the handle's own value, as setJointMotorControl2's optional arguments take Bullet's defaults
+    const auto pick = [](double given, double dflt) { return given == given ? given : dflt; };
+    const double kp = pick(position_gain, c.pd_kp), kd = pick(velocity_gain, c.pd_kd);
+    const double fmax = pick(max_force, c.torque_limit), vmax = pick(max_velocity, c.max_velocity);
+    if (kd <= 0 && control_mode == PNR_CONTROL_POSITION && vmax > 0)
+        return fail(h, PNR_ERR_INVALID, "pnr_set_joint_motor: maxVelocity needs velocity_gain > 0");
+    const bool velocity = control_mode == PNR_CONTROL_VELOCITY, capped = !velocity && vmax > 0;
+    JointMotorTable& W = h->motors;       // the folding of fill_base (oracle: orc_dyn_motor_torque), per joint
+    W.kp[joint] = (velocity || capped) ? 0.f : (float)kp;
+    W.kd[joint] = (float)kd;
+    W.cpos[joint] = capped ? (float)(kp / kd) : 0.f;
+    W.vcap[joint] = capped ? (float)vmax : INFINITY;
+    W.tcap[joint] = fmax > 0 ? (float)fmax : INFINITY;
+    W.r_ref[joint] = velocity ? 0.f : (float)target_position;
+    W.v_ref[joint] = (float)pick(target_velocity, 0.0);
+    W.from_cmd[joint] = 0;
+    return PNR_OK;
+}
+
+int pnr_world_step(pnr_handle h, float* joint_state, void* stream)
+{
+    if (!h) return fail(nullptr, PNR_ERR_INVALID, "null handle");
+    if (!h->ready) return fail(h, PNR_ERR_INVALID, "pnr_world_step before the first pnr_reset (or pnr_set_state)");
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->cfg.mode != PNR_MODE_DYNAMIC) {
+        if (!joint_state) return fail(h, PNR_ERR_INVALID, "pnr_world_step: a kinematic-mode handle steps the caller's joint_state [n][12]");
+        const long long items = h->n * kDof;
+        hipLaunchKernelGGL(kin_world_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, joint_state, (long long)h->n, (float)h->k.dt);
+        HIP_TRY(h, hipGetLastError());
+        return PNR_OK;
+    }
+    if (joint_state) return fail(h, PNR_ERR_INVALID, "pnr_world_step: joint_state must be NULL in dynamics mode (the simulated joints are the handle's)");
+    const DynParams& D = h->dbase;
+    const dim3 grid((unsigned)((h->n + kWave - 1) / kWave));
+    const bool rnd = h->cfg.randomize || h->dyn_set, ct = D.has_ground || D.has_box || D.n_scene > 0;
+#define PNR_WORLD_LAUNCH(R, C) hipLaunchKernelGGL((dyn_world_kernel<R, C>), grid, dim3(kWave), 0, st, h->state, h->dyn, (long long)h->n, D, h->motors)
+    if (D.inertia_scaled) { if (ct) { if (rnd) PNR_WORLD_LAUNCH(true, 3); else PNR_WORLD_LAUNCH(false, 3); } else { if (rnd) PNR_WORLD_LAUNCH(true, 2); else PNR_WORLD_LAUNCH(false, 2); } }
+    else { if (ct) { if (rnd) PNR_WORLD_LAUNCH(true, 1); else PNR_WORLD_LAUNCH(false, 1); } else { if (rnd) PNR_WORLD_LAUNCH(true, 0); else PNR_WORLD_LAUNCH(false, 0); } }
+#undef PNR_WORLD_LAUNCH
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;
 }

@@ -59,6 +59,15 @@ struct DynParams {
     const SceneBody* scene;     // [n_scene] in device memory (a by-value array indexed by the loop counter went to scratch)
 };
 
+// pnr_world_step (World.step, bullet_scene.py:273-275): the motor of every joint as Joint.control_position / control_velocity
+// left it (bullet_scene.py:123-155), in the terms of the one motor law above — the same for every env of the handle.  A joint
+// nobody commanded keeps the handle's own motor (DynParams), tracking the env's command state r, v (from_cmd).
+struct JointMotorTable {
+    float kp[kDof], kd[kDof], cpos[kDof], vcap[kDof], tcap[kDof];   // kp_eff, kd, c_pos, v_cap, torque cap (+inf: none) per joint
+    float r_ref[kDof], v_ref[kDof];                                  // targetPosition / targetVelocity
+    int from_cmd[kDof];                                              // 1: targets = the env's own r, v (no per-joint command)
+};
+
 constexpr float kFrictionEps = 0.05f;   // smooth sign(qd) = qd / sqrt(qd^2 + eps^2)
 
 // 1/x: hardware reciprocal (1 ulp) + one Newton step, instead of the ~10-instruction IEEE division
@@ -591,7 +600,7 @@ __device__ __forceinline__ void contact_wrenches(const DynParams& D, const float
 // PHYS: bit 0 = contacts, bit 1 = the inertia-scaled motor (its acceleration requests in ades, torque cap tcap)
 template <int PHYS>
 __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const float (&c)[kDof], const float (&s)[kDof],
-                                    const float (&qd)[kDof], const float (&tau)[kDof], const float (&ades)[kDof], float tcap,
+                                    const float (&qd)[kDof], const float (&tau)[kDof], const float (&ades)[kDof], const float (&tcap)[kDof],
                                     float (&qdd)[kDof])
 {
     constexpr bool CONTACT = (PHYS & 1) != 0, SCALED = (PHYS & 2) != 0;
@@ -620,20 +629,20 @@ __device__ __forceinline__ void aba(const DynParams& D, const DynModel& M, const
     if (CONTACT) pA = pA - fext[5];
     rigid_body<4>(M, v[4], IP, pP);
     if (CONTACT) pP = pP - fext[4];
-    aba_inward<5, SCALED>(IA, pA, v[5], qd[5], tau[5], ades[5], tcap, c[5], s[5], B[5], IP, pP);
+    aba_inward<5, SCALED>(IA, pA, v[5], qd[5], tau[5], ades[5], tcap[5], c[5], s[5], B[5], IP, pP);
     IA = IP; pA = pP; rigid_body<3>(M, v[3], IP, pP);
     if (CONTACT) pP = pP - fext[3];
-    aba_inward<4, SCALED>(IA, pA, v[4], qd[4], tau[4], ades[4], tcap, c[4], s[4], B[4], IP, pP);
+    aba_inward<4, SCALED>(IA, pA, v[4], qd[4], tau[4], ades[4], tcap[4], c[4], s[4], B[4], IP, pP);
     IA = IP; pA = pP; rigid_body<2>(M, v[2], IP, pP);
     if (CONTACT) pP = pP - fext[2];
-    aba_inward<3, SCALED>(IA, pA, v[3], qd[3], tau[3], ades[3], tcap, c[3], s[3], B[3], IP, pP);
+    aba_inward<3, SCALED>(IA, pA, v[3], qd[3], tau[3], ades[3], tcap[3], c[3], s[3], B[3], IP, pP);
     IA = IP; pA = pP; rigid_body<1>(M, v[1], IP, pP);
     if (CONTACT) pP = pP - fext[1];
-    aba_inward<2, SCALED>(IA, pA, v[2], qd[2], tau[2], ades[2], tcap, c[2], s[2], B[2], IP, pP);
+    aba_inward<2, SCALED>(IA, pA, v[2], qd[2], tau[2], ades[2], tcap[2], c[2], s[2], B[2], IP, pP);
     IA = IP; pA = pP; rigid_body<0>(M, v[0], IP, pP);
-    aba_inward<1, SCALED>(IA, pA, v[1], qd[1], tau[1], ades[1], tcap, c[1], s[1], B[1], IP, pP);
+    aba_inward<1, SCALED>(IA, pA, v[1], qd[1], tau[1], ades[1], tcap[1], c[1], s[1], B[1], IP, pP);
     IA = IP; pA = pP;
-    aba_inward<0, SCALED>(IA, pA, v[0], qd[0], tau[0], ades[0], tcap, c[0], s[0], B[0], IP, pP);
+    aba_inward<0, SCALED>(IA, pA, v[0], qd[0], tau[0], ades[0], tcap[0], c[0], s[0], B[0], IP, pP);
 
     // pass 3: base -> tip; gravity as a base acceleration +g along z
     P3 a0 = {{0.f, 0.f}, {0.f, 0.f}, {0.f, D.gravity}}, a1;
@@ -741,17 +750,20 @@ __device__ __forceinline__ void dyn_lane_load(const DynLead& in, long long base,
 #endif
 constexpr int kDynStageWords = 33;
 
-template <int PHYS>
+// WORLD (pnr_world_step): the sub-steps alone — no command integration, no teleport — with the per-joint motor table W.
+template <int PHYS, bool WORLD = false>
 __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, float (&a)[kDof], float (&v)[kDof],
                                          float (&r)[kDof], float (&q)[kDof], float (&qd)[kDof], const float (&sc)[kNumLinks],
                                          const float (&fric_)[kDof], const float (&damp_)[kDof], const float (&act)[kDof],
-                                         float* stage = nullptr)
+                                         float* stage = nullptr, const JointMotorTable* W = nullptr)
 {
+    if constexpr (!WORLD) {
 #pragma unroll
     for (int i = 0; i < kDof; ++i) {
         integrate_joint(a[i], v[i], r[i], in.max_v_to_r * (limit_hi(i) - limit_lo(i)), limit_lo(i), limit_hi(i),
                         in.dt, in.eps, v[i], r[i]);
         a[i] = act[i];
+    }
     }
 
     DynModel M;
@@ -770,7 +782,7 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
     }
 #endif
 
-    if (D.teleport) {   // resetJointState semantics: pioneer_knm_env.py:148, bullet_scene.py:157-165
+    if (!WORLD && D.teleport) {   // resetJointState semantics: pioneer_knm_env.py:148, bullet_scene.py:157-165
 #pragma unroll
         for (int i = 0; i < kDof; ++i) { q[i] = r[i]; qd[i] = 0.f; }
     }
@@ -804,11 +816,21 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
 #endif
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {
+            float tq;
+            if constexpr (WORLD) {      // the joint's own motor (wave-uniform table entries)
+                const float rr = W->from_cmd[i] ? r[i] : W->r_ref[i], vr = W->from_cmd[i] ? v[i] : W->v_ref[i];
+                const float dq = rr - q[i];
+                const float v_ask = fminf(fmaxf(vr + W->cpos[i] * dq, -W->vcap[i]), W->vcap[i]);
+                tq = W->kp[i] * dq + W->kd[i] * (v_ask - qd[i]);
+                if constexpr ((PHYS & 2) != 0) { ades[i] = tq; tq = 0.f; }
+                else { ades[i] = 0.f; tq = fminf(fmaxf(tq, -W->tcap[i]), W->tcap[i]); }
+            } else {
             const float dq = r[i] - q[i];
             const float v_ask = fminf(fmaxf(v[i] + cpos * dq, -vcap), vcap);
-            float tq = kp * dq + kd * (v_ask - qd[i]);
+            tq = kp * dq + kd * (v_ask - qd[i]);
             if constexpr ((PHYS & 2) != 0) { ades[i] = tq; tq = 0.f; }        // an acceleration request: scaled and capped inside the ABA
             else { ades[i] = 0.f; tq = fminf(fmaxf(tq, -tcap), tcap); }
+            }
             tq -= damp[i] * qd[i];
             tq -= fric[i] * qd[i] * __builtin_amdgcn_rsqf(qd[i] * qd[i] + kFrictionEps * kFrictionEps);
             tau[i] = tq;
@@ -817,7 +839,10 @@ __device__ __forceinline__ void dyn_core(const DynLead& in, const DynParams& D, 
             float c[kDof], s[kDof];
 #pragma unroll
             for (int i = 0; i < kDof; ++i) { c[i] = cs[i].x; s[i] = cs[i].y; }
-            aba<PHYS>(D, M, c, s, qd, tau, ades, tcap, qdd);
+            float tc[kDof];
+#pragma unroll
+            for (int i = 0; i < kDof; ++i) tc[i] = WORLD ? W->tcap[i] : tcap;
+            aba<PHYS>(D, M, c, s, qd, tau, ades, tc, qdd);
         }
 #pragma unroll
         for (int i = 0; i < kDof; ++i) {   // semi-implicit Euler + inelastic joint limits (selects, no branches)

@@ -681,6 +681,58 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const KParams P, const Dyn
     }
 }
 
+// ---------------------------------------------------------------------------------
+// World.step (bullet_scene.py:273-275), pnr_world_step: frame_skip sub-steps of the simulator and NOTHING else — no command
+// integration, reward, TimeLimit, reset or observation.  One env per lane (the phase-A shape of dyn_step_kernel); the joints'
+// motors are the per-joint table W (Joint.control_position / control_velocity, bullet_scene.py:123-155).
+// ---------------------------------------------------------------------------------
+template <bool RAND, int PHYS>
+__global__ __launch_bounds__(kWave) void dyn_world_kernel(const float4* __restrict__ state, float* __restrict__ dyn, const long long n,
+                                                          const DynParams D, const JointMotorTable W)
+{
+    const long long e = (long long)blockIdx.x * kWave + threadIdx.x;
+    if (e >= n) return;
+    const long long n2 = 2 * n;
+    float a[kDof], v[kDof], r[kDof], q[kDof], qd[kDof], sc[kNumLinks], fric[kDof], damp[kDof], act[kDof];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {           // the env's command state r, v: what a joint without a command of its own tracks
+        const float4 k0 = state[2 * e + p], k1 = state[n2 + 2 * e + p], k2 = state[2 * n2 + 2 * e + p];
+        a[3 * p] = k0.x; a[3 * p + 1] = k0.y; a[3 * p + 2] = k0.z; v[3 * p] = k0.w;
+        v[3 * p + 1] = k1.x; v[3 * p + 2] = k1.y; r[3 * p] = k1.z; r[3 * p + 1] = k1.w;
+        r[3 * p + 2] = k2.x;
+    }
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) {
+        q[i] = dyn[(long long)i * n + e]; qd[i] = dyn[(long long)(6 + i) * n + e];
+        fric[i] = dyn[(long long)(23 + i) * n + e]; damp[i] = dyn[(long long)(29 + i) * n + e];
+        act[i] = 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < kNumLinks; ++l) sc[l] = RAND ? dyn[(long long)(12 + l) * n + e] : 1.0f;
+    const DynLead lead = {state, dyn, nullptr, n, 0.0, 0.0, 0.f};
+    dyn_core<PHYS, true>(lead, D, a, v, r, q, qd, sc, fric, damp, act, nullptr, &W);
+#pragma unroll
+    for (int i = 0; i < kDof; ++i) { dyn[(long long)i * n + e] = q[i]; dyn[(long long)(6 + i) * n + e] = qd[i]; }
+}
+
+// The same call on a kinematic-mode handle: there is no simulated state, the caller holds the joints as Bullet would after
+// resetJointState(position, velocity) — js [n][12] = q[6] | qd[6] — and with no gravity, no motor and no collision shapes
+// (the reference's URDF and defaults) frame_skip x stepSimulation carries each joint on at its velocity:
+// q += qd * step_time, stopped at its limit with the velocity zeroed there.
+__global__ void kin_world_kernel(float* __restrict__ js, long long n, float step_time)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * kDof) return;
+    const long long e = i / kDof; const int j = (int)(i % kDof);
+    constexpr float lim[kDof] = {limit_hi(0), limit_hi(1), limit_hi(2), limit_hi(3), limit_hi(4), limit_hi(5)};
+    const float hi = lim[j];
+    float q = js[e * 12 + j], qd = js[e * 12 + 6 + j];
+    q = __builtin_fmaf(qd, step_time, q);
+    if (q >= hi) { q = hi; qd = 0.f; }
+    if (q <= -hi) { q = -hi; qd = 0.f; }
+    js[e * 12 + j] = q; js[e * 12 + 6 + j] = qd;
+}
+
 // canonical planar words [24][n] (include/pioneer_amd.h) <-> the engine's pair records
 __device__ __forceinline__ int word_of(int p, int plane, int comp)
 {

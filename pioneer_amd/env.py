@@ -73,6 +73,7 @@ class PioneerKinematicEnv(compat.GymEnv):
         self.eps = self._vec.eps                                           # :61
 
         from .scene import Scene, World
+        self._motor_cmds = {}                                              # Joint.control_*: joint -> pnr_set_joint_motor arguments
         self.scene = Scene(self)                                           # bullet_env.py:86-88: the objects the demo drives
         self.world = World(self)
         self._obs = self.reset_world()                                     # :69 (+ reset_simulator in BulletEnv.__init__)
@@ -91,6 +92,8 @@ class PioneerKinematicEnv(compat.GymEnv):
         self._vec.set_state(state)
         if dyn is not None:
             self._vec.set_dyn_state(dyn)
+            for args in self._motor_cmds.values():
+                self._vec.set_joint_motor(*args)
         old.close()
 
     # -- pickling: by constructor arguments, like gym.utils.EzPickle (pioneer_knm_env.py:38, :51) --
@@ -155,6 +158,7 @@ class PioneerKinematicEnv(compat.GymEnv):
         tgt = Item("target", "sphere", self._obs[129:132], (0.0, 0.0, 0.0, 1.0), False, (self.config.target_radius, 0.0, 0.0))
         self.scene.items = [i for i in self.scene.items if i.name != "target"] + [tgt]
         self.scene.items_by_name["target"] = tgt
+        self.scene.sync_from_env()
         return self._obs
 
     def reset(self) -> Observation:                                        # bullet_env.py:187-190
@@ -162,6 +166,7 @@ class PioneerKinematicEnv(compat.GymEnv):
         from .scene import Scene, World
         if self._vec.engine_config != self._base_engine:
             self._rebuild_engine(self._base_engine)
+        self._motor_cmds = {}
         self.scene, self.world = Scene(self), World(self)
         self.world_index += 1
         self.step_index = 0
@@ -183,6 +188,7 @@ class PioneerKinematicEnv(compat.GymEnv):
             "a": arr2str(st["a"][0]), "v": arr2str(st["v"][0]), "r": arr2str(st["r"][0]),
         }
         self._obs = obs
+        self.scene.sync_from_env()                                         # :148: act() teleported the joints into the simulator
         return obs, reward, is_done, info_dict
 
     def observe(self) -> Observation:                                      # :184-211

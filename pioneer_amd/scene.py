@@ -1,22 +1,29 @@
 """``env.scene`` / ``env.world``: the object surface the reference's demo drives (pioneer_knm_env.py:245-296 ``__main__``:
 ``env.scene.create_body_box / create_body_plane``, ``env.scene.rpy2quat``, ``env.scene.joints_by_name[...]`` with ``position()``,
-``lower_limit / upper_limit``, ``reset_state(position, velocity)``; ``env.world.step()``, ``env.world.step_time``) over the HIP engine.
+``lower_limit / upper_limit``, ``reset_state(position, velocity)``, ``control_position / control_velocity``; ``env.world.step()``,
+``env.world.step_time``) over the HIP engine.
 
 The reference's ``Scene`` / ``Joint`` / ``World`` (bullet_scene.py:70-279) are views of a PyBullet client; here they are views of the
-one-env engine batch of ``PioneerKinematicEnv``.  What maps and what does not:
+one-env engine batch of ``PioneerKinematicEnv``.  What maps and how:
 
-* joints: the six revolute joints of the URDF, by the URDF's names (bullet_env.py:141-146 keeps exactly these); ``position() /
-  velocity()`` read the engine's joint state (kinematic mode: r, v; dynamics mode: the simulated q, q̇), ``reset_state`` writes it —
-  ``resetJointState``, bullet_scene.py:157-165.  ``control_position / control_velocity`` raise: the engine's motor law is one
-  configuration for all joints (``EngineConfig.control_mode``), not a per-joint command.
+* joints: the six revolute joints of the URDF, by the URDF's names (bullet_env.py:141-146 keeps exactly these).  The Bullet client's
+  joint state is NOT the env's ``self.r / self.v`` (pioneer_knm_env.py:144-146): the env teleports its r into Bullet with velocity 0
+  on every step (:148, bullet_scene.py:157-165) and nothing flows back.  So ``position() / velocity() / reset_state`` work on the
+  SIMULATOR's joints and never on the env's command state:
+  dynamics mode — the engine's simulated q, q̇ (``pnr_get_dyn_state``);
+  kinematic mode — a [1, 12] device buffer of this Scene (q | q̇), set to (r, 0) by every ``env.step`` / ``reset_world`` — what act()
+  leaves in Bullet — and advanced by ``world.step()``.  ``env.step(a)`` followed by ``env.world.step()`` therefore changes nothing.
+* ``control_position / control_velocity`` (bullet_scene.py:123-155): dynamics mode: the joint's motor for ``world.step()``
+  (``pnr_set_joint_motor``: the engine's one motor law with this joint's targets, gains, force and maxVelocity; an argument left
+  ``None`` takes the EngineConfig's value).  Kinematic mode has no motors (the engine says so).
 * bodies: ``create_body_box / plane / sphere`` with ``mass == 0``.  The reference's arm has no ``<collision>`` shapes, so there a
   created body never touches it: in kinematic mode a body is a record (``items_by_name``), as inert as in the reference.  In dynamics
   mode a body with a collision shape becomes a static scene body of the engine (``EngineConfig.scene``; the handle is rebuilt with the
-  env's state carried over).  ``mass > 0`` asserts: moving bodies are not modelled (the reference never creates one).
-* ``world.step()``: ``frame_skip`` × ``stepSimulation``.  Under the env's defaults that is the identity on everything the env
-  observes — except for a joint whose state was reset WITH a velocity, which Bullet then carries on at that velocity:
-  kinematic mode advances such joints by ``velocity × step_time`` (clamped at the limits, velocity zeroed there) and nothing else.
-  In dynamics mode the sub-steps belong to ``env.step(action)``; ``world.step()`` raises.
+  env's state and the joints' motors carried over).  ``mass > 0`` asserts: moving bodies are not modelled (the reference never creates one).
+* ``world.step()``: ``frame_skip`` × ``stepSimulation`` = ONE engine launch (``pnr_world_step``), nothing on the host.  Dynamics
+  mode: the articulated-body sub-steps (gravity, contacts with the scene's bodies, limits, every joint's motor) and nothing else —
+  no command integration, reward or observation.  Kinematic mode: each joint carries on at the velocity it was reset with
+  (q += q̇ × step_time, stopped at its limit): what Bullet does without gravity, motor torque and collision shapes.
 Build-defined behaviour where the reference delegates to Bullet: parity unpinned, like the rest of the Bullet boundary.
 """
 import dataclasses
@@ -26,7 +33,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from . import model
+from . import _lib, model
 from .config import scene_box, scene_plane, scene_sphere
 
 
@@ -62,33 +69,44 @@ class Joint:
     def position(self) -> float:
         if self._dynamic():
             return float(self._env._vec.get_dyn_state()[self.index, 0])
-        return float(self._env._vec.state_dict()["r"][0, self.index])
+        return float(self._env.scene._bullet[0, self.index])
 
     def velocity(self) -> float:
         if self._dynamic():
             return float(self._env._vec.get_dyn_state()[6 + self.index, 0])
-        return float(self._env._vec.state_dict()["v"][0, self.index])
+        return float(self._env.scene._bullet[0, 6 + self.index])
 
     def reset_state(self, position: float, velocity: Optional[float] = None):
-        """resetJointState (bullet_scene.py:157-165): the joint is put at ``position`` (and ``velocity``, else 0)."""
-        vec = self._env._vec
+        """resetJointState (bullet_scene.py:157-165): the SIMULATOR's joint is put at ``position`` (and ``velocity``, else 0); the
+        env's own r / v are not touched (the reference's are not either)."""
         v = 0.0 if velocity is None else float(velocity)
-        w = vec.get_state()
-        f = w.view(torch.float32)
-        f[12 + self.index, 0] = float(position)               # planar state words: a 0..5, v 6..11, r 12..17
-        f[6 + self.index, 0] = v
-        vec.set_state(w)
         if self._dynamic():
+            vec = self._env._vec
             d = vec.get_dyn_state()
             d[self.index, 0] = float(position)
             d[6 + self.index, 0] = v
             vec.set_dyn_state(d)
+        else:
+            b = self._env.scene._bullet
+            b[0, self.index] = float(position)
+            b[0, 6 + self.index] = v
 
-    def control_position(self, *args, **kwargs):
-        raise NotImplementedError("per-joint motor commands are not part of the engine: its motor law is configured per env "
-                                  "(EngineConfig.control_mode, pd_kp, pd_kd, max_velocity); commands go through env.step(action)")
+    def _set_motor(self, mode, position, velocity, position_gain, velocity_gain, max_force, max_velocity):
+        nan = float("nan")
+        args = (self.index, mode, nan if position is None else float(position), nan if velocity is None else float(velocity),
+                nan if position_gain is None else float(position_gain), nan if velocity_gain is None else float(velocity_gain),
+                nan if max_force is None else float(max_force), nan if max_velocity is None else float(max_velocity))
+        self._env._vec.set_joint_motor(*args)
+        self._env._motor_cmds[self.index] = args                  # re-applied when the engine handle is rebuilt (a body created later)
 
-    control_velocity = control_position
+    def control_position(self, position: float, velocity: Optional[float] = None, max_velocity: Optional[float] = None,
+                         max_force: Optional[float] = None, position_gain: Optional[float] = None, velocity_gain: Optional[float] = None):
+        """setJointMotorControl2(POSITION_CONTROL, ...) (bullet_scene.py:123-142) for ``world.step()``."""
+        self._set_motor(_lib.CONTROL_POSITION, position, velocity, position_gain, velocity_gain, max_force, max_velocity)
+
+    def control_velocity(self, velocity: float, max_force: Optional[float] = None):
+        """setJointMotorControl2(VELOCITY_CONTROL, ...) (bullet_scene.py:144-155) for ``world.step()``."""
+        self._set_motor(_lib.CONTROL_VELOCITY, None, velocity, None, None, max_force, None)
 
 
 class Scene:
@@ -98,6 +116,14 @@ class Scene:
         self.items_by_name: Dict[str, Item] = {}
         self.joints: List[Joint] = [Joint(env, i, jd) for i, jd in enumerate(model.revolute_joints())]
         self.joints_by_name: Dict[str, Joint] = {j.name: j for j in self.joints}
+        # kinematic mode: the simulator's joints (q | qd) as act() leaves them in Bullet; see the module docstring
+        self._bullet = torch.zeros((1, 12), dtype=torch.float32, device=env._vec.device)
+
+    def sync_from_env(self):
+        """What act() does to the Bullet client on every step (pioneer_knm_env.py:148): joints at the env's r, velocity 0."""
+        if self._env._vec.engine_config.mode != "dynamic":
+            self._bullet[0, 0:6] = self._env._vec.get_state().view(torch.float32)[12:18, 0]
+            self._bullet[0, 6:12] = 0.0
 
     # -- items -----------------------------------------------------------------------------------------------------------
     def add_item(self, item: Item):
@@ -156,20 +182,6 @@ class World:
         return self.timestep * self.frame_skip
 
     def step(self):
+        """frame_skip x stepSimulation: ONE launch of the engine (pnr_world_step), no host arithmetic."""
         vec = self._env._vec
-        if vec.engine_config.mode == "dynamic":
-            raise NotImplementedError("dynamics mode: the sub-steps run inside env.step(action) (one launch: command integration, "
-                                      "frame_skip sub-steps, reward, observation)")
-        w = vec.get_state()
-        f = w.view(torch.float32)
-        v = f[6:12, 0].cpu().numpy().astype(np.float64)
-        if not v.any():
-            return                                                            # the identity of SURVEY 8 a6
-        r = f[12:18, 0].cpu().numpy().astype(np.float64) + v * self.step_time
-        lo, hi = (x.astype(np.float64) for x in self._env.joint_limits())
-        hit = (r >= hi) | (r <= lo)
-        r = np.clip(r, lo, hi)
-        v = np.where(hit, 0.0, v)
-        f[12:18, 0] = torch.from_numpy(r.astype(np.float32)).to(f.device)
-        f[6:12, 0] = torch.from_numpy(v.astype(np.float32)).to(f.device)
-        vec.set_state(w)
+        vec.world_step(None if vec.engine_config.mode == "dynamic" else self._env.scene._bullet)

@@ -189,6 +189,24 @@ class PioneerVectorEnv:
                                        self._stream()))
         return obs, rew, done, trunc
 
+    def world_step(self, joint_state=None):
+        """World.step() alone (bullet_scene.py:273-275; pnr_world_step): the simulator's sub-steps and nothing else.  Dynamics mode:
+        ``joint_state`` is None (the handle's q, qd move); kinematic mode: the caller's float32 [N, 12] device buffer (q | qd)."""
+        self._check_handle()
+        js = None
+        if joint_state is not None:
+            js = self._in(joint_state, (self.num_envs, 12), torch.float32, "joint_state")
+            assert js.data_ptr() == joint_state.data_ptr(), "joint_state is updated in place: it must already be a contiguous float32 device tensor"
+        self._chk(self.lib.pnr_world_step(self._h, _ptr(js) if js is not None else None, self._stream()))
+
+    def set_joint_motor(self, joint, control_mode, target_position=float("nan"), target_velocity=float("nan"), position_gain=float("nan"),
+                        velocity_gain=float("nan"), max_force=float("nan"), max_velocity=float("nan")):
+        """Joint.control_position / control_velocity (bullet_scene.py:123-155; pnr_set_joint_motor) for ``joint`` of every env; NaN = the
+        EngineConfig's value.  Honoured by ``world_step``."""
+        self._check_handle()
+        self._chk(self.lib.pnr_set_joint_motor(self._h, int(joint), int(control_mode), float(target_position), float(target_velocity),
+                                               float(position_gain), float(velocity_gain), float(max_force), float(max_velocity)))
+
     def observe(self, out=None):
         """observe() without stepping (pioneer_knm_env.py:184-211)."""
         self._check_handle()

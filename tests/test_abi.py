@@ -141,7 +141,7 @@ def test_product_library_has_no_ablation_switches(hip_lib):
     hits = sorted(set(re.findall(rb"PNR_[A-Z_]{3,}", blob)))
     assert hits == [], hits
     assert b"getenv" not in blob
-    assert hip_lib.pnr_abi_version() == _lib.ABI_VERSION == 4
+    assert hip_lib.pnr_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_missing_library_raises(monkeypatch, tmp_path):

@@ -65,9 +65,13 @@ def test_config3_anchor_and_dynamics_lane_roofline_are_in_the_line():
         assert "error" not in p and p["losses_finite"] and p["total_envs"] == 65536 and p["sgd_minibatch_size"] == 32768 and p["rollout_T"] == 32
         assert p["sgd_updates_per_iter"] == 4 * 64 and p["roofline"]["us_per_update"] > 0 and p["value"] > 1e6
     assert a["f32"]["value"] < a["bf16"]["value"]
-    lanes = r["dynamics_randomized"]["roofline"]["fp32_lanes"]
-    assert lanes["unit"].startswith("T fp32 lane-operations") and 0.05 < lanes["frac"] < 1.0 and abs(lanes["peak"] - 78.65) < 0.1
-    assert "second wave" in lanes["note"]
+    rf = r["dynamics_randomized"]["roofline"]
+    if rf["frac"] is None:             # the instruction count is looked up from a committed counter pass: quoted only on the sources it ran on
+        assert "stale" in rf["source"] or "profiles/" in rf["source"]
+    else:
+        lanes = rf["fp32_lanes"]
+        assert lanes["unit"].startswith("T fp32 lane-operations") and 0.05 < lanes["frac"] < 1.0 and abs(lanes["peak"] - 78.65) < 0.1
+        assert "second wave" in lanes["note"]
 
 
 def test_two_ranks_self_launched_on_the_metric_configuration():

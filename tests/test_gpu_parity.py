@@ -620,21 +620,28 @@ def test_scene_and_world_objects_of_the_reference_demo():
         env.scene.create_body_sphere(name="ball", collision=True, mass=1.0, radius=0.2, position=(0, 0, 0), orientation=q)
     j = env.scene.joints_by_name["robot:hinge1_to_arm1"]
     assert abs(j.upper_limit - 1.309) < 1e-6 and j.lower_limit == -j.upper_limit
-    # the demo's loop: reset_state(position(), velocity) then world.step(): the joint sweeps to its limit and stops there
+    # the demo's loop: reset_state(position(), velocity) then world.step(): the SIMULATOR's joint sweeps to its limit and stops there
+    # (one engine launch per world.step(): pnr_world_step on the scene's joint buffer); the env's own r / v are never touched
+    r_env, obs_env = env.joint_positions().copy(), env.observe().copy()
     j.reset_state(0.25, velocity=1.0)
-    others = env.joint_positions().copy()
+    others = [k.position() for k in env.scene.joints]
     for k in range(3):
         env.world.step()
     assert abs(j.position() - (0.25 + 3 * env.world.step_time)) < 1e-6 and abs(j.velocity() - 1.0) < 1e-7
-    now = env.joint_positions()
+    now = [k.position() for k in env.scene.joints]
     assert np.array_equal(np.delete(now, 1), np.delete(others, 1))                  # nothing else moved
     for k in range(40):
         env.world.step()
     assert j.position() == pytest.approx(j.upper_limit, abs=1e-7) and j.velocity() == 0.0
-    obs = env.observe()
-    assert abs(obs[1] - j.position()) < 1e-7                                        # the env observes the joint where the scene put it
-    with pytest.raises(NotImplementedError):
-        j.control_velocity(velocity=1.0)
+    assert np.array_equal(env.joint_positions(), r_env) and np.array_equal(env.observe(), obs_env)      # pioneer_knm_env.py:144-146: self.r is the env's
+    # act() teleports the env's r into the simulator with velocity 0 (:148): env.step(a) then env.world.step() is the identity
+    o1, _, _, _ = env.step(env.a_max * 0.3)
+    assert [k.position() for k in env.scene.joints] == pytest.approx(list(env.joint_positions()), abs=0) and j.velocity() == 0.0
+    env.world.step()
+    assert np.array_equal(env.observe(), o1) and [k.position() for k in env.scene.joints] == pytest.approx(list(env.joint_positions()), abs=0)
+    from pioneer_amd import PnrError
+    with pytest.raises(PnrError):
+        j.control_velocity(velocity=1.0)                                            # kinematic mode has no motors
     env.reset()                                                                     # reset_simulator(): a fresh scene
     assert set(env.scene.items_by_name) == {"target"}
     env.close()
@@ -646,8 +653,10 @@ def test_scene_and_world_objects_of_the_reference_demo():
     assert len(dyn._vec.engine_config.scene) == 1 and np.array_equal(dyn.joint_positions(), r_before)     # state carried over
     o, r, d, info = dyn.step(np.zeros(6, dtype=np.float32))
     assert np.isfinite(o).all()
-    with pytest.raises(NotImplementedError):
-        dyn.world.step()
+    q0 = np.array([k.position() for k in dyn.scene.joints])
+    dyn.world.step()                                                                # the sub-steps alone: a launch, no reward / observation
+    assert np.isfinite([k.position() for k in dyn.scene.joints]).all() and dyn.step_index == 1 and np.array_equal(dyn.joint_positions(), r_before)
+    assert not np.array_equal(q0, [k.position() for k in dyn.scene.joints])         # gravity moved the arm
     dyn.reset()
     assert len(dyn._vec.engine_config.scene) == 0
     dyn.close()
