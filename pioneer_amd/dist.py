@@ -56,7 +56,21 @@ def init_distributed(backend: str = None, device: torch.device = None) -> Tuple[
     return rank, world
 
 
+_FORCE = False
+
+
+def force_collectives(on: bool = True) -> None:
+    """Take the several-rank code paths (gradient bucket -> all-reduce -> pnr_mlp_adam, the two-chain learner, the filter / metric
+    all-reduces) with whatever process group is initialised, a ONE-rank group included.  What a one-GPU box can still check of the
+    N > 1 path: the collectives then are real RCCL calls with RCCL's asynchronous stream semantics (a world-size-1 all-reduce is the
+    identity on the data, so results must equal the no-collective run bit for bit).  tests/test_gpu_multirank.py."""
+    global _FORCE
+    _FORCE = bool(on)
+
+
 def is_dist() -> bool:
+    if (not _SOLO) and _FORCE and dist.is_available() and dist.is_initialized():
+        return True
     return (not _SOLO) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
