@@ -551,10 +551,10 @@ static_assert((kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats + 4 * 8) * 4
 static_assert(kFwdWaves * 32 == kMlpHid, "one 32-row block of the 256 hidden units per wave");
 
 // the one-row-block product: acc[cb] += W[32 rows of this wave][K] . tile[BM samples][K]^T (see MlpGemm for the two steps)
-template <int K, int STRIDE, int NS = 1>
+template <int K, int STRIDE, int NS = 1, int PLANE = kTilePlane, int DEPTH = PNR_MLP_RING>
 struct MlpGemm1 {
     static constexpr int KS = K / 16;
-    static constexpr int D = PNR_MLP_RING;
+    static constexpr int D = DEPTH;
     bf16x8 a[D][NS];
     const __bf16* wa;
     // w_block: this wave's row block in the fragment-native packing: k-step ks at ks * 512 (plane s: + s * kWPlane)
@@ -570,7 +570,7 @@ struct MlpGemm1 {
     }
     // init: what every column block's accumulators start from (the bias rows of this wave, the same for every sample), read as
     // the FIRST MFMA's C operand — 16 copies per column block and product less than accumulators initialised beforehand; or null
-    // tile: plane 0 of the LDS tile (plane s: + s * kTilePlane)
+    // tile: plane 0 of the LDS tile (plane s: + s * PLANE)
     template <class F>
     __device__ __forceinline__ void run(const __bf16* tile, f32x16 (&acc)[kMlpCB], int lane, F&& after_loads, const f32x16* init = nullptr)
     {
@@ -597,7 +597,7 @@ struct MlpGemm1 {
                     // (PNR_MLP_DIAG & 512, timing only: ONE sample-fragment read per k-step serves both column blocks — what a
                     // 4 row-groups x 2 sample-halves wave layout would save in LDS reads, without its doubled weight stream)
                     if ((PNR_MLP_DIAG & 512) && cb > 0) b[s][cb] = b[s][0];
-                    else b[s][cb] = *reinterpret_cast<const bf16x8*>(tb + s * kTilePlane + cb * 32 * STRIDE + 16 * ks);
+                    else b[s][cb] = *reinterpret_cast<const bf16x8*>(tb + s * PLANE + cb * 32 * STRIDE + 16 * ks);
                 }
 #pragma unroll
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
@@ -715,9 +715,26 @@ __device__ __forceinline__ void mlp_tile_b2_products(const __bf16* ztile, int zs
 // (ppo_value_sample).  hd: the tile's head rows [64][16] float32, gt: its head gradients [64][kGS] bf16 (written here, with the
 // float32 copy to g_head), rl: the parked record (rec_early) — all LDS; wsum [8 waves][4]: the waves' partial loss sums.
 // As one thread per sample on wave 0 the other seven waves waited 4 300 cycles of a tile's 38 000 for it (profiles/r03_d_mlp_stamps.json).
+// this thread's share of the tile's record, in registers (the compact layout of the fused kernel has no LDS to park it in): requested
+// early — from inside the layer-2 product — by the thread that uses it: sample tid >> 3, action dimension tid & 7
+struct MlpLossRec {
+    float a, m0, l0, adv, lp0;           // policy: action, old mean, old log-std (d < 6), advantage, old log-prob; value: adv = vtarg, lp0 = old value
+    __device__ __forceinline__ void load(const MlpFwdParams& P, int net, long long row0, int tid)
+    {
+        const int sl = tid >> 3, d = tid & 7;
+        const long long b = row0 + sl;
+        a = m0 = l0 = adv = lp0 = 0.f;
+        if (b >= P.B) return;
+        if (net == 0) {
+            if (d < kMlpAct) { a = P.rec_actions[b * 6 + d]; m0 = P.rec_mean[b * 6 + d]; l0 = P.rec_log_std[b * 6 + d]; }
+            adv = P.rec_adv[b]; lp0 = P.rec_logp[b];
+        } else if (d == 0) { adv = P.rec_vtarg[b]; lp0 = P.rec_values[b]; }
+    }
+};
+
 template <int NS = 1>
 __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, long long row0, int tid, const float* hd, __bf16* gt, const float* rl,
-                                              float* wsum, bool rec_early)
+                                              float* wsum, bool rec_early, int gplane = kTilePlane, const MlpLossRec* rr = nullptr)
 {
     const int lane = tid & 63, w = tid >> 6;
     const int sl = tid >> 3, d = tid & 7;                     // sample of the tile, lane of its group
@@ -732,7 +749,8 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
         float m = 0.f, raw = 0.f, a = 0.f, m0 = 0.f, l0 = 0.f, adv = 0.f, lp0 = 0.f;
         if (live) {
             if (dim) { m = hd[sl * kMlpHead + d]; raw = hd[sl * kMlpHead + kMlpAct + d]; }
-            if (rec_early) {
+            if (rr) { a = rr->a; m0 = rr->m0; l0 = rr->l0; adv = rr->adv; lp0 = rr->lp0; }
+            else if (rec_early) {
                 if (dim) { a = rl[sl * 6 + d]; m0 = rl[384 + sl * 6 + d]; l0 = rl[768 + sl * 6 + d]; }
                 adv = rl[1152 + sl]; lp0 = rl[1216 + sl];
             } else {
@@ -771,7 +789,7 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
         }
         if (live) { s_surr = -surr; s_kl = kl; s_ent = ent; }
     } else if (d == 0 && live) {
-        const float vt = rec_early ? rl[1152 + sl] : P.rec_vtarg[r], v0 = rec_early ? rl[1216 + sl] : P.rec_values[r];
+        const float vt = rr ? rr->adv : (rec_early ? rl[1152 + sl] : P.rec_vtarg[r]), v0 = rr ? rr->lp0 : (rec_early ? rl[1216 + sl] : P.rec_values[r]);
         float dvf;
         ppo_value_sample(hd[sl * kMlpHead], vt, v0, P.vf_clip, s_vf, dvf);
         g0 = P.vf_coeff * dvf * invB;
@@ -790,7 +808,7 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
         __bf16 p0[NS], p1[NS];
         split_scalar<NS>(g0, p0, P.gscale); split_scalar<NS>(g1, p1, P.gscale);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { gt[s * kTilePlane + sl * kGS + e0] = p0[s]; gt[s * kTilePlane + sl * kGS + e1] = p1[s]; }
+        for (int s = 0; s < NS; ++s) { gt[s * gplane + sl * kGS + e0] = p0[s]; gt[s * gplane + sl * kGS + e1] = p1[s]; }
     }
     // the tile's sums: lane 0 of every group, then across the wave's eight samples; the waves' partial sums meet in LDS
     float sums[4] = {d == 0 ? s_surr : 0.f, d == 0 ? s_vf : 0.f, d == 0 ? s_kl : 0.f, d == 0 ? s_ent : 0.f};
@@ -811,16 +829,34 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
 // and dZ1, the dead input tile holds the head rows, their gradients and the tile's record: 53 KB.
 // NS: bf16 planes per operand (1: the bf16 path; 2, 3: split float32 operands, one workgroup per CU — the LDS tile exists NS times,
 // plane s at + s * kTilePlane; the packed weights at + s * kWPlane; the saved tiles at plane stride P.act_plane)
+// COMPACT (r05; the fused kernel with fp16 planes, NS = 2): TWO workgroups per CU, as the bf16 form has them.  One tile's chain leaves
+// a CU idle at every barrier — stamps at one workgroup per CU: 57 500 cycles per tile of which 21 800 are products, 16 000 barrier waits
+// (profiles/r05_c_mlp_stamps_f32_one_workgroup_per_cu.json) — and only a second resident tile fills that.  78 KB of LDS instead of 106:
+// the input planes ALIAS the hidden planes (a barrier between layer 1's product and its epilogue), the head rows / head gradients /
+// loss sums get 10 KB of their own, the tile's record waits in registers (MlpLossRec) instead of LDS; <= 128 registers: layer 1's
+// activations are not kept for the dZ1 epilogue but read back from the H1 planes this workgroup stored (L2), the weight ring is 3 deep.
+#ifndef PNR_MLP_COMPACT
+#define PNR_MLP_COMPACT 1
+#endif
 template <bool FUSED, int NS = 1>
-__global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
+__global__ __launch_bounds__(kFwdThreads, (FUSED && (NS == 1 || (NS == 2 && PNR_MLP_COMPACT))) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[NS * kTilePlane + ((FUSED && NS == 1) ? PNR_MLP_LDS_PAD : 0)];
-    static_assert(NS >= 1 && NS <= kMlpMaxPlanes && NS * kTilePlane * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
+    constexpr bool kCompact = PNR_MLP_COMPACT && FUSED && NS == 2;
+    constexpr int XPL = kCompact ? kMlpBM * kXS : kTilePlane;          // plane strides (elements) of the input, hidden and head-gradient tiles
+    constexpr int HPL = kCompact ? kMlpBM * kHS : kTilePlane;
+    constexpr int GPL = kCompact ? kMlpBM * kGS : kTilePlane;
+    constexpr int RING = kCompact ? 3 : PNR_MLP_RING;
+    constexpr int kScrElems = kMlpBM * kMlpHead * 2 + NS * kMlpBM * kGS + 2 * 4 * kFwdWaves;      // head rows (float32) | gradient planes | loss sums
+    constexpr int kLdsElems = kCompact ? NS * kMlpBM * kHS + kScrElems : NS * kTilePlane + ((FUSED && NS == 1) ? PNR_MLP_LDS_PAD : 0);
+    __shared__ __attribute__((aligned(16))) __bf16 lds[kLdsElems];
+    static_assert(NS >= 1 && NS <= kMlpMaxPlanes && kLdsElems * 2 + (PNR_MLP_STAMPS ? 2048 : 0) <= 160 * 1024, "the planes' tiles fit one CU");
+    static_assert(!kCompact || (2 * (kLdsElems * 2 + (PNR_MLP_STAMPS ? 2048 : 0)) <= 160 * 1024 && NS * kMlpBM * kXS <= NS * kMlpBM * kHS), "two compact workgroups per CU");
     MLP_STAMP_DECL;
     __bf16* xt = lds;
-    __bf16* ht = lds + kMlpBM * kXS;
+    __bf16* ht = kCompact ? lds : lds + kMlpBM * kXS;
     const long long row0 = (long long)blockIdx.x * kMlpBM;
-    float* const scr = reinterpret_cast<float*>(xt);          // the dead input tile: head rows, head gradients, record, loss sums
+    // the dead input tile: head rows, head gradients, record, loss sums (compact: a block of their own behind the hidden planes)
+    float* const scr = kCompact ? reinterpret_cast<float*>(lds + NS * kMlpBM * kHS) : reinterpret_cast<float*>(xt);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     // this wave's accumulators hold row block w of a layer's [256 rows][64 samples] output, column blocks 0 and 1
@@ -863,7 +899,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     f32x4 bq1[NRB][4];
     bias_load(bias, bq1);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm1<kMlpInPad, kXS, NS> g1;
+    MlpGemm1<kMlpInPad, kXS, NS, XPL, RING> g1;
     g1.prefetch(wp + kOffW1 + rowblk0 * (kMlpInPad / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FUSED) {       // this launch is one optimiser update: counted here, read by the Adam kernel two launches on
@@ -901,7 +937,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
             for (int i = 0; i < kIt; ++i) {
                 const int ch = tid + kFwdThreads * i, row = ch / (kMlpInPad / 8), cc = ch % (kMlpInPad / 8);
-                if (ch < kCh) *reinterpret_cast<uint4*>(xt + s * kTilePlane + row * kXS + cc * 8) = v[s][i];
+                if (ch < kCh) *reinterpret_cast<uint4*>(xt + s * XPL + row * kXS + cc * 8) = v[s][i];
             }
         } else {
         if (P.f_loc) {
@@ -956,7 +992,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                 __bf16 p0[NS], p1[NS];
                 split_scalar<NS>(x[j], p0, F::kSX); split_scalar<NS>(x[j + 1], p1, F::kSX);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x2*>(xt + s * kTilePlane + row * kXS + CPT * part + j) = (bf16x2){p0[s], p1[s]};
+                for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x2*>(xt + s * XPL + row * kXS + CPT * part + j) = (bf16x2){p0[s], p1[s]};
             }
         }
         }
@@ -978,7 +1014,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     // dZ1 epilogue multiplies its own accumulators with), instead of coming back from L2 behind a vmcnt(0), two barriers and an
     // LDS round trip (3 500 of a tile's 44 000 cycles in the phase stamps)
     bf16x4 h1keep[(FUSED && NS == 1) ? kMlpCB * 4 : 1];
-    f32x4 h1keep_f[(FUSED && NS > 1) ? kMlpCB * 4 : 1];        // NS > 1: the float32 values themselves (what the planes add up to)
+    f32x4 h1keep_f[(FUSED && NS > 1 && !kCompact) ? kMlpCB * 4 : 1];        // NS > 1: the float32 values themselves (what the planes add up to)
     const auto epilogue = [&](bool keep, [[maybe_unused]] float inv_scale) {
 #pragma unroll
         for (int cb = 0; cb < kMlpCB; ++cb)
@@ -1002,8 +1038,8 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                     bf16x4_t pk[NS];
                     split_quad<NS>(t, pk, F::kSH);
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * kTilePlane + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
-                    if constexpr (FUSED) { if (keep) h1keep_f[4 * cb + q] = (f32x4){t[0], t[1], t[2], t[3]}; }
+                    for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * HPL + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
+                    if constexpr (FUSED && !kCompact) { if (keep) h1keep_f[4 * cb + q] = (f32x4){t[0], t[1], t[2], t[3]}; }
                 }
             }
     };
@@ -1011,7 +1047,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     const auto store_planes = [&](__bf16* dst) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            mlp_store_htile_nt<kFwdThreads>(ht + s * kTilePlane, dst + (size_t)s * P.act_plane + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
+            mlp_store_htile_nt<kFwdThreads>(ht + s * HPL, dst + (size_t)s * P.act_plane + (size_t)net * P.B * kMlpHid, row0, P.B, tid);
     };
 
     // ---- layer 1: H1^T = tanh(W1 . X^T + b1)
@@ -1022,6 +1058,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         if (PNR_MLP_DIAG & 8) bias_init(acc, b16);
         else g1.run(xt, acc, lane, [] {}, &b16[0]);
     }
+    if constexpr (kCompact) mlp_barrier();      // H1 is written over the input planes: every wave is done reading them
     MLP_STAMP(2);                         // layer-1 product issued
     if (!(PNR_MLP_DIAG & 32)) epilogue(true, 1.f / kS1);
     MLP_STAMP(3);                         // layer-1 epilogue
@@ -1029,7 +1066,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     f32x4 bq2[NRB][4];
     bias_load(bias + kMlpHid, bq2);
     __builtin_amdgcn_sched_barrier(0);
-    MlpGemm1<kMlpHid, kHS, NS> g2;
+    MlpGemm1<kMlpHid, kHS, NS, HPL, RING> g2;
     g2.prefetch(wp + kOffW2 + rowblk0 * (kMlpHid / 16) * 512, lane);
     __builtin_amdgcn_sched_barrier(0);
     mlp_barrier();
@@ -1042,10 +1079,13 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
     for (int r = 0; r < NRB; ++r) b16_2[r] = bias16(bq2, r, kS2);
     if (PNR_MLP_DIAG & 4) bias_init(acc, b16_2);
-    MlpRecordTile<kFwdThreads> rect;
+    MlpRecordTile<kCompact ? 100000 : kFwdThreads> rect;      // (compact: unused, no registers)
+    MlpLossRec lrec;
     const bool rec_early = FUSED && !P.idx && !(PNR_MLP_DIAG & 256);
     const auto l2_hook = [&] {
-        if constexpr (FUSED) {
+        if constexpr (kCompact) {
+            if (rec_early) lrec.load(P, net, row0, tid);
+        } else if constexpr (FUSED) {
             if (rec_early) {
                 // policy: actions, mean, log_std, adv, logp; value: -, -, -, vtarg, values
                 const float* const src[5] = {P.rec_actions, P.rec_mean, P.rec_log_std, net == 0 ? P.rec_adv : P.rec_vtarg, net == 0 ? P.rec_logp : P.rec_values};
@@ -1057,7 +1097,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     if (!(PNR_MLP_DIAG & 4)) {
         g2.run(ht, acc, lane, l2_hook, &b16_2[0]);
     }
-    if constexpr (FUSED) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
+    if constexpr (FUSED && !kCompact) {      // the input tile is dead since the barrier above: the record waits there, behind the head rows and gradients
         if (rec_early) rect.park(scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2, net, tid);
     }
     MLP_STAMP(6);                         // layer-2 product issued
@@ -1087,7 +1127,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         for (int ks = 0; ks < kMlpHid / 32; ++ks) {
             bf16x8 b[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const bf16x8*>(ht + s * kTilePlane + (16 * w + r16) * kHS + 32 * ks + 8 * g);
+            for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const bf16x8*>(ht + s * HPL + (16 * w + r16) * kHS + 32 * ks + 8 * g);
 #pragma unroll
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
                 a3 = mfma16<F::kHalf>(w3f[ks][SplitPairs<NS>::a[pi]], b[SplitPairs<NS>::b[pi]], a3);
@@ -1147,8 +1187,9 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
     if constexpr (FUSED) {
         float* hd = scr;                                                  // [64][16] float32 head rows (written above)
         __bf16* gt = reinterpret_cast<__bf16*>(scr) + kMlpBM * kMlpHead * 2;    // [64][kGS] bf16 head gradients, behind them
-        const float* rl = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2;     // the parked record
-        float* wsum = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats;   // [8 waves][4] loss sums
+        const float* rl = scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2;     // the parked record (compact: none, MlpLossRec)
+        float* wsum = kCompact ? scr + kMlpBM * kMlpHead + NS * kMlpBM * kGS / 2      // [8 waves][4] loss sums
+                               : scr + kMlpBM * kMlpHead + kMlpBM * kGS / 2 + kRecLdsFloats;
         // W3^T's fragment for the first backward product: requested before the H2 store and the loss
         bf16x8 w3t[NS];                                                  // [plane]
 #pragma unroll
@@ -1158,7 +1199,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         mlp_barrier();
         MLP_STAMP(12);                    // barrier before the loss
         // ---- the tile's loss on all 512 threads (mlp_tile_loss)
-        mlp_tile_loss<NS>(P, net, row0, tid, hd, gt, rl, wsum, rec_early);
+        mlp_tile_loss<NS>(P, net, row0, tid, hd, gt, rl, wsum, rec_early, GPL, (kCompact && rec_early) ? &lrec : nullptr);
         MLP_STAMP(13);                    // loss done
         mlp_barrier();
         MLP_STAMP(14);                    // barrier after the loss
@@ -1180,7 +1221,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
             bf16x4_t pk[NS];
             split_quad<NS>(d, pk);               // (fp16 planes: d is the gradient times gscale already; the split clamps)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * kTilePlane + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(ht + s * HPL + (32 * cb + c) * kHS + 32 * w + 8 * q + 4 * h) = pk[s];
         };
         const auto bwd_epilogue = [&]() {
 #pragma unroll
@@ -1194,7 +1235,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
                     } else {
                         bf16x4_t hv[NS];                                          // the planes add up to the activation (bf16 planes: exactly)
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) hv[s] = *reinterpret_cast<const bf16x4*>(at + s * kTilePlane);
+                        for (int s = 0; s < NS; ++s) hv[s] = *reinterpret_cast<const bf16x4*>(at + s * HPL);
                         dtanh_split(cb, q, planes_value<NS>(hv, 1.f / F::kSH));
                     }
                 }
@@ -1211,7 +1252,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         [[maybe_unused]] const float inv_g = 1.f / P.gscale;       // (a power of two: exact)
         if (w3p) {
             f32x4 aw3[2], ab3;
-            mlp_tile_w3_products<NS>(gt, kGS, ht, kHS, lane, w, aw3, ab3, kTilePlane, kTilePlane);
+            mlp_tile_w3_products<NS>(gt, kGS, ht, kHS, lane, w, aw3, ab3, GPL, HPL);
             const int c16 = lane & 15, g = lane >> 4;              // C: col = lane & 15, rows 4g .. 4g+3
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -1229,7 +1270,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
-                for (int cb = 0; cb < kMlpCB; ++cb) b[s][cb] = *reinterpret_cast<const bf16x8*>(gt + s * kTilePlane + (32 * cb + c) * kGS + 8 * h);
+                for (int cb = 0; cb < kMlpCB; ++cb) b[s][cb] = *reinterpret_cast<const bf16x8*>(gt + s * GPL + (32 * cb + c) * kGS + 8 * h);
 #pragma unroll
             for (int pi = 0; pi < SplitPairs<NS>::n; ++pi)
 #pragma unroll
@@ -1240,7 +1281,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         const auto b2_products = [&] {                             // db2 = 1^T . dZ2 of this wave's columns 32 w .., now that they hold dZ2
             if (w3p) {
                 f32x4 ab2[2];
-                mlp_tile_b2_products<NS>(ht, kHS, lane, w, ab2, kTilePlane);
+                mlp_tile_b2_products<NS>(ht, kHS, lane, w, ab2, HPL);
                 if ((lane >> 4) == 0) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) w3p[kMlpHead * kMlpHid + 32 * w + 16 * b + (lane & 15)] = F::kHalf ? ab2[b][0] * inv_g : ab2[b][0];
@@ -1249,7 +1290,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         };
         b2_products();                                             // (only this wave wrote these columns)
         MLP_STAMP(15);                    // dH2 product + its epilogue
-        MlpGemm1<kMlpHid, kHS, NS> g4;    // W2^T's first fragments ahead of the barrier
+        MlpGemm1<kMlpHid, kHS, NS, HPL, RING> g4;    // W2^T's first fragments ahead of the barrier
         g4.prefetch(wp + kOffW2T + rowblk0 * (kMlpHid / 16) * 512, lane);
         __builtin_amdgcn_sched_barrier(0);
         mlp_barrier();
@@ -1260,6 +1301,21 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
         const auto dz2_hook = [&] { if (!(PNR_MLP_DIAG & 64)) store_planes(P.dz2); };
         g4.run(ht, acc, lane, dz2_hook);
         MLP_STAMP(17);                    // dZ2 store + W2^T product issued
+        // compact: layer 1's activations, this lane's quads, back from the H1 planes this workgroup stored during layer 2's product (the
+        // stores have completed: every wave has since waited for later loads of its own, vector-memory operations complete in order,
+        // and barriers followed) — requested here, consumed behind the barrier
+        bf16x4 h1back[kCompact ? kMlpCB * 4 : 1][kCompact ? NS : 1];
+        if constexpr (kCompact) {
+#pragma unroll
+            for (int cb = 0; cb < kMlpCB; ++cb) {
+                const long long row = row0 + 32 * cb + c;
+                const __bf16* src = P.h1 + ((size_t)net * P.B + (row < P.B ? row : 0)) * kMlpHid + 32 * w + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) h1back[4 * cb + q][s] = *reinterpret_cast<const bf16x4*>(src + (size_t)s * P.act_plane + 8 * q);
+            }
+        }
         MLP_STAMP(18);
         mlp_barrier();                         // every read of dZ2 (the product and the store inside it) is done: the tile is free
         MLP_STAMP(19);
@@ -1270,6 +1326,7 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && NS == 1) ? 4 : 2) void mlp_f
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if constexpr (NS == 1) *reinterpret_cast<bf16x4*>(ht + (32 * colblk(cb) + c) * kHS + 32 * rowblk(cb) + 8 * q + 4 * h) = dtanh_quad(acc[cb], q, h1keep[4 * cb + q]);
+                else if constexpr (kCompact) dtanh_split(cb, q, planes_value<NS>(h1back[4 * cb + q], 1.f / F::kSH));
                 else dtanh_split(cb, q, h1keep_f[4 * cb + q]);
             }
         MLP_STAMP(21);
