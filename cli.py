@@ -49,10 +49,11 @@ def build_parser() -> argparse.ArgumentParser:
     tr.add_argument("--iterations", type=int, default=1000)
     tr.add_argument("--envs-per-worker", type=int, default=4096)
     tr.add_argument("--mode", choices=["kinematic", "dynamic"], default="kinematic")
-    tr.add_argument("--precision", choices=["bf16", "f32", "bf16x3", "torch"], default="bf16",
-                    help="the learner's arithmetic: bf16 MFMA operands (default), float32-accurate products on the same kernels "
-                         "('f32': two scaled fp16 planes per operand; 'bf16x3': three bf16 planes), or the float32 torch formulation — the reference's "
-                         "learner is float32 torch (pioneer_knm_train.py:47)")
+    tr.add_argument("--precision", choices=["f32", "bf16", "bf16x3", "torch"], default="f32",
+                    help="the learner's arithmetic on the hand-written kernels: 'f32' (default) float32-accurate products — two scaled fp16 planes per "
+                         "operand — the arithmetic of the reference's float32 torch learner (pioneer_knm_train.py:47); 'bf16' the reduced-precision "
+                         "fast variant (8 significant bits per operand, ~2.3x the env-steps/s); 'bf16x3' three bf16 planes per operand; 'torch' the "
+                         "float32 torch formulation itself")
     tr.add_argument("--restore", default=None, metavar="CHECKPOINT", help="start every trial from this PPOTrainer.save() file")
     tr.add_argument("--trial-parallel", action="store_true",
                     help="several GPUs: rank r runs trials r, r + world, ... on its own (no traffic between the GPUs)")

@@ -839,9 +839,9 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
 #define PNR_MLP_COMPACT 1
 #endif
 template <bool FUSED, int NS = 1>
-__global__ __launch_bounds__(kFwdThreads, (FUSED && (NS == 1 || (NS == 2 && PNR_MLP_COMPACT))) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
+__global__ __launch_bounds__(kFwdThreads, ((FUSED && NS == 1) || (NS == 2 && PNR_MLP_COMPACT)) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
-    constexpr bool kCompact = PNR_MLP_COMPACT && FUSED && NS == 2;
+    constexpr bool kCompact = PNR_MLP_COMPACT && NS == 2;          // (the plain forward too: the sampler's pnr_mlp_act then runs its 512 (tile, net) units in one round)
     constexpr int XPL = kCompact ? kMlpBM * kXS : kTilePlane;          // plane strides (elements) of the input, hidden and head-gradient tiles
     constexpr int HPL = kCompact ? kMlpBM * kHS : kTilePlane;
     constexpr int GPL = kCompact ? kMlpBM * kGS : kTilePlane;
@@ -908,7 +908,8 @@ __global__ __launch_bounds__(kFwdThreads, (FUSED && (NS == 1 || (NS == 2 && PNR_
 
     // ---- stage 0: the tile's observations, filtered, as bf16 [BM][144] (columns 137.. zero)
     {
-        float* fv = reinterpret_cast<float*>(ht);                 // loc | inv | lo | hi, 4 x 144 floats, in the idle tile
+        float* fv = kCompact ? scr : reinterpret_cast<float*>(ht);   // loc | inv | lo | hi, 4 x 144 floats, in the idle tile (compact: the scratch block)
+        static_assert(4 * kMlpInPad * 2 <= kScrElems, "the filter vectors fit the scratch block");
         if (P.xs_in) {                                            // the tile's 64 rows are 18 KB of contiguous bf16: a plain copy,
             // every load of the thread in flight before the first LDS write
             constexpr int kCh = kMlpBM * (kMlpInPad / 8), kIt = (kCh + kFwdThreads - 1) / kFwdThreads;

@@ -52,8 +52,9 @@ def train(results_dir: str,
     independently (pioneer_knm_train.py:43-44; cli.py:15 defaults to 128 of them): rank r trains trials r, r + world, ... on
     its own GPU with ``num_workers x envs_per_worker`` envs each and NO traffic between the GPUs until the result rows are
     gathered at the end.  ``restore``: a PPOTrainer.save() checkpoint every trial starts from (Tune's restore=...).
-    ``hip_kernels``: the learner's arithmetic when no ``ppo_config`` is given — True / "bf16" (default), "f32" / "bf16x3" (float32-
-    accurate split operands on the same kernels) or False (the float32 torch formulation); PPOConfig.hip_kernels."""
+    ``hip_kernels``: the learner's arithmetic when no ``ppo_config`` is given — "f32" (default: float32-accurate products on the
+    hand-written kernels, the arithmetic of the reference's float32 torch learner, pioneer_knm_train.py:47), True / "bf16" (the
+    reduced-precision fast variant), "bf16x3", or False (the float32 torch formulation itself); PPOConfig.hip_kernels."""
     # the engine's own options: as given, or — dynamics mode — the inertia-scaled motor (omega = 20 rad/s, zeta = 1 on every
     # joint: with plain torque gains PPO does not learn the task, DESIGN.md section 6); TimeLimit(500) and auto-reset as
     # the reference's prepare_env wraps it (pioneer_knm_train.py:27)
@@ -84,13 +85,13 @@ def train(results_dir: str,
             os.makedirs(tdir, exist_ok=True)
         # default when no PPOConfig is given: the reference's learning rate, nets, filter and entropy schedule, but
         # GPU-scale batching: T = 32 steps of every env per iteration (131 072 samples per 4 096
-        # envs instead of train_batch_size 8 000), 4 epochs of 32 768-sample minibatches instead of 20 x 128, bf16 GEMMs
+        # envs instead of train_batch_size 8 000), 4 epochs of 32 768-sample minibatches instead of 20 x 128, float32-accurate products
         # The entropy schedule keeps the reference's LENGTH IN ITERATIONS: 1 M timesteps of 8 000-sample batches
         # = 125 iterations there (pioneer_knm_train.py:37-40, :62); left at 1 M timesteps it would be over after
         # 8 of these 131 072-sample iterations (2 at 16 384 envs).
         cfg = ppo_config or PPOConfig(num_sgd_iter=4, sgd_minibatch_size=max(1, 32768 // world),   # 32 768 samples per GLOBAL minibatch
                                       entropy_decay_steps=125 * 32 * total_envs,
-                                      **({} if hip_kernels is None else {"hip_kernels": hip_kernels}))
+                                      hip_kernels="f32" if hip_kernels is None else hip_kernels)
         ent_rng = np.random.RandomState(cfg.seed + 7919 * trial)
         cfg = PPOConfig(**{**cfg.__dict__, "entropy_coeff_start": sample_entropy_start(ent_rng),
                            "seed": cfg.seed + trial})

@@ -21,7 +21,7 @@ def test_parser_keeps_the_reference_options():
     assert e.checkpoint == "ck.pt" and e.gif == "o.gif" and e.episodes == 3
     a = ap.parse_args(["pioneer-train-kinem", "-e", "x", "--restore", "ck.pt", "--trial-parallel"])
     assert a.restore == "ck.pt" and a.trial_parallel
-    assert a.precision == "bf16" and ap.parse_args(["pioneer-train-kinem", "-e", "x", "--precision", "f32"]).precision == "f32"
+    assert a.precision == "f32" and ap.parse_args(["pioneer-train-kinem", "-e", "x", "--precision", "bf16"]).precision == "bf16"
     with pytest.raises(SystemExit):
         ap.parse_args(["pioneer-train-kinem", "-e", "x", "--precision", "fp8"])
     t = ap.parse_args(["tensorboard", "-e", "exp1"])                # the reference's second sub-command (cli.py:43-55)

@@ -440,3 +440,41 @@ def test_split_operand_train_step_matches_float32_autograd_and_adam(planes, B):
     assert float((tot - one.wpack.float()).abs().max()) <= 2.0 ** -8 * float(one.wpack.float().abs().max())
     w2 = mlp.params[2].detach()                                   # .. checked where the packing is the identity map's inverse: max |error| of W2
     assert float(tot.abs().max()) >= 0.9 * float(w2.abs().max())
+
+
+def test_fp16_planes_saturate_instead_of_overflowing():
+    """planes = 2 carries every operand as scaled fp16 planes, whose largest finite value is 65 504 (include/pioneer_amd.h, `planes`):
+    net inputs beyond 4 094 (unfiltered observations: the env does not clip actions), weights beyond 255 and per-sample gradients beyond
+    16 384 / batch are CLAMPED at the conversion — never inf, never NaN: the update of such a batch stays finite, the samples that are in
+    range are unaffected, and the in-range answer agrees with float32 autograd as always."""
+    from pioneer_amd.mlp import HipMLP
+    B = 4096
+    model, _, obs, _, _ = make(B, seed=41)
+    dev = obs.device
+    rec = _record(B, dev)
+    klc = torch.tensor(0.2, device=dev); entc = torch.tensor(0.01, device=dev)
+
+    def grad_of(o, r):
+        mlp = HipMLP(model, B, dev, planes=2)
+        mlp.pack()
+        g = mlp.gather_epoch(o, torch.arange(B, device=dev), None, r)
+        flat = torch.zeros(int(mlp.lib.pnr_mlp_grad_floats()), device=dev)
+        means = torch.zeros(8, device=dev)
+        mlp.train_step(None, None, None, {k: g[k] for k in mlp.REC_KEYS}, klc, entc, 0.3, 10.0, 1.0, means, 1e-3, flat_grad=flat, xs_in=g["xs"])
+        head = mlp.forward_nograd(o)
+        torch.cuda.synchronize()
+        return flat, means, head
+
+    clean, _, head_clean = grad_of(obs, rec)
+    wild_obs = obs.clone(); wild_obs[7, :] = 3.0e7; wild_obs[8, 5] = -1.0e30; wild_obs[9, 0] = float(2 ** 15)      # far beyond the fp16 range
+    wild_rec = {k: v.clone() for k, v in rec.items()}
+    wild_rec["adv"][11] = 1.0e9; wild_rec["adv"][12] = -1.0e12; wild_rec["vtarg"][13] = 1.0e20                     # per-sample gradients beyond it
+    flat, means, head = grad_of(wild_obs, wild_rec)
+    assert torch.isfinite(flat).all() and torch.isfinite(head).all()
+    keep = torch.ones(B, dtype=torch.bool, device=dev); keep[7:10] = False
+    assert torch.equal(head[:, keep], head_clean[:, keep]), "samples inside the range must not notice their neighbours"
+    # the clamp is where the header says: an input of 2^15 enters the first layer as 65504 / 16
+    x = wild_obs[9:10].clone(); x[0, 0] = 65504.0 / 16.0
+    mlp = HipMLP(model, B, dev, planes=2); mlp.pack()
+    assert torch.equal(mlp.forward_nograd(torch.cat([x, obs[:1]]))[:, 0], head[:, 9])
+    assert float((flat - clean).abs().max()) > 0 and float(flat.abs().max()) < 1e6
