@@ -54,7 +54,7 @@ MIN_SERIES_S = 0.06        # the timed K-step block is repeated back to back unt
 MIN_REPEATS = 5            # ... and at least this often; `ms_per_step` = series wall time / (repeats x K)
 MAX_REPEATS = 20000
 DYN_PACKED_FRAC = 361.0 / 977.0                 # v_pk_*_f32 share of the dynamics sub-step loop's VALU instructions (tools/isa_loop_mix.py)
-DYN_COUNTERS = "r04_f_dyn_sq_counters.json"      # tools/dyn_counters_summary.py (VALU instructions per launch of the dynamics kernel)
+DYN_COUNTERS = "r05_e_dyn_sq_counters.json"      # tools/dyn_counters_summary.py (VALU instructions per launch of the dynamics kernel)
 
 
 def parse_args(argv=None):

@@ -7,7 +7,9 @@ from pioneer_amd import PioneerVectorEnv, EngineConfig
 from pioneer_amd.ppo import PPOConfig, PPOTrainer
 g = os.environ.get("PPO_PROFILE_GRAPH") == "1"
 env = PioneerVectorEnv(16384, device="cuda:0", seed=0, engine_config=EngineConfig(max_episode_steps=500))
-tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=int(os.environ.get("PPO_PROFILE_MBS", "32768"))), use_graph=g)
+prec = os.environ.get("PPO_PROFILE_PRECISION", "f32")      # f32 (the credited loop) | bf16 | bf16x3
+tr = PPOTrainer(env, PPOConfig(rollout_fragment_length=32, num_sgd_iter=4, sgd_minibatch_size=int(os.environ.get("PPO_PROFILE_MBS", "32768")),
+                               hip_kernels=True if prec == "bf16" else prec), use_graph=g)
 for _ in range(int(os.environ.get("PPO_PROFILE_ITERS", "4"))):
     r = tr.train()
 print(r["sample_time_s"], r["learn_time_s"])

@@ -43,11 +43,15 @@ if has dyntraffic; then
   python3 $R/tools/pmc_traffic.py $O/prof_${TAG}_dyn_pmc_fetch.json $O/prof_${TAG}_dyn_pmc_write.json $O/prof_${TAG}_pmc_traffic.json "$RND $TAG" dynamic > $O/prof_${TAG}_dyn_pmc_traffic.txt
 fi
 if has ppo; then
-  db=$(prof ppo --kernel-trace -d /tmp/p_ppo -o t -- python3 $R/tools/ppo_profile.py)
-  python3 $R/tools/rocpd_stats.py $db --skip-frac 0.6 --csv $O/prof_${TAG}_ppo_loop_kernel_stats.csv > $O/prof_${TAG}_ppo_loop_kernel_stats.txt
   SQM="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"
-  db=$(prof ppopmc --kernel-trace --pmc $SQM -d /tmp/p_ppopmc -o t -- python3 $R/tools/ppo_profile.py)
-  python3 $R/tools/rocpd_pmc.py $db $O/prof_${TAG}_learner_pmc_sq.json > /dev/null
+  for PREC in f32 bf16; do
+    export PPO_PROFILE_PRECISION=$PREC
+    db=$(prof ppo$PREC --kernel-trace -d /tmp/p_ppo$PREC -o t -- python3 $R/tools/ppo_profile.py)
+    python3 $R/tools/rocpd_stats.py $db --skip-frac 0.6 --csv $O/prof_${TAG}_ppo_loop_${PREC}_kernel_stats.csv > $O/prof_${TAG}_ppo_loop_${PREC}_kernel_stats.txt
+    db=$(prof ppopmc$PREC --kernel-trace --pmc $SQM -d /tmp/p_ppopmc$PREC -o t -- python3 $R/tools/ppo_profile.py)
+    python3 $R/tools/rocpd_pmc.py $db $O/prof_${TAG}_learner_${PREC}_pmc_sq.json > /dev/null
+  done
+  unset PPO_PROFILE_PRECISION
 fi
 if has learner; then
   cp $R/profiles/learner_pmc_traffic.json $O/prof_${TAG}_learner_pmc_traffic.json 2>/dev/null || true
