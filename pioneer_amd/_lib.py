@@ -242,8 +242,8 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=(), ou
     parallel (only those whose object does not carry the fingerprint of the current sources) and linked.  extra_flags / out_path
     build a variant next to it (e.g. -DPNR_DYN_LDS_MODEL=1 for the LDS-staging A/B, -DPNR_DIAG_BUILD=1 for the timing-only
     ablations), with objects of its own; `units` names the translation units the flags concern (e.g. ("pnr_learn.hip",) for an
-    MLP kernel A/B) — the others are linked from the default build's objects.  A full forced build takes ~90 s on 8 cores
-    (pnr_learn.hip: 85 s, pnr_api.hip: 60 s, in parallel)."""
+    MLP kernel A/B) — the others are linked from the default build's objects.  A full forced build takes ~95 s on 8 cores
+    (pnr_api.hip: ~95 s, pnr_learn.hip: ~20 s, in parallel)."""
     variant = out_path is not None or bool(extra_flags)
     if variant:
         force = True

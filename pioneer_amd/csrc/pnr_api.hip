@@ -542,10 +542,11 @@ int pnr_world_step(pnr_handle h, float* joint_state, void* stream)
     if (joint_state) return fail(h, PNR_ERR_INVALID, "pnr_world_step: joint_state must be NULL in dynamics mode (the simulated joints are the handle's)");
     const DynParams& D = h->dbase;
     const dim3 grid((unsigned)((h->n + kWave - 1) / kWave));
-    const bool rnd = h->cfg.randomize || h->dyn_set, ct = D.has_ground || D.has_box || D.n_scene > 0;
-#define PNR_WORLD_LAUNCH(R, C) hipLaunchKernelGGL((dyn_world_kernel<R, C>), grid, dim3(kWave), 0, st, h->state, h->dyn, (long long)h->n, D, h->motors)
-    if (D.inertia_scaled) { if (ct) { if (rnd) PNR_WORLD_LAUNCH(true, 3); else PNR_WORLD_LAUNCH(false, 3); } else { if (rnd) PNR_WORLD_LAUNCH(true, 2); else PNR_WORLD_LAUNCH(false, 2); } }
-    else { if (ct) { if (rnd) PNR_WORLD_LAUNCH(true, 1); else PNR_WORLD_LAUNCH(false, 1); } else { if (rnd) PNR_WORLD_LAUNCH(true, 0); else PNR_WORLD_LAUNCH(false, 0); } }
+    const bool ct = D.has_ground || D.has_box || D.n_scene > 0;
+    // (always the instantiation that reads the per-env link scales: without randomisation they are stored as 1)
+#define PNR_WORLD_LAUNCH(C) hipLaunchKernelGGL((dyn_world_kernel<true, C>), grid, dim3(kWave), 0, st, h->state, h->dyn, (long long)h->n, D, h->motors)
+    if (D.inertia_scaled) { if (ct) PNR_WORLD_LAUNCH(3); else PNR_WORLD_LAUNCH(2); }
+    else { if (ct) PNR_WORLD_LAUNCH(1); else PNR_WORLD_LAUNCH(0); }
 #undef PNR_WORLD_LAUNCH
     HIP_TRY(h, hipGetLastError());
     return PNR_OK;

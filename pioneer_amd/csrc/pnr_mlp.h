@@ -1580,13 +1580,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_backward_data_kernel(const Ml
 // weight gradients: dW = dZ^T . H over the samples of one batch slice, written to that slice's slab.
 // grid (slices, 4 parts, nets): part 0 / 1 = the two 128-column halves of dW2, part 2 = dW1 and db1 (the input tile
 // carries a column of ones at k = 144), part 3 = dW3, db3 and db2 (16x16x32 MFMAs, a fragment of ones).  One workgroup
-// per CU (342 registers); tried and dropped (r02): dW1 as two row-halves for 2 waves per SIMD — five roles x 64 slices
-// x 2 nets = 640 workgroups are 2.5 rounds of the 256 CUs instead of 2, 41 -> 45-50 us; db2 moved from part 3 into part 0
-// (one read of dZ2 less, 64 more accumulator registers): 35.0 -> 35.0 us; two chunks in flight per workgroup in parts 0 / 1
-// (48 more registers): 37.3 us, in parts 0 / 1 / 3: 37.6 us, in every part (part 2's 160 accumulator registers + two chunk
-// sets: 52 B of scratch): 60 us; five roles (dW1 as two row halves, 80 accumulator registers) x 25 slices with two chunks in
-// flight everywhere, no scratch: 47.4 us = the 28 % more rows per workgroup.  A workgroup costs ~2.2 us per 64-sample chunk
-// whatever its role and prefetch depth; the kernel is bound neither by its byte count nor by the depth of its prefetch.
+// per CU.  (What was tried and dropped here in r02 / r03 — more roles, two chunks in flight, register-staged chunks: DESIGN_HISTORY.md.)
 // ---------------------------------------------------------------------------------------------------------------
 struct MlpWgradParams {
     const float* g_head;       // [2][B][16]
@@ -1683,14 +1677,7 @@ __device__ __forceinline__ bf16x8 wg_frag32(const __bf16* tile, int tstride, int
     // every sample = 0 mod 4 came out weighted four times and the others not at all
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-#ifndef PNR_SLAB_NT
-#define PNR_SLAB_NT 1
-#endif
-#if PNR_SLAB_NT
-#define PNR_SLAB_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define PNR_SLAB_STORE(p, v) (*(p) = (v))
-#endif
+#define PNR_SLAB_STORE(p, v) __builtin_nontemporal_store((v), (p))      // slabs are written once and read by another kernel: streaming stores
 // store a 32x32 accumulator block to a row-major float32 matrix: rows row0.., cols col0.. (cols < ncols kept)
 __device__ __forceinline__ void wg_store_block(float* __restrict__ m, int ld, int row0, int col0, int ncols, const f32x16& a, int lane)
 {
@@ -1871,11 +1858,7 @@ __device__ __forceinline__ void wg_store_block_lds(float* scratch, float* __rest
         const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (r + 8 * pss) * kWgTrS + 4 * q);
         if (col0 + 4 * q < ncols) {
             f32x4* dst = reinterpret_cast<f32x4*>(m + (size_t)(row0 + r + 8 * pss) * ld + col0 + 4 * q);
-#if PNR_SLAB_NT
             __builtin_nontemporal_store(v, dst);
-#else
-            *dst = v;
-#endif
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the reads are done before the next block overwrites the tile
