@@ -1413,16 +1413,19 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGather
                 *reinterpret_cast<uint4*>(P.xs_out + b * kMlpInPad + cc * 8) = *reinterpret_cast<const uint4*>(P.xs_src + r * kMlpInPad + cc * 8);
         }
     }
-    const float* src = P.obs + r * kMlpIn + CPT * part;
+    // a row's four threads take its 16-byte pieces INTERLEAVED (thread `part`: pieces part, part + 4, ...), so that one load instruction
+    // reads 64 contiguous bytes of each of the wave's 16 random rows; with a contiguous 36-column share per thread (r02 - r04) every
+    // instruction touched 64 different cache lines for 16 bytes each, four times the L2 sectors per row
+    const float* src = P.obs + r * kMlpIn;
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     f32x4 v[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int col = CPT * part + 4 * j;
+        const int col = 4 * TPR * j + 4 * part;
         v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (P.xs_src) continue;
-        if (col + 3 < kMlpIn) v[j] = *reinterpret_cast<const f32x4u*>(src + 4 * j);
-        else if (col < kMlpIn) v[j][0] = src[4 * j];
+        if (col + 3 < kMlpIn) v[j] = *reinterpret_cast<const f32x4u*>(src + col);
+        else if (col < kMlpIn) v[j][0] = src[col];
     }
     float recv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};             // this thread's share of the record: part 0 actions, 1 mean, 2 log_std
     float sc[4] = {0.f, 0.f, 0.f, 0.f};                         // part 3: logp, adv, vtarg, values
@@ -1440,7 +1443,7 @@ __global__ __launch_bounds__(kMlpThreads) void mlp_gather_kernel(const MlpGather
     if (!P.xs_src) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int col = CPT * part + 4 * j;
+        const int col = 4 * TPR * j + 4 * part;
         f32x4 x = v[j];
         if (P.f_loc) {
             const f32x4 loc = *reinterpret_cast<const f32x4*>(fv + col), inv = *reinterpret_cast<const f32x4*>(fv + kMlpInPad + col);
