@@ -73,6 +73,27 @@ int main(void)
         ok &= close_to(o[91], trace[t][2], 2e-6, "v[1]") & close_to(o[1], trace[t][3], 2e-6, "r[1]");
         ok &= close_to(o[108], k.a_max[0], 0, "obs shows the action just given");
     }
+    /* World.step() alone (bullet_scene.py:273-275; ABI 5): on a kinematic-mode handle the caller's joint buffer [N][12] = q | qd moves by
+     * qd * step_time and stops at the joint limit — the reference's demo loop (pioneer_knm_env.py:282-295) through the plain C ABI */
+    {
+        float js[N * 12] = {0}, *d_js;
+        js[12 * 1 + 1] = 0.25f; js[12 * 1 + 6 + 1] = 1.0f;             /* env 1, joint robot:hinge1_to_arm1: position 0.25, velocity 1 */
+        js[12 * 2 + 0] = 3.1f;  js[12 * 2 + 6 + 0] = 2.0f;             /* env 2, joint 0: one step from its limit */
+        HIP(hipMalloc((void**)&d_js, sizeof js)); HIP(hipMemcpy(d_js, js, sizeof js, hipMemcpyHostToDevice));
+        if (pnr_world_step(h, NULL, NULL) != PNR_ERR_INVALID) { fprintf(stderr, "kinematic world step without a joint buffer did not fail\n"); return 1; }
+        if (pnr_set_joint_motor(h, 0, PNR_CONTROL_VELOCITY, 0, 1.0, NAN, NAN, NAN, NAN) != PNR_ERR_INVALID) { fprintf(stderr, "a motor on a kinematic handle did not fail\n"); return 1; }
+        for (int t = 0; t < 3; t++) CHECK(pnr_world_step(h, d_js, NULL));
+        HIP(hipDeviceSynchronize());
+        HIP(hipMemcpy(js, d_js, sizeof js, hipMemcpyDeviceToHost));
+        ok &= close_to(js[12 * 1 + 1], 0.25 + 3 * k.dt, 1e-6, "world.step: q += qd * step_time") & close_to(js[12 * 1 + 7], 1.0, 0, "velocity kept");
+        ok &= close_to(js[12 * 2 + 0], k.r_hi[0], 0, "world.step: stopped at the limit") & close_to(js[12 * 2 + 6], 0.0, 0, "velocity zeroed there");
+        ok &= close_to(js[12 * 0 + 3], 0.0, 0, "a joint at rest stays");
+        hipFree(d_js);
+    }
+    {   /* the binary says what it was built from */
+        const char* fp = pnr_build_fingerprint();
+        if (!fp || strncmp(fp, "api=", 4) != 0 || !strstr(fp, ";learn=")) { fprintf(stderr, "pnr_build_fingerprint: %s\n", fp ? fp : "(null)"); return 1; }
+    }
     CHECK(pnr_destroy(h));
     hipFree(d_jp); hipFree(d_tp); hipFree(d_act); hipFree(d_obs); hipFree(d_rew); hipFree(d_done); hipFree(d_trunc);
     if (!ok) return 2;

@@ -449,3 +449,57 @@ def test_inertia_scaled_gains_track_every_joint_alike(oracle_built):
         err[name] = np.abs(o.dstate["q"][0] - o.state["r"][0])
     assert err["scaled"].max() < 0.03, err
     assert err["plain"][:3].max() > 0.1, err
+
+
+# ---- World.step() alone and the per-joint motors (r05: orc_dyn_world_step; include/pioneer_amd.h pnr_world_step, pnr_set_joint_motor) ------
+def test_world_step_is_frame_skip_substeps_on_the_commanded_state(oracle_built):
+    """Without per-joint motors World.step() (bullet_scene.py:273-275) is frame_skip sub-steps of the env-wide law tracking the env's own
+    command state r, v: the same as calling orc_dyn_substep frame_skip times; it touches neither the command state nor the counters."""
+    kw = dict(gravity=9.81, kp=4000.0, kd=400.0, torque_limit=900.0, joint_damping=0.3, joint_friction=0.05, ground_z=0.0, contact_kp=2000.0, contact_kd=50.0)
+    a, b = DynOracle(1, seed=4, dyn=kw), DynOracle(1, seed=4, dyn=kw)
+    a.reset(); b.reset()
+    for o in (a, b):
+        o.dstate["q"][0] += 0.05; o.dstate["qd"][0] = np.linspace(-0.4, 0.4, 6)
+    before = a.state.copy()
+    a.world_step()
+    for _ in range(b.d.frame_skip):
+        b.substep(b.state["r"][0], b.state["v"][0].astype(np.float64))
+    assert np.array_equal(a.dstate["q"], b.dstate["q"]) and np.array_equal(a.dstate["qd"], b.dstate["qd"])
+    assert a.state.tobytes() == before.tobytes()
+    assert not np.array_equal(a.dstate["q"][0], a.state["r"][0])            # it did move: gravity and the motor pulled
+
+
+def test_world_step_on_a_teleport_handle_coasts(oracle_built):
+    """teleport = the reference's semantics (no motor torque): with no gravity, friction or contacts a joint reset with a velocity — the
+    demo's reset_state(position(), velocity), pioneer_knm_env.py:282 — moves the whole coupled chain, and the kinetic energy is conserved."""
+    o = DynOracle(1, seed=2, dyn=dict(teleport=1))
+    o.reset()
+    o.dstate["q"][0] = [0.2, 0.3, -0.4, 0.1, 0.2, 0.0]; o.dstate["qd"][0] = [0.0, 1.0, 0.0, 0.0, 0.0, 0.0]
+    e0 = sum(o.energy())
+    for _ in range(5):
+        o.world_step()
+    assert abs(sum(o.energy()) - e0) < 2e-3 * e0 and o.dstate["q"][0][1] > 0.3 + 0.15
+    assert np.abs(o.dstate["qd"][0][[0, 2, 3, 4, 5]]).max() > 1e-3          # the other joints are dragged along (no motors hold them)
+
+
+def test_per_joint_motors_of_world_step(oracle_built):
+    """Joint.control_velocity / control_position (bullet_scene.py:123-155) as per-joint motors of World.step(): in zero gravity a velocity
+    motor reaches its target velocity, a position motor with maxVelocity travels no faster than that and arrives, max_force bounds the
+    joint's acceleration, and a joint nobody commanded keeps tracking the env's command state."""
+    o = DynOracle(1, seed=1, dyn=dict(kp=4000.0, kd=400.0))
+    o.reset()
+    r0 = o.state["r"][0].copy()
+    o.set_joint_motor(5, 1, target_velocity=0.7)                            # the wrist: light, converges fast
+    o.set_joint_motor(3, 0, target_position=float(r0[3]) + 0.8, max_velocity=0.5)
+    peak = 0.0
+    for _ in range(60):
+        o.world_step()
+        peak = max(peak, abs(o.dstate["qd"][0][3]))
+    assert abs(o.dstate["qd"][0][5] - 0.7) < 0.02
+    assert peak < 0.5 * 1.1 and abs(o.dstate["q"][0][3] - (r0[3] + 0.8)) < 0.02
+    assert np.abs(o.dstate["q"][0][[0, 1, 2, 4]] - r0[[0, 1, 2, 4]]).max() < 0.02          # the others hold the command state
+    weak = DynOracle(1, seed=1, dyn=dict(kp=4000.0, kd=400.0)); weak.reset()
+    strong = DynOracle(1, seed=1, dyn=dict(kp=4000.0, kd=400.0)); strong.reset()
+    weak.set_joint_motor(0, 1, target_velocity=1.0, max_force=5.0); strong.set_joint_motor(0, 1, target_velocity=1.0, max_force=5000.0)
+    weak.world_step(); strong.world_step()
+    assert 0 < weak.dstate["qd"][0][0] < 0.2 * strong.dstate["qd"][0][0]
