@@ -734,8 +734,10 @@ struct MlpLossRec {
 
 template <int NS = 1>
 __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, long long row0, int tid, const float* hd, __bf16* gt, const float* rl,
-                                              float* wsum, bool rec_early, int gplane = kTilePlane, const MlpLossRec* rr = nullptr)
+                                              float* wsum, bool rec_early, int gplane = kTilePlane, bool rec_regs = false, MlpLossRec rv = MlpLossRec())
 {
+    // (rec_regs: the record comes in registers, by value — behind a pointer that may be null it was demoted to scratch)
+    const MlpLossRec* rr = rec_regs ? &rv : nullptr;
     const int lane = tid & 63, w = tid >> 6;
     const int sl = tid >> 3, d = tid & 7;                     // sample of the tile, lane of its group
     const long long b = row0 + sl;
@@ -838,6 +840,9 @@ __device__ __forceinline__ void mlp_tile_loss(const MlpFwdParams& P, int net, lo
 #ifndef PNR_MLP_COMPACT
 #define PNR_MLP_COMPACT 1
 #endif
+#ifndef PNR_MLP_COMPACT_RING
+#define PNR_MLP_COMPACT_RING 3
+#endif
 template <bool FUSED, int NS = 1>
 __global__ __launch_bounds__(kFwdThreads, ((FUSED && NS == 1) || (NS == 2 && PNR_MLP_COMPACT)) ? 4 : 2) void mlp_forward_kernel(const MlpFwdParams P)
 {
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(kFwdThreads, ((FUSED && NS == 1) || (NS == 2 && PNR
     constexpr int XPL = kCompact ? kMlpBM * kXS : kTilePlane;          // plane strides (elements) of the input, hidden and head-gradient tiles
     constexpr int HPL = kCompact ? kMlpBM * kHS : kTilePlane;
     constexpr int GPL = kCompact ? kMlpBM * kGS : kTilePlane;
-    constexpr int RING = kCompact ? 3 : PNR_MLP_RING;
+    constexpr int RING = kCompact ? PNR_MLP_COMPACT_RING : PNR_MLP_RING;
     constexpr int kScrElems = kMlpBM * kMlpHead * 2 + NS * kMlpBM * kGS + 2 * 4 * kFwdWaves;      // head rows (float32) | gradient planes | loss sums
     constexpr int kLdsElems = kCompact ? NS * kMlpBM * kHS + kScrElems : NS * kTilePlane + ((FUSED && NS == 1) ? PNR_MLP_LDS_PAD : 0);
     __shared__ __attribute__((aligned(16))) __bf16 lds[kLdsElems];
@@ -1200,7 +1205,7 @@ __global__ __launch_bounds__(kFwdThreads, ((FUSED && NS == 1) || (NS == 2 && PNR
         mlp_barrier();
         MLP_STAMP(12);                    // barrier before the loss
         // ---- the tile's loss on all 512 threads (mlp_tile_loss)
-        mlp_tile_loss<NS>(P, net, row0, tid, hd, gt, rl, wsum, rec_early, GPL, (kCompact && rec_early) ? &lrec : nullptr);
+        mlp_tile_loss<NS>(P, net, row0, tid, hd, gt, rl, wsum, rec_early, GPL, kCompact && rec_early, lrec);
         MLP_STAMP(13);                    // loss done
         mlp_barrier();
         MLP_STAMP(14);                    // barrier after the loss
