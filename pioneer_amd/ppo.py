@@ -64,10 +64,12 @@ class PPOConfig:
 
     @classmethod
     def from_dict(cls, d: Dict) -> "PPOConfig":
-        """From a checkpoint's / params.json's dict: lists back to tuples, r01 / r02's `amp_bf16` read as `hip_kernels`."""
+        """From a checkpoint's / params.json's dict: lists back to tuples, r01 / r02's `amp_bf16` read as `hip_kernels`, r04's "bf16x2" as "f32"."""
         d = dict(d)
         if "amp_bf16" in d:
             d.setdefault("hip_kernels", bool(d.pop("amp_bf16")))
+        if d.get("hip_kernels") == "bf16x2":          # r04's two-bf16-plane form no longer exists: its successor is the two-fp16-plane "f32"
+            d["hip_kernels"] = "f32"
         return cls(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k in cls.__dataclass_fields__})
 
     def mlp_planes(self) -> int:

@@ -27,6 +27,11 @@ def test_config_from_dict_reads_old_checkpoints():
     c = PPOConfig.from_dict({"fcnet_hiddens": [256, 256], "lr": 1e-4, "amp_bf16": False, "some_removed_option": 3})
     assert c.fcnet_hiddens == (256, 256) and c.lr == 1e-4 and c.hip_kernels is False
     assert PPOConfig.from_dict(PPOConfig().__dict__) == PPOConfig()
+    # r04 checkpoints: "bf16x2" (two bf16 planes) no longer exists and reads as its successor, the two-fp16-plane "f32"; the names map to planes
+    assert PPOConfig.from_dict({"hip_kernels": "bf16x2"}).hip_kernels == "f32"
+    assert [PPOConfig(hip_kernels=k).mlp_planes() for k in (True, "bf16", "f32", "bf16x3")] == [1, 1, 2, 3]
+    with pytest.raises(AssertionError):
+        PPOConfig(hip_kernels="fp8").mlp_planes()
     assert not PPOConfig().wants_hip("cpu") and PPOConfig().wants_hip("cuda:0") and not PPOConfig(fcnet_hiddens=(64, 64)).wants_hip("cuda:0")
     m = ActorCritic(PPOConfig())
     mean, log_std, v = m(torch.randn(33, 137))
