@@ -357,10 +357,12 @@ def run_rank(args):
         lane = {"achieved": lane_ops / (avg_launch_ms * 1e-3) / 1e12, "peak": 157.3 / 2, "unit": "T fp32 lane-operations/s",
                 "frac": lane_ops / (avg_launch_ms * 1e-3) / (157.3e12 / 2), "packed_instruction_fraction": DYN_PACKED_FRAC,
                 "note": "packed instructions counted twice.  Reconciles the issue model above with the occupancy A/B (DESIGN_HISTORY r03: 1.75 / 1.73 / "
-                        "1.60 us per 65 536 env-sub-steps at 1 / 2 / 4 waves per SIMD — a second wave buys 1 %): a packed fp32 instruction takes "
-                        "one issue slot but two passes of the SIMD's fp32 lanes, so for this stream (37 % packed) the unit that fills is the lanes of "
-                        "the SIMD, not one wave's issue port — ONE wave per SIMD already keeps them this busy, and more waves can only share them; "
-                        "the 2-cycle issue peak is reached by unpacked streams at eight waves (profiles/r03_a_valu_issue_probe.jsonl)"}
+                        "1.60 us per 65 536 env-sub-steps at 1 / 2 / 4 waves per SIMD — a second wave buys 1 %, four buy 9 %): a SIMD's measured VALU issue "
+                        "rate grows slowly with occupancy — one wave64 instruction per 5.6 cycles for a lone dependent chain, per 4.2 with two waves, 3.0 with "
+                        "four, 2.4 with eight, packed and unpacked alike (profiles/r03_a_valu_issue_probe.jsonl) — and this kernel, ONE wave per SIMD with "
+                        "its own instruction-level parallelism, already issues one per 4.3 cycles: the rate two waves reach together, so a second wave has "
+                        "nothing to add.  The issue model's 2-cycle peak needs >= 8 waves per SIMD, which 244-256 registers per lane rule out; of the rate "
+                        "reachable at one or two waves per SIMD the kernel is at 0.98"}
         return {"bound": "valu", "achieved": ach / 1e9, "peak": simds * clock / 2 / 1e9, "unit": "G wave-instructions/s",
                 "frac": ach / (simds * clock / 2), "frac_of_single_wave_issue": cnt["frac_of_single_wave_issue"], "fp32_lanes": lane,
                 "source": "VALU wave-instructions per 65 536-env launch from " + src + "; duration = this run's HIP events; peak = one "

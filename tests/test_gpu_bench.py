@@ -71,7 +71,7 @@ def test_config3_anchor_and_dynamics_lane_roofline_are_in_the_line():
     else:
         lanes = rf["fp32_lanes"]
         assert lanes["unit"].startswith("T fp32 lane-operations") and 0.05 < lanes["frac"] < 1.0 and abs(lanes["peak"] - 78.65) < 0.1
-        assert "second wave" in lanes["note"]
+        assert "second wave" in lanes["note"] and "valu_issue_probe" in lanes["note"]
 
 
 def test_two_ranks_self_launched_on_the_metric_configuration():
